@@ -1,0 +1,211 @@
+"""Flat weight container (checkpoint-variable name -> fp32 array) and a seeded generator.
+
+No checkpoint ships with the reference (weights sit behind a Baidu-pan link, README.md:47-48), so
+parity and throughput are measured on seeded synthetic weights of the exact reference shapes.  The
+tensor NAMES are the reference's own checkpoint variable names, so a real-checkpoint importer is a
+rename-free dict fill:
+
+* zk / lds: TF1 variable names as created by ``code/imagebert_zk/pixelbert.py:200-266``,
+  ``model_triple.py:62,189-193``, ``code/imagebert_lds/src/pixelmodel.py:196-270,439-498`` and
+  ``run_pretraining_predict_score.py:484-490`` (dense ``kernel`` is [in, out]).
+* lxmert: ``KDDModel.state_dict()`` keys (torch ``Linear.weight`` is [out, in]); the unused MLM /
+  AM-softmax heads (``kdd_model.py:174-181``) are not generated.
+
+The generator is counter-based (splitmix64 keyed by tensor name) so the same tensors exist in this
+container and on the GPU box without shipping them.  Matrices that feed MFMA are rounded to
+bf16-representable fp32 values: bf16 is this build's *storage format* for GEMM weights, and both the
+oracle and the HIP path consume exactly the same numbers (DESIGN.md "precision modes").
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from .config import FEAT_DIM, HIDDEN, LABEL_LEN, LdsConfig, LxmertConfig, ZkConfig
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def _key(name: str, seed: int) -> np.uint64:
+    h = hashlib.sha256(("%d|%s" % (seed, name)).encode()).digest()
+    return np.uint64(int.from_bytes(h[:8], "little"))
+
+
+def uniform01(name: str, n: int, seed: int, stream: int = 0) -> np.ndarray:
+    """n doubles in (0, 1), a pure function of (name, seed, stream, index)."""
+    with np.errstate(over="ignore"):
+        ctr = np.arange(n, dtype=np.uint64) * np.uint64(2) + np.uint64(stream)
+        bits = _splitmix64(_splitmix64(ctr ^ _key(name, seed)))
+    return ((bits >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def normal(name: str, shape, seed: int, std: float = 1.0, mean: float = 0.0) -> np.ndarray:
+    n = int(np.prod(shape))
+    u1 = uniform01(name, n, seed, 0)
+    u2 = uniform01(name, n, seed, 1)
+    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return (mean + std * z).reshape(shape).astype(np.float32)
+
+
+def round_to_bf16(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16, returned as fp32 (low 16 mantissa bits zero)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    b = x.view(np.uint32).astype(np.uint64)
+    b = (b + np.uint64(0x7FFF) + ((b >> np.uint64(16)) & np.uint64(1))) & np.uint64(0xFFFF0000)
+    return b.astype(np.uint32).view(np.float32).reshape(x.shape)
+
+
+class _Gen:
+    def __init__(self, seed: int, bf16_matrices: bool):
+        self.seed, self.bf16 = seed, bf16_matrices
+        self.out: dict[str, np.ndarray] = {}
+
+    def mat(self, name, shape, std):
+        w = normal(name, shape, self.seed, std)
+        self.out[name] = round_to_bf16(w) if self.bf16 else w
+
+    def vec(self, name, shape, std, mean=0.0):
+        self.out[name] = normal(name, shape, self.seed, std, mean)
+
+    def ln_tf(self, scope):
+        self.vec(scope + "/gamma", (HIDDEN,), 0.1, 1.0)
+        self.vec(scope + "/beta", (HIDDEN,), 0.1)
+
+    def ln_pt(self, scope, n=HIDDEN):
+        self.vec(scope + ".weight", (n,), 0.1, 1.0)
+        self.vec(scope + ".bias", (n,), 0.1)
+
+
+# std choices: fan-in scaled so post-LN activations, attention logits (std ~ 2) and the final
+# 2-way logits stay O(1) through the whole depth -- a 1e-3 *relative* logit check is then meaningful.
+_STD_H = 0.04      # fan-in 768
+_STD_I = 0.02      # fan-in 3072
+_STD_F = 0.03      # fan-in 2048, inputs relu(N(0,1))
+_STD_B = 0.02      # biases
+_STD_E = 0.05      # embedding tables
+
+
+def _tf_encoder(g: _Gen, layers: int, inter: int):
+    for i in range(layers):
+        p = "bert/encoder/layer_%d" % i
+        for n in ("query", "key", "value"):
+            g.mat("%s/attention/self/%s/kernel" % (p, n), (HIDDEN, HIDDEN), _STD_H)
+            g.vec("%s/attention/self/%s/bias" % (p, n), (HIDDEN,), _STD_B)
+        g.mat(p + "/attention/output/dense/kernel", (HIDDEN, HIDDEN), _STD_H)
+        g.vec(p + "/attention/output/dense/bias", (HIDDEN,), _STD_B)
+        g.ln_tf(p + "/attention/output/LayerNorm")
+        g.mat(p + "/intermediate/dense/kernel", (HIDDEN, inter), _STD_H)
+        g.vec(p + "/intermediate/dense/bias", (inter,), _STD_B)
+        g.mat(p + "/output/dense/kernel", (inter, HIDDEN), _STD_I)
+        g.vec(p + "/output/dense/bias", (HIDDEN,), _STD_B)
+        g.ln_tf(p + "/output/LayerNorm")
+    g.mat("bert/pooler/dense/kernel", (HIDDEN, HIDDEN), _STD_H)
+    g.vec("bert/pooler/dense/bias", (HIDDEN,), _STD_B)
+
+
+def _tf_embeddings(g: _Gen, cfg):
+    g.vec("bert/embeddings/word_embeddings", (cfg.vocab, HIDDEN), _STD_E)
+    g.vec("bert/embeddings/token_type_embeddings", (cfg.type_vocab, HIDDEN), _STD_E)
+    g.vec("bert/embeddings/position_embeddings", (cfg.max_pos, HIDDEN), _STD_E)
+    g.ln_tf("bert/embeddings/LayerNorm")
+
+
+def make_zk_weights(cfg: ZkConfig = ZkConfig(), seed: int = 20200823, bf16_matrices: bool = True):
+    g = _Gen(seed, bf16_matrices)
+    _tf_embeddings(g, cfg)
+    g.mat("kdd_conv1/weights", (1, LABEL_LEN, HIDDEN, HIDDEN), 0.25)  # inputs are 0.05-std embeddings
+    g.vec("kdd_conv1/biases", (HIDDEN,), 0.1)
+    g.vec("kdd_dense1/weights", (cfg.box_dim, HIDDEN), 0.5)
+    g.vec("kdd_dense1/biases", (HIDDEN,), _STD_B)
+    g.mat("kdd_conv2/weights", (1, 1, FEAT_DIM, HIDDEN), _STD_F)
+    g.vec("kdd_conv2/biases", (HIDDEN,), 0.1)
+    g.mat("kdd_featureemb/fully_connected/weights", (HIDDEN, HIDDEN), _STD_H)
+    g.vec("kdd_featureemb/fully_connected/biases", (HIDDEN,), _STD_B)
+    _tf_encoder(g, cfg.layers, cfg.inter)
+    g.vec("cls/seq_relationship/am_kernel", (HIDDEN, 2), 0.05)
+    return g.out
+
+
+def make_lds_weights(cfg: LdsConfig = LdsConfig(), seed: int = 20200823, bf16_matrices: bool = True):
+    g = _Gen(seed + 1, bf16_matrices)
+    _tf_embeddings(g, cfg)
+    g.vec("bert/embeddings/word_embeddings_labelembedding", (LABEL_LEN, 1), 2.0)
+    g.mat("featureemb/fully_connected/weights", (FEAT_DIM, HIDDEN), _STD_F)
+    g.vec("featureemb/fully_connected/biases", (HIDDEN,), 0.1)
+    _tf_encoder(g, cfg.layers, cfg.inter)
+    g.vec("cls/seq_relationship/output_weights", (2, HIDDEN), 0.05)
+    g.vec("cls/seq_relationship/output_bias", (2,), 0.1)
+    return g.out
+
+
+def _pt_att(g: _Gen, p: str, sub: str):
+    for n in ("query", "key", "value"):
+        g.mat("%s.%s.%s.weight" % (p, sub, n), (HIDDEN, HIDDEN), _STD_H)
+        g.vec("%s.%s.%s.bias" % (p, sub, n), (HIDDEN,), _STD_B)
+    g.mat(p + ".output.dense.weight", (HIDDEN, HIDDEN), _STD_H)
+    g.vec(p + ".output.dense.bias", (HIDDEN,), _STD_B)
+    g.ln_pt(p + ".output.LayerNorm")
+
+
+def _pt_ffn(g: _Gen, inter_name: str, out_name: str, inter: int):
+    g.mat(inter_name + ".dense.weight", (inter, HIDDEN), _STD_H)
+    g.vec(inter_name + ".dense.bias", (inter,), _STD_B)
+    g.mat(out_name + ".dense.weight", (HIDDEN, inter), _STD_I)
+    g.vec(out_name + ".dense.bias", (HIDDEN,), _STD_B)
+    g.ln_pt(out_name + ".LayerNorm")
+
+
+def make_lxmert_weights(cfg: LxmertConfig = LxmertConfig(), seed: int = 20200823,
+                        bf16_matrices: bool = True):
+    g = _Gen(seed + 2, bf16_matrices)
+    b = "lxrt_encoder.model.bert."
+    g.vec(b + "embeddings.word_embeddings.weight", (cfg.vocab, HIDDEN), _STD_E)
+    g.vec(b + "embeddings.position_embeddings.weight", (cfg.max_pos, HIDDEN), _STD_E)
+    g.vec(b + "embeddings.token_type_embeddings.weight", (cfg.type_vocab, HIDDEN), _STD_E)
+    g.ln_pt(b + "embeddings.LayerNorm")
+    v = b + "encoder.visn_fc."
+    g.mat(v + "visn_fc.weight", (HIDDEN, FEAT_DIM), _STD_F)
+    g.vec(v + "visn_fc.bias", (HIDDEN,), 0.1)
+    g.ln_pt(v + "visn_layer_norm")
+    g.vec(v + "box_fc.weight", (HIDDEN, cfg.box_dim), 0.5)
+    g.vec(v + "box_fc.bias", (HIDDEN,), _STD_B)
+    g.ln_pt(v + "box_layer_norm")
+    g.vec(v + "label_conv.weight", (1, LABEL_LEN, 1, 1), 0.5)
+    g.vec(v + "label_conv.bias", (1,), 0.1)
+    g.mat(v + "label_fc.weight", (HIDDEN, HIDDEN), _STD_H)
+    g.vec(v + "label_fc.bias", (HIDDEN,), _STD_B)
+    g.ln_pt(v + "label_layer_norm")
+    for kind, n in (("layer", cfg.l_layers), ("r_layers", cfg.r_layers)):
+        for i in range(n):
+            p = "%sencoder.%s.%d" % (b, kind, i)
+            _pt_att(g, p + ".attention", "self")
+            _pt_ffn(g, p + ".intermediate", p + ".output", cfg.inter)
+    for i in range(cfg.x_layers):
+        p = "%sencoder.x_layers.%d" % (b, i)
+        _pt_att(g, p + ".visual_attention", "att")
+        _pt_att(g, p + ".lang_self_att", "self")
+        _pt_att(g, p + ".visn_self_att", "self")
+        _pt_ffn(g, p + ".lang_inter", p + ".lang_output", cfg.inter)
+        _pt_ffn(g, p + ".visn_inter", p + ".visn_output", cfg.inter)
+    g.mat(b + "pooler.dense.weight", (HIDDEN, HIDDEN), _STD_H)
+    g.vec(b + "pooler.dense.bias", (HIDDEN,), _STD_B)
+    g.mat("logit_fc.0.weight", (2 * HIDDEN, HIDDEN), _STD_H)
+    g.vec("logit_fc.0.bias", (2 * HIDDEN,), _STD_B)
+    g.ln_pt("logit_fc.2", 2 * HIDDEN)
+    g.vec("logit_fc.3.weight", (2, 2 * HIDDEN), 0.03)
+    g.vec("logit_fc.3.bias", (2,), 0.1)
+    return g.out
+
+
+def make_weights(cfg, seed: int = 20200823, bf16_matrices: bool = True):
+    return {"zk": make_zk_weights, "lds": make_lds_weights, "lxmert": make_lxmert_weights}[cfg.name](
+        cfg, seed, bf16_matrices)
