@@ -1,0 +1,163 @@
+"""bench.py -- pairs scored per second on the headline workload of BASELINE.json.
+
+Workload (config.workload): imagebert_zk, full 12-layer / 768 / 3072 model, 1000 synthetic queries x
+30 candidates per GPU (<= 10 boxes x 2048-d fp32 features), inputs resident in HBM before the timed
+region.  One "step" = one scoring pass over the rank's whole 30 000-pair set, plus the all-gather of
+scores when N > 1 (queries are sharded by rank: weak scaling).  Prints ONE JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--model zk|lds|lxmert] [--precision 1|2]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from kddcup_2020_multimodalitiesrecall_2nd_place_amd import scorers, sharding, synth, weights  # noqa: E402
+from kddcup_2020_multimodalitiesrecall_2nd_place_amd.config import (FEAT_DIM, N_BOX, LdsConfig, LxmertConfig,  # noqa: E402
+                                                                    ZkConfig, flops_per_pair)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+BASELINE_FLOPS = {"zk": 5.174e9, "lds": 6.886e9, "lxmert": 6.829e9}
+
+
+def device_feats(ps, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    f = torch.randn((ps.n, N_BOX, FEAT_DIM), device=device, dtype=torch.float32, generator=g).clamp_(min=0)
+    live = torch.arange(N_BOX, device=device)[None, :] < torch.as_tensor(ps.num_boxes, device=device)[:, None]
+    return f * live[:, :, None]
+
+
+def prepare(scorer, cfg, ps, feats):
+    ps.feats = feats
+    b = synth.batch_for(cfg, ps)
+    key = {"zk": "np_images_features", "lds": "features", "lxmert": "feats"}[cfg.name]
+    b[key] = feats
+    if cfg.name == "zk":
+        return scorer.prepare(b["num_boxes"], b["np_boxes_5"], b[key], b["np_idx_class_labels"], b["np_idx_query_"],
+                              b["len_query_"], b["labels"], b["segment_ids"])
+    if cfg.name == "lds":
+        return scorer.prepare(b)
+    return scorer.prepare(b["input_ids"], b["boxes_label_input_ids"], b["input_mask"], b[key], b["boxes"],
+                          b["visual_attention_mask"])
+
+
+def cpu_baseline(cfg, w, budget_s=15.0):
+    """The oracle's torch-fp32 port of the same forward on this box's host cores (bounded sample)."""
+    from oracle import np_models, torch_models  # checker / baseline only
+    cores = torch.get_num_threads()
+    ps = synth.make_pairs(3, 30, tag="/cpu")  # 90 pairs of config 1's shape
+    b = synth.batch_for(cfg, ps)
+    run = (lambda bb: torch_models.forward(cfg, w, bb)) if cfg.name != "lxmert" else \
+        (lambda bb: np_models.forward(cfg, w, bb, np.float32))
+    t0 = time.time()
+    run({k: (v[:30] if hasattr(v, "__len__") and len(v) == ps.n else v) for k, v in b.items()})
+    t30 = time.time() - t0
+    reps = int(max(1, min(30, budget_s / max(t30 * 3, 1e-3))))
+    t0 = time.time()
+    for _ in range(reps):
+        run(b)
+    dt = time.time() - t0
+    return {"value": round(reps * ps.n / dt, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d x 90 pairs (3 queries x 30 candidates), torch fp32 restatement of %s, batch 90" % (reps, cfg.name)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="zk")
+    ap.add_argument("--precision", type=int, default=2)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--cands", type=int, default=30)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = {"zk": ZkConfig(), "lds": LdsConfig(), "lxmert": LxmertConfig()}[a.model]
+    w = weights.make_weights(cfg)
+    scorer = scorers.make_scorer(cfg, w, precision=a.precision, device=local, chunk_pairs=a.chunk)
+    # rank r owns queries [r*Q, (r+1)*Q) of the logical N*Q-query job (weak scaling)
+    ps = synth.make_pairs(a.queries, a.cands, tag="/bench%d" % rank, with_feats=False, query_offset=rank * a.queries)
+    feats = device_feats(ps, dev, 20200823 + rank)
+    prep = prepare(scorer, cfg, ps, feats)
+    qid = torch.as_tensor(ps.query_id, device=dev)
+    pid = torch.as_tensor(ps.product_id, device=dev)
+
+    def step(with_ids=False):
+        logits, probs = scorer.score_prepared(prep)
+        score = probs[:, 1].contiguous()
+        return sharding.gather_scores(score, qid if with_ids else None, pid if with_ids else None)
+
+    for i in range(a.warmup):
+        step(with_ids=(i == 0))
+    scorer.handle.gemm_timing(True, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    gemm_ms, gemm_n, gemm_fl = scorer.handle.gemm_timing(False, True, read=True)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    pairs_total = ps.n * world * a.steps
+    value = pairs_total / dt
+
+    if rank == 0:
+        fpp = BASELINE_FLOPS[cfg.name]
+        assert abs(flops_per_pair(cfg) / fpp - 1) < 5e-3
+        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        res = {
+            "metric": "query-image pairs scored/sec (whole node)", "value": round(value, 1), "unit": "pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 MFMA operands (weights bf16; activations %s), fp32 accumulate/residual/LN/softmax"
+                     % ("split hi+lo bf16, 2 passes" if a.precision == 2 else "bf16, 1 pass"),
+            "data": "synthetic",
+            "config": {"workload": "imagebert_%s 12-layer, %d queries x %d candidates per GPU (<=10 boxes x 2048-d), "
+                                   "seeded weights, inputs HBM-resident" % (cfg.name, a.queries, a.cands)
+                       if cfg.name != "lxmert" else "lxmert 9/5/5, %d queries x %d candidates per GPU" % (a.queries, a.cands),
+                       "pairs_per_gpu": ps.n, "precision_mode": a.precision, "parallelism": "query-sharded dp%d" % world},
+            "model_tflops_per_gpu": round(value / world * fpp / 1e12, 2),
+            "model_mfma_frac": round(value / world * fpp / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<%d,*> (all dense contractions)" % a.precision,
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches": int(gemm_n), "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
+                         "algorithmic_flops_per_launch": round(gemm_fl / max(gemm_n, 1), 1)},
+        }
+        if world == 1 and not a.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(cfg, w)
+        print(json.dumps(res))
+    scorer.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

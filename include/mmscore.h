@@ -1,0 +1,136 @@
+/*
+ * libmmscore -- C ABI of the MI355X-native (gfx950) cross-modal pair scorer.
+ *
+ * The reference (zuokai/KDDCUP_2020_MultimodalitiesRecall_2nd_Place) has no FFI of its own: its
+ * hot path is entered through three Python/TF1/PyTorch call surfaces.  Each entry point below
+ * replaces one of them (paths relative to the reference root):
+ *
+ *   mms_score_zk      <- model_triple.model_attention_channel_e(...)  code/imagebert_zk/model_triple.py:162-214,
+ *                        driven by sess.run([probs, ...])              code/imagebert_zk/evaluate_normal.py:227-238
+ *   mms_score_lds     <- bertmodel(... features ...)                   code/imagebert_lds/src/run_pretraining_predict_score.py:288-336,
+ *                        get_next_sentence_output                      :479-501, sess.run :566-570
+ *   mms_score_lxmert  <- KDDModel.forward(...)                         code/lxmert/src/tasks/kdd_model.py:183-214,
+ *                        called from KDD.predict                       :97-100
+ *   mms_load_weight   <- tf.train.Saver.restore / load_state_dict      evaluate_normal.py:204-212,
+ *                        run_pretraining_predict_score.py:558-563, kdd_model.py:131-152
+ *                        (tensor names are the reference's own checkpoint variable names)
+ *
+ * Conventions
+ *   - plain C, no torch / STL types; every function returns an int status (0 = MMS_OK) and never
+ *     throws; mms_last_error(h) gives the message of the last failing call on that handle.
+ *   - all batch pointers are DEVICE pointers (HBM-resident inputs) unless the field says host;
+ *     the caller owns every input/output buffer, the handle owns weights and workspace.
+ *   - one handle per GPU/stream; calls on one handle must be serialised by the caller; kernels are
+ *     enqueued asynchronously on the hipStream_t passed as `stream` (NULL = default stream).
+ *   - integer dtypes are the reference feed dtypes (zk: int32 ids, int64 labels; lds/lxmert: int64).
+ */
+#ifndef MMSCORE_H
+#define MMSCORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMS_OK 0
+#define MMS_ERR_ARG 1
+#define MMS_ERR_WEIGHT 2
+#define MMS_ERR_HIP 3
+#define MMS_ERR_STATE 4
+
+#define MMS_MODEL_ZK 0
+#define MMS_MODEL_LDS 1
+#define MMS_MODEL_LXMERT 2
+
+typedef struct mms_handle mms_handle;
+
+typedef struct mms_config {
+    int32_t model;            /* MMS_MODEL_* */
+    int32_t layers;           /* zk/lds: encoder layers (12); lxmert: language layers (9) */
+    int32_t r_layers;         /* lxmert: relational (vision) layers (5) */
+    int32_t x_layers;         /* lxmert: cross-modality layers (5) */
+    int32_t vocab;            /* 21128 */
+    int32_t inter;            /* 3072, multiple of 128 */
+    int32_t max_pos;          /* 512 */
+    int32_t type_vocab;       /* 2 */
+    int32_t text_len;         /* zk/lds 20, lxmert 23 */
+    int32_t precision;        /* 1: bf16 activations, one MFMA pass; 2: split-bf16 (hi+lo), two passes */
+    int32_t chunk_pairs;      /* pairs per internal launch wave (0 = default 4096) */
+    int32_t stop_after;       /* debug: run only the first n encoder layers (-1 = all) and skip nothing else */
+    int32_t device;           /* HIP device ordinal */
+} mms_config;
+
+/* zk feed, code/imagebert_zk/evaluate_normal.py:141-152.  np_idx_class_labels [B,10,8] is passed
+ * de-duplicated: uniq_label_ids [U,8] + label_index [B,10] (U = B*10 and index = arange reproduces
+ * the dense graph; the label-text encoder depends only on the 8-id tuple). */
+typedef struct mms_zk_batch {
+    int64_t n_pairs;
+    const int32_t* num_boxes;      /* [B] */
+    const float* boxes_5;          /* [B,10,5] */
+    const float* feats;            /* [B,10,2048] */
+    const int32_t* uniq_label_ids; /* [U,8] */
+    int64_t n_uniq_labels;
+    const int32_t* label_index;    /* [B,10] -> row of uniq_label_ids */
+    const int32_t* query_ids;      /* [B,text_len] */
+    const int32_t* len_query;      /* [B] */
+    const int64_t* labels;         /* [B] (AM-softmax head is label dependent, model_triple.py:68-81) */
+    const int32_t* segment_ids;    /* [B,text_len+10] */
+} mms_zk_batch;
+
+/* lds feed, code/imagebert_lds/src/run_pretraining_predict_score.py:526-548 (boxes is unused there) */
+typedef struct mms_lds_batch {
+    int64_t n_pairs;
+    const int64_t* input_ids;      /* [B,text_len] */
+    const int64_t* segment_ids;    /* [B,text_len] */
+    const float* features;         /* [B,10,2048] */
+    const int64_t* labelfeat;      /* [B,10,8] */
+} mms_lds_batch;
+
+/* lxmert feed, code/lxmert/src/tasks/kdd_model.py:183-186 (label text de-duplicated as for zk) */
+typedef struct mms_lxmert_batch {
+    int64_t n_pairs;
+    const int64_t* input_ids;      /* [B,text_len] */
+    const int64_t* input_mask;     /* [B,text_len] */
+    const int64_t* uniq_label_ids; /* [U,8] */
+    int64_t n_uniq_labels;
+    const int32_t* label_index;    /* [B,10] */
+    const float* feats;            /* [B,10,2048] */
+    const float* boxes;            /* [B,10,4] */
+    const float* visual_attention_mask; /* [B,10] */
+} mms_lxmert_batch;
+
+int mms_version(void);
+const char* mms_global_error(void);              /* message of the last failing mms_create */
+
+int mms_create(const mms_config* cfg, mms_handle** out);
+void mms_destroy(mms_handle* h);
+const char* mms_last_error(const mms_handle* h);
+
+/* host fp32 tensor, copied; names = reference checkpoint variable names (see weights.py) */
+int mms_load_weight(mms_handle* h, const char* name, const float* host_data, const int64_t* shape, int32_t rank);
+/* builds the device-resident model: bf16 [N][K] GEMM matrices (fused QKV), fp32 tables/vectors */
+int mms_finalize(mms_handle* h);
+
+/* logits / probs: device fp32 [B,2] (probs may be NULL) */
+int mms_score_zk(mms_handle* h, const mms_zk_batch* b, float* logits, float* probs, void* stream);
+int mms_score_lds(mms_handle* h, const mms_lds_batch* b, float* logits, float* probs, void* stream);
+int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, float* probs, void* stream);
+
+/* accumulated hipEvent time (ms) and launch count of the GEMM kernels since the last reset;
+ * enable = 1 brackets every GEMM launch with events on its stream (bench / roofline only) */
+int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out, int64_t* launches_out, double* flops_out);
+
+/* ---- debug / test hooks (kernel-level parity tests call the same kernels the scorers launch) ---- */
+int mms_debug_read_x(mms_handle* h, float* dst_dev, int64_t rows, void* stream); /* current hidden state -> fp32 [rows,768] */
+int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const float* w_f32_nk, int64_t N,
+                 const float* bias, const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes,
+                 float* c_f32, void* stream);
+int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B, int32_t Sq, int32_t Sk,
+                      const float* key_add, float* out_f32, void* stream);
+int mms_dbg_layernorm(const float* x, const float* gamma, const float* beta, int64_t M, float* out_f32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -112,7 +112,7 @@ def flops_per_pair(cfg) -> float:
         return cfg.layers * layer(S) + emb + head
     if cfg.name == "lxmert":
         L, V = cfg.text_len, N_BOX
-        emb = 2 * V * FEAT_DIM * H + 2 * V * cfg.box_dim * H
+        emb = 2 * V * FEAT_DIM * H + 2 * V * cfg.box_dim * H + 2 * V * H * H  # visn_fc, box_fc, label_fc
         xl = 0
         # cross: q on own rows, k/v on other rows, out dense on own rows
         for sq, sk in ((L, V), (V, L)):

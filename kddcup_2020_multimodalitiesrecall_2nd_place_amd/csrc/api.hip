@@ -1,0 +1,824 @@
+// libmmscore C ABI: handle, weight container, workspace and the launch plans of the three forwards.
+// See include/mmscore.h for the contract and the reference call sites each entry point replaces.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mmscore.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int H = MMS_HIDDEN;
+thread_local std::string g_err;
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct Planes {
+    bf16* hi = nullptr;
+    bf16* lo = nullptr;
+    Planes at(long long elem_off) const { Planes p; p.hi = hi + elem_off; p.lo = lo + elem_off; return p; }
+};
+
+struct AttW { bf16* wqkv; float* bqkv; bf16* wo; float* bo; float* g; float* b; };
+struct FfnW { bf16* wi; float* bi; bf16* wd; float* bd; float* g; float* b; };
+struct LayerW { AttW att; FfnW ffn; };
+struct XLayerW { AttW cross, lang_self, visn_self; FfnW lang_ffn, visn_ffn; };
+
+inline uint16_t f2bf(float f) {  // round-to-nearest-even, same as v_cvt_pk_bf16_f32
+    uint32_t u; std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+}  // namespace
+
+struct mms_handle {
+    mms_config cfg{};
+    std::string err;
+    std::unordered_map<std::string, HostTensor> host;
+    std::vector<void*> w_allocs, ws_allocs, lab_allocs;
+    bool finalized = false;
+    int nsplit = 2;
+
+    // ---- weights (device) ----
+    float *E = nullptr, *type_tab = nullptr, *pos_tab = nullptr, *emb_g = nullptr, *emb_b = nullptr;
+    std::vector<LayerW> layers, r_layers;
+    std::vector<XLayerW> x_layers;
+    bf16* w_pool = nullptr; float* b_pool = nullptr;
+    // zk
+    bf16 *w_conv1 = nullptr, *w_conv2 = nullptr, *w_femb = nullptr;
+    float *b_conv1 = nullptr, *b_conv2 = nullptr, *b_femb = nullptr, *w_dense1 = nullptr, *b_dense1 = nullptr, *am_kernel = nullptr;
+    // lds
+    bf16* w_feat = nullptr; float *b_feat = nullptr, *w_lab8 = nullptr, *w_cls = nullptr, *b_cls = nullptr;
+    // lxmert
+    bf16 *w_visn = nullptr, *w_labfc = nullptr, *w_fc0 = nullptr;
+    float *b_visn = nullptr, *g_visn = nullptr, *be_visn = nullptr, *w_box = nullptr, *b_box = nullptr, *g_box = nullptr,
+          *be_box = nullptr, *w_lconv = nullptr, *b_lconv = nullptr, *b_labfc = nullptr, *g_lab = nullptr, *be_lab = nullptr,
+          *b_fc0 = nullptr, *g_fc2 = nullptr, *be_fc2 = nullptr, *w_fc3 = nullptr, *b_fc3 = nullptr;
+
+    // ---- workspace (device), sized for ws_pairs ----
+    int64_t ws_pairs = 0;
+    Planes x, ctx, y, mid;
+    float *qkv = nullptr, *t = nullptr, *key_add = nullptr, *key_add2 = nullptr, *pooled = nullptr, *hbuf = nullptr;
+    int64_t x_rows = 0;  // rows of the hidden state per pair-chunk (for mms_debug_read_x)
+    // label-text workspace, sized for lab_cap unique labels
+    int64_t lab_cap = 0;
+    Planes lab_planes; float *lab_f32 = nullptr, *lab_feat = nullptr; int64_t lab_feat_cap = 0;
+
+    // ---- gemm timing ----
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double gemm_flops = 0;
+    int64_t gemm_launches = 0;
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                                  \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return (h)->fail(MMS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+int dev_alloc(mms_handle* h, std::vector<void*>& pool, void** out, size_t bytes) {
+    void* p = nullptr;
+    HIP_TRY(h, hipMalloc(&p, bytes ? bytes : 16));
+    pool.push_back(p);
+    *out = p;
+    return MMS_OK;
+}
+void free_pool(std::vector<void*>& pool) {
+    for (void* p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+const HostTensor* find(mms_handle* h, const std::string& name) {
+    auto it = h->host.find(name);
+    return it == h->host.end() ? nullptr : &it->second;
+}
+
+int need(mms_handle* h, const std::string& name, std::vector<int64_t> shape, const HostTensor** out) {
+    const HostTensor* t = find(h, name);
+    if (!t) return h->fail(MMS_ERR_WEIGHT, "missing weight: " + name);
+    if (t->shape != shape) {
+        std::string s = "weight " + name + " has shape [";
+        for (auto d : t->shape) s += std::to_string(d) + ",";
+        s += "] expected [";
+        for (auto d : shape) s += std::to_string(d) + ",";
+        return h->fail(MMS_ERR_WEIGHT, s + "]");
+    }
+    *out = t;
+    return MMS_OK;
+}
+
+int upload_f32(mms_handle* h, const float* src, size_t n, float** out) {
+    void* p;
+    if (int rc = dev_alloc(h, h->w_allocs, &p, n * 4)) return rc;
+    HIP_TRY(h, hipMemcpy(p, src, n * 4, hipMemcpyHostToDevice));
+    *out = (float*)p;
+    return MMS_OK;
+}
+int vec(mms_handle* h, const std::string& name, int64_t n, float** out) {
+    const HostTensor* t;
+    if (int rc = need(h, name, {n}, &t)) return rc;
+    return upload_f32(h, t->data.data(), (size_t)n, out);
+}
+int tab(mms_handle* h, const std::string& name, std::vector<int64_t> shape, float** out) {
+    const HostTensor* t;
+    if (int rc = need(h, name, shape, &t)) return rc;
+    return upload_f32(h, t->data.data(), (size_t)t->numel(), out);
+}
+
+// Build a bf16 [N][K] device matrix from a list of host sources.  Each source contributes n_i output
+// rows; `in_out` sources are [K, n_i] (TF dense kernel), otherwise [n_i, K] (torch Linear weight).
+struct MatSrc { const float* p; int64_t n; bool in_out; };
+int upload_mat(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, bf16** out) {
+    int64_t N = 0;
+    for (auto& s : srcs) N += s.n;
+    std::vector<uint16_t> buf((size_t)(N * K));
+    int64_t r0 = 0;
+    for (auto& s : srcs) {
+        for (int64_t n = 0; n < s.n; ++n)
+            for (int64_t k = 0; k < K; ++k)
+                buf[(size_t)((r0 + n) * K + k)] = f2bf(s.in_out ? s.p[k * s.n + n] : s.p[n * K + k]);
+        r0 += s.n;
+    }
+    void* p;
+    if (int rc = dev_alloc(h, h->w_allocs, &p, buf.size() * 2)) return rc;
+    HIP_TRY(h, hipMemcpy(p, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
+    *out = (bf16*)p;
+    return MMS_OK;
+}
+int mat(mms_handle* h, const std::string& name, int64_t N, int64_t K, bool in_out, bf16** out,
+        std::vector<int64_t> shape_override = {}) {
+    const HostTensor* t;
+    std::vector<int64_t> shape = shape_override.empty() ? (in_out ? std::vector<int64_t>{K, N} : std::vector<int64_t>{N, K})
+                                                        : shape_override;
+    if (int rc = need(h, name, shape, &t)) return rc;
+    return upload_mat(h, {{t->data.data(), N, in_out}}, K, out);
+}
+int cat_vec(mms_handle* h, const std::vector<std::string>& names, int64_t n_each, float** out) {
+    std::vector<float> buf;
+    for (auto& nm : names) {
+        const HostTensor* t;
+        if (int rc = need(h, nm, {n_each}, &t)) return rc;
+        buf.insert(buf.end(), t->data.begin(), t->data.end());
+    }
+    return upload_f32(h, buf.data(), buf.size(), out);
+}
+
+// attention block weights; tf: scope names with /kernel [in,out]; pt: module names with .weight [out,in]
+int load_att(mms_handle* h, bool tf, const std::string& self_scope, const std::string& out_scope, AttW* w) {
+    const char* qkv[3] = {"query", "key", "value"};
+    std::vector<MatSrc> srcs;
+    std::vector<std::string> bnames;
+    for (int i = 0; i < 3; ++i) {
+        const HostTensor* t;
+        const std::string nm = self_scope + (tf ? "/" : ".") + qkv[i] + (tf ? "/kernel" : ".weight");
+        if (int rc = need(h, nm, {H, H}, &t)) return rc;
+        srcs.push_back({t->data.data(), H, tf});
+        bnames.push_back(self_scope + (tf ? "/" : ".") + qkv[i] + (tf ? "/bias" : ".bias"));
+    }
+    if (int rc = upload_mat(h, srcs, H, &w->wqkv)) return rc;
+    if (int rc = cat_vec(h, bnames, H, &w->bqkv)) return rc;
+    if (int rc = mat(h, out_scope + (tf ? "/dense/kernel" : ".dense.weight"), H, H, tf, &w->wo)) return rc;
+    if (int rc = vec(h, out_scope + (tf ? "/dense/bias" : ".dense.bias"), H, &w->bo)) return rc;
+    if (int rc = vec(h, out_scope + (tf ? "/LayerNorm/gamma" : ".LayerNorm.weight"), H, &w->g)) return rc;
+    if (int rc = vec(h, out_scope + (tf ? "/LayerNorm/beta" : ".LayerNorm.bias"), H, &w->b)) return rc;
+    return MMS_OK;
+}
+int load_ffn(mms_handle* h, bool tf, const std::string& inter, const std::string& out, FfnW* w) {
+    const int64_t I = h->cfg.inter;
+    if (int rc = mat(h, inter + (tf ? "/dense/kernel" : ".dense.weight"), I, H, tf, &w->wi)) return rc;
+    if (int rc = vec(h, inter + (tf ? "/dense/bias" : ".dense.bias"), I, &w->bi)) return rc;
+    if (int rc = mat(h, out + (tf ? "/dense/kernel" : ".dense.weight"), H, I, tf, &w->wd)) return rc;
+    if (int rc = vec(h, out + (tf ? "/dense/bias" : ".dense.bias"), H, &w->bd)) return rc;
+    if (int rc = vec(h, out + (tf ? "/LayerNorm/gamma" : ".LayerNorm.weight"), H, &w->g)) return rc;
+    if (int rc = vec(h, out + (tf ? "/LayerNorm/beta" : ".LayerNorm.bias"), H, &w->b)) return rc;
+    return MMS_OK;
+}
+
+int finalize_tf_common(mms_handle* h) {
+    const mms_config& c = h->cfg;
+    if (int rc = tab(h, "bert/embeddings/word_embeddings", {c.vocab, H}, &h->E)) return rc;
+    if (int rc = tab(h, "bert/embeddings/token_type_embeddings", {c.type_vocab, H}, &h->type_tab)) return rc;
+    if (int rc = tab(h, "bert/embeddings/position_embeddings", {c.max_pos, H}, &h->pos_tab)) return rc;
+    if (int rc = vec(h, "bert/embeddings/LayerNorm/gamma", H, &h->emb_g)) return rc;
+    if (int rc = vec(h, "bert/embeddings/LayerNorm/beta", H, &h->emb_b)) return rc;
+    h->layers.resize(c.layers);
+    for (int i = 0; i < c.layers; ++i) {
+        const std::string p = "bert/encoder/layer_" + std::to_string(i);
+        if (int rc = load_att(h, true, p + "/attention/self", p + "/attention/output", &h->layers[i].att)) return rc;
+        if (int rc = load_ffn(h, true, p + "/intermediate", p + "/output", &h->layers[i].ffn)) return rc;
+    }
+    if (int rc = mat(h, "bert/pooler/dense/kernel", H, H, true, &h->w_pool)) return rc;
+    if (int rc = vec(h, "bert/pooler/dense/bias", H, &h->b_pool)) return rc;
+    return MMS_OK;
+}
+
+int finalize_zk(mms_handle* h) {
+    if (int rc = finalize_tf_common(h)) return rc;
+    // kdd_conv1 [1,8,in,out] -> im2col weight [out][k*768 + in]
+    const HostTensor* t;
+    if (int rc = need(h, "kdd_conv1/weights", {1, MMS_LABEL_LEN, H, H}, &t)) return rc;
+    if (int rc = upload_mat(h, {{t->data.data(), H, true}}, (int64_t)MMS_LABEL_LEN * H, &h->w_conv1)) return rc;
+    if (int rc = vec(h, "kdd_conv1/biases", H, &h->b_conv1)) return rc;
+    if (int rc = tab(h, "kdd_dense1/weights", {5, H}, &h->w_dense1)) return rc;
+    if (int rc = vec(h, "kdd_dense1/biases", H, &h->b_dense1)) return rc;
+    if (int rc = mat(h, "kdd_conv2/weights", H, MMS_FEAT, true, &h->w_conv2, {1, 1, MMS_FEAT, H})) return rc;
+    if (int rc = vec(h, "kdd_conv2/biases", H, &h->b_conv2)) return rc;
+    if (int rc = mat(h, "kdd_featureemb/fully_connected/weights", H, H, true, &h->w_femb)) return rc;
+    if (int rc = vec(h, "kdd_featureemb/fully_connected/biases", H, &h->b_femb)) return rc;
+    if (int rc = tab(h, "cls/seq_relationship/am_kernel", {H, 2}, &h->am_kernel)) return rc;
+    return MMS_OK;
+}
+
+int finalize_lds(mms_handle* h) {
+    if (int rc = finalize_tf_common(h)) return rc;
+    if (int rc = mat(h, "featureemb/fully_connected/weights", H, MMS_FEAT, true, &h->w_feat)) return rc;
+    if (int rc = vec(h, "featureemb/fully_connected/biases", H, &h->b_feat)) return rc;
+    if (int rc = tab(h, "bert/embeddings/word_embeddings_labelembedding", {MMS_LABEL_LEN, 1}, &h->w_lab8)) return rc;
+    if (int rc = tab(h, "cls/seq_relationship/output_weights", {2, H}, &h->w_cls)) return rc;
+    if (int rc = vec(h, "cls/seq_relationship/output_bias", 2, &h->b_cls)) return rc;
+    return MMS_OK;
+}
+
+int finalize_lxmert(mms_handle* h) {
+    const mms_config& c = h->cfg;
+    const std::string b = "lxrt_encoder.model.bert.";
+    if (int rc = tab(h, b + "embeddings.word_embeddings.weight", {c.vocab, H}, &h->E)) return rc;
+    if (int rc = tab(h, b + "embeddings.position_embeddings.weight", {c.max_pos, H}, &h->pos_tab)) return rc;
+    if (int rc = tab(h, b + "embeddings.token_type_embeddings.weight", {c.type_vocab, H}, &h->type_tab)) return rc;
+    if (int rc = vec(h, b + "embeddings.LayerNorm.weight", H, &h->emb_g)) return rc;
+    if (int rc = vec(h, b + "embeddings.LayerNorm.bias", H, &h->emb_b)) return rc;
+    const std::string v = b + "encoder.visn_fc.";
+    if (int rc = mat(h, v + "visn_fc.weight", H, MMS_FEAT, false, &h->w_visn)) return rc;
+    if (int rc = vec(h, v + "visn_fc.bias", H, &h->b_visn)) return rc;
+    if (int rc = vec(h, v + "visn_layer_norm.weight", H, &h->g_visn)) return rc;
+    if (int rc = vec(h, v + "visn_layer_norm.bias", H, &h->be_visn)) return rc;
+    if (int rc = tab(h, v + "box_fc.weight", {H, 4}, &h->w_box)) return rc;
+    if (int rc = vec(h, v + "box_fc.bias", H, &h->b_box)) return rc;
+    if (int rc = vec(h, v + "box_layer_norm.weight", H, &h->g_box)) return rc;
+    if (int rc = vec(h, v + "box_layer_norm.bias", H, &h->be_box)) return rc;
+    if (int rc = tab(h, v + "label_conv.weight", {1, MMS_LABEL_LEN, 1, 1}, &h->w_lconv)) return rc;
+    if (int rc = vec(h, v + "label_conv.bias", 1, &h->b_lconv)) return rc;
+    if (int rc = mat(h, v + "label_fc.weight", H, H, false, &h->w_labfc)) return rc;
+    if (int rc = vec(h, v + "label_fc.bias", H, &h->b_labfc)) return rc;
+    if (int rc = vec(h, v + "label_layer_norm.weight", H, &h->g_lab)) return rc;
+    if (int rc = vec(h, v + "label_layer_norm.bias", H, &h->be_lab)) return rc;
+    h->layers.resize(c.layers);
+    h->r_layers.resize(c.r_layers);
+    h->x_layers.resize(c.x_layers);
+    for (int i = 0; i < c.layers; ++i) {
+        const std::string p = b + "encoder.layer." + std::to_string(i);
+        if (int rc = load_att(h, false, p + ".attention.self", p + ".attention.output", &h->layers[i].att)) return rc;
+        if (int rc = load_ffn(h, false, p + ".intermediate", p + ".output", &h->layers[i].ffn)) return rc;
+    }
+    for (int i = 0; i < c.r_layers; ++i) {
+        const std::string p = b + "encoder.r_layers." + std::to_string(i);
+        if (int rc = load_att(h, false, p + ".attention.self", p + ".attention.output", &h->r_layers[i].att)) return rc;
+        if (int rc = load_ffn(h, false, p + ".intermediate", p + ".output", &h->r_layers[i].ffn)) return rc;
+    }
+    for (int i = 0; i < c.x_layers; ++i) {
+        const std::string p = b + "encoder.x_layers." + std::to_string(i);
+        XLayerW& x = h->x_layers[i];
+        if (int rc = load_att(h, false, p + ".visual_attention.att", p + ".visual_attention.output", &x.cross)) return rc;
+        if (int rc = load_att(h, false, p + ".lang_self_att.self", p + ".lang_self_att.output", &x.lang_self)) return rc;
+        if (int rc = load_att(h, false, p + ".visn_self_att.self", p + ".visn_self_att.output", &x.visn_self)) return rc;
+        if (int rc = load_ffn(h, false, p + ".lang_inter", p + ".lang_output", &x.lang_ffn)) return rc;
+        if (int rc = load_ffn(h, false, p + ".visn_inter", p + ".visn_output", &x.visn_ffn)) return rc;
+    }
+    if (int rc = mat(h, b + "pooler.dense.weight", H, H, false, &h->w_pool)) return rc;
+    if (int rc = vec(h, b + "pooler.dense.bias", H, &h->b_pool)) return rc;
+    if (int rc = mat(h, "logit_fc.0.weight", 2 * H, H, false, &h->w_fc0)) return rc;
+    if (int rc = vec(h, "logit_fc.0.bias", 2 * H, &h->b_fc0)) return rc;
+    if (int rc = vec(h, "logit_fc.2.weight", 2 * H, &h->g_fc2)) return rc;
+    if (int rc = vec(h, "logit_fc.2.bias", 2 * H, &h->be_fc2)) return rc;
+    if (int rc = tab(h, "logit_fc.3.weight", {2, 2 * H}, &h->w_fc3)) return rc;
+    if (int rc = vec(h, "logit_fc.3.bias", 2, &h->b_fc3)) return rc;
+    return MMS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+int alloc_planes(mms_handle* h, std::vector<void*>& pool, Planes* p, int64_t elems) {
+    void* q;
+    if (int rc = dev_alloc(h, pool, &q, (size_t)elems * 2 * 2)) return rc;
+    p->hi = (bf16*)q;
+    p->lo = p->hi + elems;
+    return MMS_OK;
+}
+
+int ensure_workspace(mms_handle* h, int64_t pairs) {
+    if (pairs <= h->ws_pairs) return MMS_OK;
+    free_pool(h->ws_allocs);
+    h->ws_pairs = 0;
+    const mms_config& c = h->cfg;
+    const int64_t T = c.text_len;
+    int64_t rows, mid_rows;
+    if (c.model == MMS_MODEL_ZK) rows = mid_rows = pairs * (T + MMS_NBOX);
+    else if (c.model == MMS_MODEL_LDS) rows = mid_rows = pairs * (T + 2 * MMS_NBOX);
+    else { rows = pairs * (T + MMS_NBOX); mid_rows = pairs * (T > MMS_NBOX ? T : MMS_NBOX); }
+    h->x_rows = rows / pairs;
+    // mid also hosts the split 2048-d box features during the embedding stage
+    int64_t mid_elems = mid_rows * c.inter;
+    const int64_t feat_elems = pairs * MMS_NBOX * MMS_FEAT;
+    if (mid_elems < feat_elems) mid_elems = feat_elems;
+    void* p;
+    if (int rc = alloc_planes(h, h->ws_allocs, &h->x, rows * H)) return rc;
+    if (int rc = alloc_planes(h, h->ws_allocs, &h->ctx, rows * H)) return rc;
+    if (int rc = alloc_planes(h, h->ws_allocs, &h->y, rows * H)) return rc;
+    if (int rc = alloc_planes(h, h->ws_allocs, &h->mid, mid_elems)) return rc;
+    if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * 3 * H * 4)) return rc;
+    h->qkv = (float*)p;
+    if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * H * 4)) return rc;
+    h->t = (float*)p;
+    if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * 4)) return rc;
+    h->key_add = (float*)p;
+    if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * 4)) return rc;
+    h->key_add2 = (float*)p;
+    if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)pairs * H * 4)) return rc;
+    h->pooled = (float*)p;
+    if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)pairs * 2 * H * 4)) return rc;
+    h->hbuf = (float*)p;
+    h->ws_pairs = pairs;
+    return MMS_OK;
+}
+
+constexpr int64_t LAB_CHUNK = 2048;  // unique label texts encoded per GEMM wave (bounds the im2col buffer)
+
+int ensure_label_ws(mms_handle* h, int64_t U) {
+    if (U > h->lab_feat_cap || h->lab_cap == 0) {
+        free_pool(h->lab_allocs);
+        h->lab_cap = 0;
+        const int64_t cap = U < LAB_CHUNK ? U : LAB_CHUNK;
+        const int64_t kdim = h->cfg.model == MMS_MODEL_ZK ? (int64_t)MMS_LABEL_LEN * H : H;
+        const int64_t rows = h->cfg.model == MMS_MODEL_ZK ? cap * MMS_LABEL_LEN : cap;
+        void* p;
+        if (int rc = alloc_planes(h, h->lab_allocs, &h->lab_planes, rows * kdim)) return rc;
+        if (int rc = dev_alloc(h, h->lab_allocs, &p, (size_t)rows * H * 4)) return rc;
+        h->lab_f32 = (float*)p;
+        if (int rc = dev_alloc(h, h->lab_allocs, &p, (size_t)U * H * 4)) return rc;
+        h->lab_feat = (float*)p;
+        h->lab_cap = cap;
+        h->lab_feat_cap = U;
+    }
+    return MMS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+struct GemmOut {
+    float* f32 = nullptr; int ldc = 0;
+    Planes pl; int ldp = 0;
+    RowMap cmap{0, 0, 0};
+};
+
+int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf16* w, const float* bias, int64_t M,
+         int N, int K, int act, const GemmOut& out, const Planes* resid = nullptr) {
+    if (M <= 0) return MMS_OK;
+    if (N % 128 || K % 64) return h->fail(MMS_ERR_ARG, "gemm: N % 128 or K % 64 != 0");
+    GemmParams p{};
+    p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.amap = amap;
+    p.w = w; p.bias = bias; p.M = (int)M; p.N = N; p.K = K;
+    p.act = act;
+    p.out_kind = out.f32 ? OUT_F32 : OUT_PLANES;
+    p.c_f32 = out.f32; p.ldc = out.ldc;
+    p.c_hi = out.pl.hi; p.c_lo = out.pl.lo; p.ldp = out.ldp; p.cmap = out.cmap;
+    if (resid) { p.r_hi = resid->hi; p.r_lo = resid->lo; p.ldr = H; }
+    if (h && h->timing) {
+        if (h->ev_used + 2 > h->ev.size()) {
+            h->ev.resize(h->ev_used + 2);
+            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used]));
+            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used + 1]));
+        }
+        HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
+        launch_gemm(p, h->nsplit, st);
+        HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
+        h->ev_used += 2;
+        h->gemm_flops += 2.0 * (double)M * N * K;
+        h->gemm_launches += 1;
+    } else {
+        launch_gemm(p, h->nsplit, st);
+    }
+    return MMS_OK;
+}
+
+GemmOut to_f32(float* p, int ldc) { GemmOut o; o.f32 = p; o.ldc = ldc; return o; }
+GemmOut to_planes(Planes p, int ldp, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.pl = p; o.ldp = ldp; o.cmap = m; return o; }
+const RowMap ID{0, 0, 0};
+
+// attention sub-layer: out = LN(dense(attn(in_q, in_kv)) + in_q)    (pixelbert.py:932-966, modeling.py:355-392)
+// All row offsets are in rows of the [rows, 768] hidden-state buffers; qkv rows mirror them.
+int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes out, int64_t q_row0, int Sq, int64_t kv_row0,
+              int Sk, int64_t B, const float* key_add, bool qkv_ready = false, int64_t proj_row0 = 0, int64_t proj_rows = 0) {
+    if (!qkv_ready) {
+        // self-attention: one fused QKV projection over the q rows (q rows == kv rows)
+        if (int rc = gemm(h, st, in.at(q_row0 * H), H, ID, w.wqkv, w.bqkv, B * Sq, 3 * H, H, ACT_NONE,
+                          to_f32(h->qkv + q_row0 * 3 * H, 3 * H))) return rc;
+    }
+    (void)proj_row0; (void)proj_rows;
+    AttnParams a{};
+    a.q = h->qkv + q_row0 * 3 * H; a.ldq = 3 * H;
+    a.k = h->qkv + kv_row0 * 3 * H + H; a.v = h->qkv + kv_row0 * 3 * H + 2 * H; a.ldkv = 3 * H;
+    a.q_base = 0; a.Sq = Sq; a.kv_base = 0; a.Sk = Sk;
+    a.key_add = key_add;
+    a.o_hi = h->ctx.hi + q_row0 * H; a.o_lo = h->ctx.lo + q_row0 * H; a.ldo = H;
+    a.B = (int)B;
+    launch_attention(a, st);
+    const Planes resid = in.at(q_row0 * H);
+    if (int rc = gemm(h, st, h->ctx.at(q_row0 * H), H, ID, w.wo, w.bo, B * Sq, H, H, ACT_NONE,
+                      to_f32(h->t + q_row0 * H, H), &resid)) return rc;
+    launch_ln_to_planes(h->t + q_row0 * H, H, w.g, w.b, out.hi + q_row0 * H, out.lo + q_row0 * H, H, (int)(B * Sq), st);
+    return MMS_OK;
+}
+
+// feed-forward sub-layer: out = LN(dense(act(dense(in))) + in)      (pixelbert.py:969-985, modeling.py:395-420)
+int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes out, int64_t row0, int64_t M, int act) {
+    const int I = h->cfg.inter;
+    if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I))) return rc;
+    const Planes resid = in.at(row0 * H);
+    if (int rc = gemm(h, st, h->mid, I, ID, w.wd, w.bd, M, H, I, ACT_NONE, to_f32(h->t + row0 * H, H), &resid)) return rc;
+    launch_ln_to_planes(h->t + row0 * H, H, w.g, w.b, out.hi + row0 * H, out.lo + row0 * H, H, (int)M, st);
+    return MMS_OK;
+}
+
+int check_ready(mms_handle* h, int model, const void* batch, const float* logits) {
+    if (!h) return MMS_ERR_ARG;
+    if (!h->finalized) return h->fail(MMS_ERR_STATE, "mms_finalize has not been called");
+    if (h->cfg.model != model) return h->fail(MMS_ERR_ARG, "handle was created for a different model");
+    if (!batch || !logits) return h->fail(MMS_ERR_ARG, "null batch or logits pointer");
+    return MMS_OK;
+}
+
+int post_launch(mms_handle* h) {
+    HIP_TRY(h, hipGetLastError());
+    return MMS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// zk forward
+// ------------------------------------------------------------------------------------------------
+int zk_label_features(mms_handle* h, hipStream_t st, const int32_t* uniq_ids, int64_t U) {
+    if (int rc = ensure_label_ws(h, U)) return rc;
+    const int KD = MMS_LABEL_LEN * H;
+    for (int64_t u0 = 0; u0 < U; u0 += h->lab_cap) {
+        const int64_t n = (U - u0) < h->lab_cap ? (U - u0) : h->lab_cap;
+        launch_zk_im2col(h->E, uniq_ids + u0 * MMS_LABEL_LEN, (int)n, h->cfg.vocab, h->lab_planes.hi, h->lab_planes.lo, st);
+        if (int rc = gemm(h, st, h->lab_planes, KD, ID, h->w_conv1, h->b_conv1, n * MMS_LABEL_LEN, H, KD, ACT_RELU,
+                          to_f32(h->lab_f32, H))) return rc;
+        launch_mean8(h->lab_f32, h->lab_feat + u0 * H, (int)n, st);
+    }
+    return MMS_OK;
+}
+
+int zk_chunk(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, int64_t n, float* logits, float* probs) {
+    const mms_config& c = h->cfg;
+    const int T = c.text_len, S = T + MMS_NBOX;
+    const int64_t NB = n * MMS_NBOX;
+    // --- image tokens (model_triple.py:189-195, pixelbert.py:449-452) ---
+    Planes featp = h->mid;  // split box features live in the (still unused) FFN buffer
+    launch_split_f32(b->feats + p0 * MMS_NBOX * MMS_FEAT, featp.hi, featp.lo, NB * MMS_FEAT, st);
+    float* img = h->qkv;                 // [NB,768] fp32, aliases the (still unused) QKV buffer
+    float* tok = h->qkv + NB * H;        // [NB,768] fp32
+    if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_conv2, h->b_conv2, NB, H, MMS_FEAT, ACT_RELU, to_f32(img, H))) return rc;
+    launch_zk_tokpre(h->lab_feat, b->label_index + p0 * MMS_NBOX, b->boxes_5 + p0 * MMS_NBOX * 5, h->w_dense1, h->b_dense1,
+                     img, h->ctx.hi, h->ctx.lo, (int)NB, st);
+    if (int rc = gemm(h, st, h->ctx, H, ID, h->w_femb, h->b_femb, NB, H, H, ACT_NONE, to_f32(tok, H))) return rc;
+    // --- embeddings + mask ---
+    launch_zk_embed(h->E, h->type_tab, h->pos_tab, h->emb_g, h->emb_b, b->query_ids + p0 * T, b->segment_ids + p0 * S, tok, T,
+                    c.vocab, h->x.hi, h->x.lo, (int)n, st);
+    launch_zk_mask(b->len_query + p0, b->num_boxes + p0, T, h->key_add, (int)n, st);
+    // --- encoder ---
+    const int nl = (c.stop_after >= 0 && c.stop_after < c.layers) ? c.stop_after : c.layers;
+    for (int i = 0; i < nl; ++i) {
+        if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, 0, S, n, h->key_add)) return rc;
+        if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * S, ACT_GELU_TANH)) return rc;
+    }
+    // --- pooler on the CLS rows + AM-softmax head ---
+    if (int rc = gemm(h, st, h->x, H, RowMap{1, S, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H))) return rc;
+    launch_zk_head(h->pooled, h->am_kernel, b->labels + p0, 30.0f, 0.35f, logits + p0 * 2, probs ? probs + p0 * 2 : nullptr, (int)n, st);
+    return MMS_OK;
+}
+
+int lds_chunk(mms_handle* h, hipStream_t st, const mms_lds_batch* b, int64_t p0, int64_t n, float* logits, float* probs) {
+    const mms_config& c = h->cfg;
+    const int T = c.text_len, S = T + 2 * MMS_NBOX;
+    const int64_t NB = n * MMS_NBOX;
+    launch_lds_embed_text(h->E, h->type_tab, h->pos_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, b->segment_ids + p0 * T, T, S,
+                          c.vocab, h->x.hi, h->x.lo, (int)n, st);
+    Planes featp = h->mid;
+    launch_split_f32(b->features + p0 * MMS_NBOX * MMS_FEAT, featp.hi, featp.lo, NB * MMS_FEAT, st);
+    // featureemb (linear) written straight into rows b*S + T + n of the hidden state (pixelmodel.py:600-601)
+    if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_feat, h->b_feat, NB, H, MMS_FEAT, ACT_NONE,
+                      to_planes(h->x, H, RowMap{MMS_NBOX, S, T}))) return rc;
+    launch_lds_label(h->E, h->w_lab8, b->labelfeat + p0 * MMS_NBOX * MMS_LABEL_LEN, c.vocab, S, T + MMS_NBOX, h->x.hi, h->x.lo, (int)n, st);
+    const int nl = (c.stop_after >= 0 && c.stop_after < c.layers) ? c.stop_after : c.layers;
+    for (int i = 0; i < nl; ++i) {
+        if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, 0, S, n, nullptr)) return rc;
+        if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * S, ACT_GELU_TANH)) return rc;
+    }
+    if (int rc = gemm(h, st, h->x, H, RowMap{1, S, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H))) return rc;
+    launch_lds_head(h->pooled, h->w_cls, h->b_cls, logits + p0 * 2, probs ? probs + p0 * 2 : nullptr, (int)n, st);
+    return MMS_OK;
+}
+
+int lx_label_features(mms_handle* h, hipStream_t st, const int64_t* uniq_ids, int64_t U) {
+    if (int rc = ensure_label_ws(h, U)) return rc;
+    for (int64_t u0 = 0; u0 < U; u0 += h->lab_cap) {
+        const int64_t n = (U - u0) < h->lab_cap ? (U - u0) : h->lab_cap;
+        launch_lx_label_emb(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, h->w_lconv, h->b_lconv, uniq_ids + u0 * MMS_LABEL_LEN,
+                            h->cfg.vocab, h->lab_planes.hi, h->lab_planes.lo, (int)n, st);
+        if (int rc = gemm(h, st, h->lab_planes, H, ID, h->w_labfc, h->b_labfc, n, H, H, ACT_NONE, to_f32(h->lab_f32, H))) return rc;
+        launch_ln_f32(h->lab_f32, h->g_lab, h->be_lab, h->lab_feat + u0 * H, (int)n, st);
+    }
+    return MMS_OK;
+}
+
+int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p0, int64_t n, float* logits, float* probs) {
+    const mms_config& c = h->cfg;
+    const int T = c.text_len, V = MMS_NBOX;
+    const int64_t ML = n * T, MV = n * V, R = ML + MV;  // language rows [0, ML), vision rows [ML, R)
+    float* lang_add = h->key_add;
+    float* visn_add = h->key_add2;
+    launch_lx_masks(b->input_mask + p0 * T, b->visual_attention_mask + p0 * V, T, lang_add, visn_add, (int)n, st);
+    launch_lx_embed_lang(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->x.hi, h->x.lo, (int)n, st);
+    Planes featp = h->mid;
+    launch_split_f32(b->feats + p0 * V * MMS_FEAT, featp.hi, featp.lo, MV * MMS_FEAT, st);
+    float* xf = h->qkv;
+    if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_visn, h->b_visn, MV, H, MMS_FEAT, ACT_NONE, to_f32(xf, H))) return rc;
+    launch_lx_visn(xf, h->g_visn, h->be_visn, b->boxes + p0 * V * 4, 4, h->w_box, h->b_box, h->g_box, h->be_box, h->lab_feat,
+                   b->label_index + p0 * V, h->x.hi + ML * H, h->x.lo + ML * H, (int)MV, st);
+    int budget = c.stop_after >= 0 ? c.stop_after : (1 << 30);
+    for (int i = 0; i < c.layers && budget > 0; ++i, --budget) {
+        if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, T, 0, T, n, lang_add)) return rc;
+        if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, ML, ACT_GELU_ERF)) return rc;
+    }
+    for (int i = 0; i < c.r_layers && budget > 0; ++i, --budget) {
+        if (int rc = att_block(h, st, h->r_layers[i].att, h->x, h->y, ML, V, ML, V, n, visn_add)) return rc;
+        if (int rc = ffn_block(h, st, h->r_layers[i].ffn, h->y, h->x, ML, MV, ACT_GELU_ERF)) return rc;
+    }
+    for (int i = 0; i < c.x_layers && budget > 0; ++i, --budget) {
+        const XLayerW& w = h->x_layers[i];
+        // cross attention, both directions with the SAME weights (modeling.py:460-464): one QKV
+        // projection over all R rows, two attention launches, one output dense + LN over all R rows
+        if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, R, 3 * H, H, ACT_NONE, to_f32(h->qkv, 3 * H))) return rc;
+        AttnParams a{};
+        a.ldq = a.ldkv = 3 * H; a.ldo = H; a.B = (int)n; a.q_base = a.kv_base = 0;
+        a.q = h->qkv; a.Sq = T;                                   // lang <- visn
+        a.k = h->qkv + ML * 3 * H + H; a.v = h->qkv + ML * 3 * H + 2 * H; a.Sk = V; a.key_add = visn_add;
+        a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo;
+        launch_attention(a, st);
+        a.q = h->qkv + ML * 3 * H; a.Sq = V;                      // visn <- lang
+        a.k = h->qkv + H; a.v = h->qkv + 2 * H; a.Sk = T; a.key_add = lang_add;
+        a.o_hi = h->ctx.hi + ML * H; a.o_lo = h->ctx.lo + ML * H;
+        launch_attention(a, st);
+        if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, R, H, H, ACT_NONE, to_f32(h->t, H), &h->x)) return rc;
+        launch_ln_to_planes(h->t, H, w.cross.g, w.cross.b, h->y.hi, h->y.lo, H, (int)R, st);
+        // per-stream self attention (y -> x), then per-stream FFN (x -> x)
+        if (int rc = att_block(h, st, w.lang_self, h->y, h->x, 0, T, 0, T, n, lang_add)) return rc;
+        if (int rc = att_block(h, st, w.visn_self, h->y, h->x, ML, V, ML, V, n, visn_add)) return rc;
+        if (int rc = ffn_block(h, st, w.lang_ffn, h->x, h->x, 0, ML, ACT_GELU_ERF)) return rc;
+        if (int rc = ffn_block(h, st, w.visn_ffn, h->x, h->x, ML, MV, ACT_GELU_ERF)) return rc;
+    }
+    // pooler (modeling.py:596-608) -> logit_fc (kdd_model.py:167-172)
+    if (int rc = gemm(h, st, h->x, H, RowMap{1, T, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_planes(h->ctx, H))) return rc;
+    if (int rc = gemm(h, st, h->ctx, H, ID, h->w_fc0, h->b_fc0, n, 2 * H, H, ACT_GELU_ERF, to_f32(h->hbuf, 2 * H))) return rc;
+    launch_lx_head(h->hbuf, h->g_fc2, h->be_fc2, h->w_fc3, h->b_fc3, logits + p0 * 2, probs ? probs + p0 * 2 : nullptr, (int)n, st);
+    return MMS_OK;
+}
+
+int chunk_size(const mms_handle* h, int64_t B) {
+    int64_t c = h->cfg.chunk_pairs > 0 ? h->cfg.chunk_pairs : 4096;
+    return (int)(B < c ? B : c);
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int mms_version(void) { return 1; }
+const char* mms_global_error(void) { return g_err.c_str(); }
+const char* mms_last_error(const mms_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int mms_create(const mms_config* cfg, mms_handle** out) {
+    if (!cfg || !out) { g_err = "null argument"; return MMS_ERR_ARG; }
+    *out = nullptr;
+    if (cfg->model < 0 || cfg->model > 2) { g_err = "bad model id"; return MMS_ERR_ARG; }
+    if (cfg->inter <= 0 || cfg->inter % 128) { g_err = "inter must be a positive multiple of 128"; return MMS_ERR_ARG; }
+    if (cfg->precision != 1 && cfg->precision != 2) { g_err = "precision must be 1 or 2"; return MMS_ERR_ARG; }
+    if (cfg->text_len <= 0 || cfg->text_len > 32 || cfg->text_len + 1 > cfg->max_pos) { g_err = "bad text_len"; return MMS_ERR_ARG; }
+    if (cfg->layers < 0 || cfg->vocab <= 0 || cfg->type_vocab <= 0) { g_err = "bad layer/vocab config"; return MMS_ERR_ARG; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { g_err = std::string("no HIP device: ") + hipGetErrorString(e); return MMS_ERR_HIP; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_err = "bad device ordinal"; return MMS_ERR_ARG; }
+    e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) { g_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return MMS_ERR_HIP; }
+    mms_handle* h = new mms_handle();
+    h->cfg = *cfg;
+    h->nsplit = cfg->precision;
+    *out = h;
+    return MMS_OK;
+}
+
+void mms_destroy(mms_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    free_pool(h->w_allocs);
+    free_pool(h->ws_allocs);
+    free_pool(h->lab_allocs);
+    for (auto e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+}
+
+int mms_load_weight(mms_handle* h, const char* name, const float* host_data, const int64_t* shape, int32_t rank) {
+    if (!h) return MMS_ERR_ARG;
+    if (!name || !host_data || !shape || rank < 1 || rank > 4) return h->fail(MMS_ERR_ARG, "mms_load_weight: bad argument");
+    if (h->finalized) return h->fail(MMS_ERR_STATE, "mms_load_weight after mms_finalize");
+    HostTensor t;
+    t.shape.assign(shape, shape + rank);
+    const int64_t n = t.numel();
+    if (n <= 0) return h->fail(MMS_ERR_ARG, std::string("mms_load_weight: empty tensor ") + name);
+    t.data.assign(host_data, host_data + n);
+    h->host[name] = std::move(t);
+    return MMS_OK;
+}
+
+int mms_finalize(mms_handle* h) {
+    if (!h) return MMS_ERR_ARG;
+    if (h->finalized) return h->fail(MMS_ERR_STATE, "already finalized");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    int rc = h->cfg.model == MMS_MODEL_ZK ? finalize_zk(h) : h->cfg.model == MMS_MODEL_LDS ? finalize_lds(h) : finalize_lxmert(h);
+    if (rc) { free_pool(h->w_allocs); return rc; }
+    h->host.clear();
+    h->finalized = true;
+    return MMS_OK;
+}
+
+int mms_score_zk(mms_handle* h, const mms_zk_batch* b, float* logits, float* probs, void* stream) {
+    if (int rc = check_ready(h, MMS_MODEL_ZK, b, logits)) return rc;
+    const int64_t B = b->n_pairs;
+    if (B < 0 || b->n_uniq_labels < 0) return h->fail(MMS_ERR_ARG, "negative batch size");
+    if (B == 0) return MMS_OK;
+    if (!b->num_boxes || !b->boxes_5 || !b->feats || !b->uniq_label_ids || !b->label_index || !b->query_ids || !b->len_query ||
+        !b->labels || !b->segment_ids || b->n_uniq_labels == 0)
+        return h->fail(MMS_ERR_ARG, "mms_score_zk: null batch field");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    const int cs = chunk_size(h, B);
+    if (int rc = ensure_workspace(h, cs)) return rc;
+    if (int rc = zk_label_features(h, st, b->uniq_label_ids, b->n_uniq_labels)) return rc;
+    for (int64_t p0 = 0; p0 < B; p0 += cs)
+        if (int rc = zk_chunk(h, st, b, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
+    return post_launch(h);
+}
+
+int mms_score_lds(mms_handle* h, const mms_lds_batch* b, float* logits, float* probs, void* stream) {
+    if (int rc = check_ready(h, MMS_MODEL_LDS, b, logits)) return rc;
+    const int64_t B = b->n_pairs;
+    if (B < 0) return h->fail(MMS_ERR_ARG, "negative batch size");
+    if (B == 0) return MMS_OK;
+    if (!b->input_ids || !b->segment_ids || !b->features || !b->labelfeat) return h->fail(MMS_ERR_ARG, "mms_score_lds: null batch field");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    const int cs = chunk_size(h, B);
+    if (int rc = ensure_workspace(h, cs)) return rc;
+    for (int64_t p0 = 0; p0 < B; p0 += cs)
+        if (int rc = lds_chunk(h, st, b, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
+    return post_launch(h);
+}
+
+int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, float* probs, void* stream) {
+    if (int rc = check_ready(h, MMS_MODEL_LXMERT, b, logits)) return rc;
+    const int64_t B = b->n_pairs;
+    if (B < 0 || b->n_uniq_labels < 0) return h->fail(MMS_ERR_ARG, "negative batch size");
+    if (B == 0) return MMS_OK;
+    if (!b->input_ids || !b->input_mask || !b->uniq_label_ids || !b->label_index || !b->feats || !b->boxes ||
+        !b->visual_attention_mask || b->n_uniq_labels == 0)
+        return h->fail(MMS_ERR_ARG, "mms_score_lxmert: null batch field");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    const int cs = chunk_size(h, B);
+    if (int rc = ensure_workspace(h, cs)) return rc;
+    if (int rc = lx_label_features(h, st, b->uniq_label_ids, b->n_uniq_labels)) return rc;
+    for (int64_t p0 = 0; p0 < B; p0 += cs)
+        if (int rc = lx_chunk(h, st, b, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
+    return post_launch(h);
+}
+
+int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out, int64_t* launches_out, double* flops_out) {
+    if (!h) return MMS_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (ms_out || launches_out || flops_out) {
+        double ms = 0;
+        if (h->ev_used) HIP_TRY(h, hipEventSynchronize(h->ev[h->ev_used - 1]));
+        for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+            float t = 0;
+            HIP_TRY(h, hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
+            ms += t;
+        }
+        if (ms_out) *ms_out = ms;
+        if (launches_out) *launches_out = h->gemm_launches;
+        if (flops_out) *flops_out = h->gemm_flops;
+    }
+    if (reset) { h->ev_used = 0; h->gemm_flops = 0; h->gemm_launches = 0; }
+    h->timing = enable != 0;
+    return MMS_OK;
+}
+
+int mms_debug_read_x(mms_handle* h, float* dst_dev, int64_t rows, void* stream) {
+    if (!h || !dst_dev) return MMS_ERR_ARG;
+    if (!h->ws_pairs) return h->fail(MMS_ERR_STATE, "no forward has run yet");
+    if (rows < 0 || rows > h->ws_pairs * h->x_rows) return h->fail(MMS_ERR_ARG, "rows exceeds the workspace");
+    launch_planes_to_f32(h->x.hi, h->x.lo, dst_dev, rows * H, (hipStream_t)stream);
+    return post_launch(h);
+}
+
+// ---- kernel-level test hooks: fp32 in / fp32 out around the production kernels --------------------
+static int dbg_fail(const char* m) { g_err = m; return MMS_ERR_HIP; }
+#define DBG_TRY(expr) do { if ((expr) != hipSuccess) return dbg_fail(#expr); } while (0)
+
+int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const float* w_f32_nk, int64_t N, const float* bias,
+                 const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes, float* c_f32, void* stream) {
+    if (!a_f32 || !w_f32_nk || !c_f32 || M <= 0 || N % 128 || K % 64 || lda < K || lda % 8) { g_err = "mms_dbg_gemm: bad argument"; return MMS_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    bf16 *ap = nullptr, *wp = nullptr, *rp = nullptr, *cp = nullptr;
+    float* wtmp = nullptr;
+    DBG_TRY(hipMalloc((void**)&ap, (size_t)M * lda * 4));
+    DBG_TRY(hipMalloc((void**)&wp, (size_t)N * K * 4));
+    launch_split_f32(a_f32, ap, ap + M * lda, M * lda, st);
+    launch_split_f32(w_f32_nk, wp, wp + N * K, N * K, st);  // hi plane == RNE bf16 of the weights
+    GemmParams p{};
+    p.a_hi = ap; p.a_lo = ap + M * lda; p.lda = (int)lda; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
+    p.w = wp; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
+    if (resid_f32) {
+        DBG_TRY(hipMalloc((void**)&rp, (size_t)M * N * 4));
+        launch_split_f32(resid_f32, rp, rp + M * N, M * N, st);
+        p.r_hi = rp; p.r_lo = rp + M * N; p.ldr = (int)N;
+    }
+    if (out_planes) {
+        DBG_TRY(hipMalloc((void**)&cp, (size_t)M * N * 4));
+        p.out_kind = OUT_PLANES; p.c_hi = cp; p.c_lo = cp + M * N; p.ldp = (int)N;
+    } else {
+        p.out_kind = OUT_F32; p.c_f32 = c_f32; p.ldc = (int)N;
+    }
+    launch_gemm(p, nsplit, st);
+    if (out_planes) launch_planes_to_f32(cp, cp + M * N, c_f32, M * N, st);
+    DBG_TRY(hipStreamSynchronize(st));
+    DBG_TRY(hipGetLastError());
+    (void)hipFree(ap); (void)hipFree(wp); (void)hipFree(rp); (void)hipFree(cp); (void)wtmp;
+    return MMS_OK;
+}
+
+int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B, int32_t Sq, int32_t Sk, const float* key_add,
+                      float* out_f32, void* stream) {
+    if (!q || !k || !v || !out_f32 || B <= 0 || Sq <= 0 || Sk <= 0 || Sq > 48 || Sk > 48) { g_err = "mms_dbg_attention: bad argument"; return MMS_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    bf16* op = nullptr;
+    const int64_t n = B * Sq * H;
+    DBG_TRY(hipMalloc((void**)&op, (size_t)n * 4));
+    AttnParams a{};
+    a.q = q; a.ldq = H; a.k = k; a.v = v; a.ldkv = H; a.q_base = 0; a.Sq = Sq; a.kv_base = 0; a.Sk = Sk;
+    a.key_add = key_add; a.o_hi = op; a.o_lo = op + n; a.ldo = H; a.B = (int)B;
+    launch_attention(a, st);
+    launch_planes_to_f32(op, op + n, out_f32, n, st);
+    DBG_TRY(hipStreamSynchronize(st));
+    DBG_TRY(hipGetLastError());
+    (void)hipFree(op);
+    return MMS_OK;
+}
+
+int mms_dbg_layernorm(const float* x, const float* gamma, const float* beta, int64_t M, float* out_f32, void* stream) {
+    if (!x || !gamma || !beta || !out_f32 || M <= 0) { g_err = "mms_dbg_layernorm: bad argument"; return MMS_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    bf16* op = nullptr;
+    const int64_t n = M * H;
+    DBG_TRY(hipMalloc((void**)&op, (size_t)n * 4));
+    launch_ln_to_planes(x, H, gamma, beta, op, op + n, H, (int)M, st);
+    launch_planes_to_f32(op, op + n, out_f32, n, st);
+    DBG_TRY(hipStreamSynchronize(st));
+    DBG_TRY(hipGetLastError());
+    (void)hipFree(op);
+    return MMS_OK;
+}
+
+}  // extern "C"

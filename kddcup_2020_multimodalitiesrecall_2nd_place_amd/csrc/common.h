@@ -1,0 +1,61 @@
+// Shared device helpers for libmmscore (gfx950 / CDNA4 only).
+//
+// Activation format between kernels: "split planes".  A logical fp32 activation x[M][K] is kept in
+// HBM as two bf16 planes hi = bf16(x), lo = bf16(x - hi) (same bytes as fp32).  hi+lo carries
+// 16-17 significant bits; GEMMs feed MFMA with hi (precision mode 1) or hi and lo as two MFMA
+// passes that share the weight fragment (mode 2, the parity mode: SURVEY.md Appendix C row
+// "split-bf16 activations").  Residual / LayerNorm / softmax / GELU always run in fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define MMS_HIDDEN 768
+#define MMS_HEADS 12
+#define MMS_HEAD_DIM 64
+#define MMS_NBOX 10
+#define MMS_LABEL_LEN 8
+#define MMS_FEAT 2048
+#define MMS_LN_EPS 1e-12f
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU_TANH = 2, ACT_GELU_ERF = 3, ACT_TANH = 4 };
+enum { OUT_F32 = 0, OUT_PLANES = 1 };
+
+__device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
+    hi = (bf16)v;                 // v_cvt_pk_bf16_f32: round-to-nearest-even
+    lo = (bf16)(v - (float)hi);   // exact remainder, rounded once
+}
+
+__device__ __forceinline__ float join_bf16(bf16 hi, bf16 lo) { return (float)hi + (float)lo; }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.0f);
+        case ACT_GELU_TANH: {  // pixelbert.py:326-328
+            const float c = 0.7978845608028654f;
+            return v * (0.5f * (1.0f + tanhf(c * (v + 0.044715f * v * v * v))));
+        }
+        case ACT_GELU_ERF:     // lxrt/modeling.py:119
+            return v * 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+        case ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// row remap: logical row r -> physical row (r / grp) * stride + off + r % grp   (grp == 0: identity)
+struct RowMap {
+    int grp, stride, off;
+    __device__ __forceinline__ long long operator()(int r) const {
+        return grp ? (long long)(r / grp) * stride + off + (r % grp) : (long long)r;
+    }
+};

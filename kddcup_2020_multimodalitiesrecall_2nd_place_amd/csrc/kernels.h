@@ -1,0 +1,81 @@
+// Host-side launcher declarations for the libmmscore kernels (all launches are async on `st`).
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// GEMM  C[M,N] = act(A[M,K] * W[N,K]^T + bias (+ residual))      (gemm.hip)
+// A is a split-plane activation (hi/lo bf16), W is bf16 [N][K] (K contiguous), N % 128 == 0,
+// K % 64 == 0.  nsplit 1: hi plane only (1 MFMA pass), 2: hi + lo (2 passes, parity mode).
+// ---------------------------------------------------------------------------------------------
+struct GemmParams {
+    const bf16* a_hi; const bf16* a_lo; int lda;
+    RowMap amap;                 // logical row -> A row
+    const bf16* w;
+    const float* bias;           // [N] or nullptr
+    int M, N, K;
+    int out_kind, act;
+    float* c_f32; int ldc;       // OUT_F32
+    bf16* c_hi; bf16* c_lo; int ldp;  // OUT_PLANES
+    RowMap cmap;                 // logical row -> output row
+    const bf16* r_hi; const bf16* r_lo; int ldr;  // residual planes (logical rows) or nullptr
+};
+void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Attention for one (pair, head) per wavefront, S <= 48               (attn.hip)
+// q/k/v: fp32 projections; row of (b, i) = base + b * S + i; o: split planes on the q rows.
+// ---------------------------------------------------------------------------------------------
+struct AttnParams {
+    const float* q; int ldq;
+    const float* k; const float* v; int ldkv;
+    int q_base, Sq, kv_base, Sk;
+    const float* key_add;        // [B][Sk] additive mask or nullptr
+    bf16* o_hi; bf16* o_lo; int ldo;
+    int B;
+};
+void launch_attention(const AttnParams& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Row-wise kernels (one wavefront per 768-wide row)                   (rowops.hip)
+// ---------------------------------------------------------------------------------------------
+void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta,
+                         bf16* o_hi, bf16* o_lo, int ldo, int M, hipStream_t st);
+void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipStream_t st);
+void launch_planes_to_f32(const bf16* hi, const bf16* lo, float* out, long long n, hipStream_t st);
+void launch_mean8(const float* in, float* out, int U, hipStream_t st);
+
+// zk (code/imagebert_zk/model_triple.py:162-214, pixelbert.py:541-621)
+void launch_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab, bf16* o_hi, bf16* o_lo, hipStream_t st);
+void launch_zk_tokpre(const float* labfeat, const int* lab_index, const float* boxes5, const float* Wd,
+                      const float* bd, const float* img, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st);
+void launch_zk_embed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
+                     const float* beta, const int* query_ids, const int* segment_ids, const float* tok,
+                     int T, int vocab, bf16* o_hi, bf16* o_lo, int B, hipStream_t st);
+void launch_zk_mask(const int* len_query, const int* num_boxes, int T, float* key_add, int B, hipStream_t st);
+void launch_zk_head(const float* pooled, const float* am_kernel, const int64_t* labels, float scale,
+                    float margin, float* logits, float* probs, int B, hipStream_t st);
+
+// lds (code/imagebert_lds/src/pixelmodel.py:444-602, run_pretraining_predict_score.py:479-501)
+void launch_lds_embed_text(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
+                           const float* beta, const int64_t* input_ids, const int64_t* segment_ids,
+                           int T, int S, int vocab, bf16* o_hi, bf16* o_lo, int B, hipStream_t st);
+void launch_lds_label(const float* E, const float* wl, const int64_t* labelfeat, int vocab, int S,
+                      int row_off, bf16* o_hi, bf16* o_lo, int B, hipStream_t st);
+void launch_lds_head(const float* pooled, const float* W, const float* b, float* logits, float* probs,
+                     int B, hipStream_t st);
+
+// lxmert (code/lxmert/src/lxrt/modeling.py:269-297,496-533,872-927; tasks/kdd_model.py:167-214)
+void launch_lx_embed_lang(const float* E, const float* pos_tab, const float* type_tab, const float* gamma,
+                          const float* beta, const int64_t* input_ids, int T, int vocab,
+                          bf16* o_hi, bf16* o_lo, int B, hipStream_t st);
+void launch_lx_label_emb(const float* E, const float* pos_tab, const float* type_tab, const float* gamma,
+                         const float* beta, const float* conv_w, const float* conv_b,
+                         const int64_t* uniq_ids, int vocab, bf16* o_hi, bf16* o_lo, int U, hipStream_t st);
+void launch_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes, int box_dim,
+                    const float* Wb, const float* bb, const float* g_y, const float* b_y, const float* z,
+                    const int* lab_index, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st);
+void launch_ln_f32(const float* in, const float* gamma, const float* beta, float* out, int M, hipStream_t st);
+void launch_lx_masks(const int64_t* input_mask, const float* visual_mask, int T, float* lang_add,
+                     float* visn_add, int B, hipStream_t st);
+void launch_lx_head(const float* h, const float* gamma, const float* beta, const float* W, const float* b,
+                    float* logits, float* probs, int B, hipStream_t st);

@@ -1,0 +1,513 @@
+// Row-wise (HBM-bound) kernels: embedding gathers + LayerNorm, feature splitting, box/label token
+// assembly, masks and match heads.  One wavefront owns one 768-wide row: lane l covers columns
+// t*256 + 4*l .. +3 (t = 0..2), i.e. three coalesced 16-B accesses per lane per fp32 row and three
+// 8-B bf16x4 accesses per plane.  All arithmetic fp32; LayerNorm is two-pass (mean, then centred
+// variance) with biased variance and eps 1e-12 inside the square root, exactly as
+// tf.contrib.layers.layer_norm (pixelbert.py:414-417) and torch.nn.LayerNorm (modeling.py:266).
+#include "kernels.h"
+
+#define ROWS_PER_BLOCK 4
+
+struct Row { float v[12]; };
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_row() { return blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); }
+
+__device__ __forceinline__ void row_zero(Row& x) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x.v[i] = 0.f;
+}
+__device__ __forceinline__ void row_load(Row& x, const float* p) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const float4 f = *reinterpret_cast<const float4*>(p + t * 256 + lane_id() * 4);
+        x.v[t * 4 + 0] = f.x; x.v[t * 4 + 1] = f.y; x.v[t * 4 + 2] = f.z; x.v[t * 4 + 3] = f.w;
+    }
+}
+__device__ __forceinline__ void row_axpy(Row& x, float a, const float* p) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const float4 f = *reinterpret_cast<const float4*>(p + t * 256 + lane_id() * 4);
+        x.v[t * 4 + 0] += a * f.x; x.v[t * 4 + 1] += a * f.y; x.v[t * 4 + 2] += a * f.z; x.v[t * 4 + 3] += a * f.w;
+    }
+}
+__device__ __forceinline__ void row_add(Row& x, const float* p) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const float4 f = *reinterpret_cast<const float4*>(p + t * 256 + lane_id() * 4);
+        x.v[t * 4 + 0] += f.x; x.v[t * 4 + 1] += f.y; x.v[t * 4 + 2] += f.z; x.v[t * 4 + 3] += f.w;
+    }
+}
+__device__ __forceinline__ void row_store_f32(const Row& x, float* p) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        *reinterpret_cast<float4*>(p + t * 256 + lane_id() * 4) =
+            make_float4(x.v[t * 4], x.v[t * 4 + 1], x.v[t * 4 + 2], x.v[t * 4 + 3]);
+}
+__device__ __forceinline__ void row_store_planes(const Row& x, bf16* hi, bf16* lo) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bf16 a, c;
+            split_bf16(x.v[t * 4 + e], a, c);
+            h[e] = a; l[e] = c;
+        }
+        *reinterpret_cast<bf16x4*>(hi + t * 256 + lane_id() * 4) = h;
+        *reinterpret_cast<bf16x4*>(lo + t * 256 + lane_id() * 4) = l;
+    }
+}
+__device__ __forceinline__ void row_ln(Row& x, const float* gamma, const float* beta) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s += x.v[i];
+    const float mean = wave_sum(s) * (1.0f / MMS_HIDDEN);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const float d = x.v[i] - mean; q += d * d; }
+    const float var = wave_sum(q) * (1.0f / MMS_HIDDEN);
+    const float inv = 1.0f / sqrtf(var + MMS_LN_EPS);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + t * 256 + lane_id() * 4);
+        const float4 b = *reinterpret_cast<const float4*>(beta + t * 256 + lane_id() * 4);
+        x.v[t * 4 + 0] = (x.v[t * 4 + 0] - mean) * inv * g.x + b.x;
+        x.v[t * 4 + 1] = (x.v[t * 4 + 1] - mean) * inv * g.y + b.y;
+        x.v[t * 4 + 2] = (x.v[t * 4 + 2] - mean) * inv * g.z + b.z;
+        x.v[t * 4 + 3] = (x.v[t * 4 + 3] - mean) * inv * g.w + b.w;
+    }
+}
+__device__ __forceinline__ long long clamp_id(long long id, int vocab) {
+    return id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+}
+
+static inline dim3 row_grid(long long rows) { return dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)); }
+
+// ------------------------------------------------------------------------------------------------
+// generic
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ln_to_planes(const float* in, int ld, const float* gamma,
+                                                      const float* beta, bf16* o_hi, bf16* o_lo, int ldo, int M) {
+    const int row = wave_row();
+    if (row >= M) return;
+    Row x;
+    row_load(x, in + (long long)row * ld);
+    row_ln(x, gamma, beta);
+    row_store_planes(x, o_hi + (long long)row * ldo, o_lo + (long long)row * ldo);
+}
+void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta, bf16* o_hi,
+                         bf16* o_lo, int ldo, int M, hipStream_t st) {
+    if (M > 0) hipLaunchKernelGGL(k_ln_to_planes, row_grid(M), dim3(256), 0, st, in, ld, gamma, beta, o_hi, o_lo, ldo, M);
+}
+
+__global__ __launch_bounds__(256) void k_ln_f32(const float* in, const float* gamma, const float* beta,
+                                                float* out, int M) {
+    const int row = wave_row();
+    if (row >= M) return;
+    Row x;
+    row_load(x, in + (long long)row * MMS_HIDDEN);
+    row_ln(x, gamma, beta);
+    row_store_f32(x, out + (long long)row * MMS_HIDDEN);
+}
+void launch_ln_f32(const float* in, const float* gamma, const float* beta, float* out, int M, hipStream_t st) {
+    if (M > 0) hipLaunchKernelGGL(k_ln_f32, row_grid(M), dim3(256), 0, st, in, gamma, beta, out, M);
+}
+
+__global__ __launch_bounds__(256) void k_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 f = reinterpret_cast<const float4*>(in)[i];
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bf16 a, c; split_bf16(v[e], a, c); h[e] = a; l[e] = c; }
+        reinterpret_cast<bf16x4*>(o_hi)[i] = h;
+        reinterpret_cast<bf16x4*>(o_lo)[i] = l;
+    }
+}
+void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipStream_t st) {
+    const long long n4 = n / 4;
+    if (n4 <= 0) return;
+    const long long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(k_split_f32, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, in, o_hi, o_lo, n4);
+}
+
+__global__ __launch_bounds__(256) void k_planes_to_f32(const bf16* hi, const bf16* lo, float* out, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const bf16x4 h = reinterpret_cast<const bf16x4*>(hi)[i];
+        const bf16x4 l = reinterpret_cast<const bf16x4*>(lo)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(join_bf16(h[0], l[0]), join_bf16(h[1], l[1]),
+                                                        join_bf16(h[2], l[2]), join_bf16(h[3], l[3]));
+    }
+}
+void launch_planes_to_f32(const bf16* hi, const bf16* lo, float* out, long long n, hipStream_t st) {
+    const long long n4 = n / 4;
+    if (n4 <= 0) return;
+    const long long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(k_planes_to_f32, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, hi, lo, out, n4);
+}
+
+__global__ __launch_bounds__(256) void k_mean8(const float* in, float* out, int U) {
+    const int row = wave_row();
+    if (row >= U) return;
+    Row x;
+    row_zero(x);
+    for (int p = 0; p < MMS_LABEL_LEN; ++p) row_add(x, in + ((long long)row * MMS_LABEL_LEN + p) * MMS_HIDDEN);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x.v[i] *= (1.0f / MMS_LABEL_LEN);
+    row_store_f32(x, out + (long long)row * MMS_HIDDEN);
+}
+void launch_mean8(const float* in, float* out, int U, hipStream_t st) {
+    if (U > 0) hipLaunchKernelGGL(k_mean8, row_grid(U), dim3(256), 0, st, in, out, U);
+}
+
+// ------------------------------------------------------------------------------------------------
+// zk
+// ------------------------------------------------------------------------------------------------
+// im2col for kdd_conv1 (model_triple.py:189): row (u, p), column block k holds E[ids[u][p+k-3]] or 0
+// (SAME padding of an 8-tap window over 8 positions: 3 left / 4 right).
+__global__ __launch_bounds__(256) void k_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab,
+                                                   bf16* o_hi, bf16* o_lo) {
+    const int w = wave_row();
+    if (w >= U * MMS_LABEL_LEN * MMS_LABEL_LEN) return;
+    const int k = w % MMS_LABEL_LEN, p = (w / MMS_LABEL_LEN) % MMS_LABEL_LEN, u = w / (MMS_LABEL_LEN * MMS_LABEL_LEN);
+    const int src = p + k - 3;
+    Row x;
+    row_zero(x);
+    if (src >= 0 && src < MMS_LABEL_LEN)
+        row_load(x, E + clamp_id(uniq_ids[u * MMS_LABEL_LEN + src], vocab) * MMS_HIDDEN);
+    const long long off = ((long long)u * MMS_LABEL_LEN + p) * (MMS_LABEL_LEN * MMS_HIDDEN) + k * MMS_HIDDEN;
+    row_store_planes(x, o_hi + off, o_lo + off);
+}
+void launch_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab, bf16* o_hi, bf16* o_lo, hipStream_t st) {
+    if (U > 0)
+        hipLaunchKernelGGL(k_zk_im2col, row_grid((long long)U * 64), dim3(256), 0, st, E, uniq_ids, U, vocab, o_hi, o_lo);
+}
+
+// model_triple.py:190-195: mean(relu(conv1)) [by unique label] + kdd_dense1(boxes_5) + relu(conv2(feats))
+__global__ __launch_bounds__(256) void k_zk_tokpre(const float* labfeat, const int* lab_index, const float* boxes5,
+                                                   const float* Wd, const float* bd, const float* img,
+                                                   bf16* o_hi, bf16* o_lo, int rows) {
+    const int row = wave_row();
+    if (row >= rows) return;
+    Row x;
+    row_load(x, labfeat + (long long)lab_index[row] * MMS_HIDDEN);
+    row_add(x, bd);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) row_axpy(x, boxes5[(long long)row * 5 + k], Wd + k * MMS_HIDDEN);
+    row_add(x, img + (long long)row * MMS_HIDDEN);
+    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+}
+void launch_zk_tokpre(const float* labfeat, const int* lab_index, const float* boxes5, const float* Wd,
+                      const float* bd, const float* img, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st) {
+    if (rows > 0)
+        hipLaunchKernelGGL(k_zk_tokpre, row_grid(rows), dim3(256), 0, st, labfeat, lab_index, boxes5, Wd, bd, img, o_hi, o_lo, rows);
+}
+
+// pixelbert.py:580-621: concat text || image tokens, + token_type[segment_ids], + positions
+// [0..T-1] + [T]*10, LayerNorm over every row.
+__global__ __launch_bounds__(256) void k_zk_embed(const float* E, const float* type_tab, const float* pos_tab,
+                                                  const float* gamma, const float* beta, const int* query_ids,
+                                                  const int* segment_ids, const float* tok, int T, int vocab,
+                                                  bf16* o_hi, bf16* o_lo, int B) {
+    const int S = T + MMS_NBOX;
+    const int row = wave_row();
+    if (row >= B * S) return;
+    const int b = row / S, s = row % S;
+    Row x;
+    if (s < T) row_load(x, E + clamp_id(query_ids[b * T + s], vocab) * MMS_HIDDEN);
+    else row_load(x, tok + ((long long)b * MMS_NBOX + (s - T)) * MMS_HIDDEN);
+    row_add(x, type_tab + clamp_id(segment_ids[row], 2) * MMS_HIDDEN);
+    row_add(x, pos_tab + (s < T ? s : T) * MMS_HIDDEN);
+    row_ln(x, gamma, beta);
+    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+}
+void launch_zk_embed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
+                     const float* beta, const int* query_ids, const int* segment_ids, const float* tok,
+                     int T, int vocab, bf16* o_hi, bf16* o_lo, int B, hipStream_t st) {
+    if (B > 0)
+        hipLaunchKernelGGL(k_zk_embed, row_grid((long long)B * (T + MMS_NBOX)), dim3(256), 0, st, E, type_tab, pos_tab,
+                           gamma, beta, query_ids, segment_ids, tok, T, vocab, o_hi, o_lo, B);
+}
+
+// model_triple.py:198-201 + pixelbert.py:813: additive key mask (1 - mask) * -10000
+__global__ void k_zk_mask(const int* len_query, const int* num_boxes, int T, float* key_add, int B) {
+    const int S = T + MMS_NBOX;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * S) return;
+    const int b = i / S, s = i % S;
+    const bool keep = s < T ? (s < len_query[b]) : ((s - T) < num_boxes[b]);
+    key_add[i] = keep ? 0.f : -10000.f;
+}
+void launch_zk_mask(const int* len_query, const int* num_boxes, int T, float* key_add, int B, hipStream_t st) {
+    if (B > 0)
+        hipLaunchKernelGGL(k_zk_mask, dim3((B * (T + MMS_NBOX) + 255) / 256), dim3(256), 0, st, len_query, num_boxes, T, key_add, B);
+}
+
+// amsoftmax_loss, model_triple.py:56-86 (label-dependent margin at inference)
+__global__ __launch_bounds__(256) void k_zk_head(const float* pooled, const float* am_kernel, const int64_t* labels,
+                                                 float scale, float margin, float* logits, float* probs, int B) {
+    const int row = wave_row();
+    if (row >= B) return;
+    Row x;
+    row_load(x, pooled + (long long)row * MMS_HIDDEN);
+    float ss = 0.f, d0 = 0.f, d1 = 0.f, k0 = 0.f, k1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = t * 256 + lane_id() * 4 + e;
+            const float v = x.v[t * 4 + e], a = am_kernel[col * 2], c = am_kernel[col * 2 + 1];
+            ss += v * v; d0 += v * a; d1 += v * c; k0 += a * a; k1 += c * c;
+        }
+    ss = wave_sum(ss); d0 = wave_sum(d0); d1 = wave_sum(d1); k0 = wave_sum(k0); k1 = wave_sum(k1);
+    const float xn = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    float c0 = d0 * xn * (1.0f / sqrtf(fmaxf(k0, 1e-10f)));
+    float c1 = d1 * xn * (1.0f / sqrtf(fmaxf(k1, 1e-10f)));
+    c0 = fminf(fmaxf(c0, -1.f), 1.f);
+    c1 = fminf(fmaxf(c1, -1.f), 1.f);
+    const int lab = labels[row] != 0;
+    const float gt = lab ? c1 : c0;
+    const float m = gt > margin ? margin : 0.f;
+    const float l0 = (c0 - (lab ? 0.f : m)) * scale, l1 = (c1 - (lab ? m : 0.f)) * scale;
+    if (lane_id() == 0) {
+        const float mx = fmaxf(l0, l1), e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.0f / (e0 + e1);
+        logits[row * 2] = l0; logits[row * 2 + 1] = l1;
+        if (probs) { probs[row * 2] = e0 * inv; probs[row * 2 + 1] = e1 * inv; }
+    }
+}
+void launch_zk_head(const float* pooled, const float* am_kernel, const int64_t* labels, float scale, float margin,
+                    float* logits, float* probs, int B, hipStream_t st) {
+    if (B > 0) hipLaunchKernelGGL(k_zk_head, row_grid(B), dim3(256), 0, st, pooled, am_kernel, labels, scale, margin, logits, probs, B);
+}
+
+// ------------------------------------------------------------------------------------------------
+// lds
+// ------------------------------------------------------------------------------------------------
+// pixelmodel.py:506-598: text = E[id] + type[segment] + pos[t] -> LN, written to rows b*S + t
+__global__ __launch_bounds__(256) void k_lds_embed_text(const float* E, const float* type_tab, const float* pos_tab,
+                                                        const float* gamma, const float* beta, const int64_t* input_ids,
+                                                        const int64_t* segment_ids, int T, int S, int vocab,
+                                                        bf16* o_hi, bf16* o_lo, int B) {
+    const int row = wave_row();
+    if (row >= B * T) return;
+    const int b = row / T, t = row % T;
+    Row x;
+    row_load(x, E + clamp_id(input_ids[row], vocab) * MMS_HIDDEN);
+    row_add(x, type_tab + clamp_id(segment_ids[row], 2) * MMS_HIDDEN);
+    row_add(x, pos_tab + t * MMS_HIDDEN);
+    row_ln(x, gamma, beta);
+    const long long off = ((long long)b * S + t) * MMS_HIDDEN;
+    row_store_planes(x, o_hi + off, o_lo + off);
+}
+void launch_lds_embed_text(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
+                           const float* beta, const int64_t* input_ids, const int64_t* segment_ids, int T, int S,
+                           int vocab, bf16* o_hi, bf16* o_lo, int B, hipStream_t st) {
+    if (B > 0)
+        hipLaunchKernelGGL(k_lds_embed_text, row_grid((long long)B * T), dim3(256), 0, st, E, type_tab, pos_tab, gamma, beta,
+                           input_ids, segment_ids, T, S, vocab, o_hi, o_lo, B);
+}
+
+// pixelmodel.py:489-498 raw reshape-matmul: out[b,box,j] = sum_k wl[k] * E[ids[b,box,j/96]][8*(j%96)+k]
+__global__ __launch_bounds__(256) void k_lds_label(const float* E, const float* wl, const int64_t* labelfeat, int vocab,
+                                                   int S, int row_off, bf16* o_hi, bf16* o_lo, int B) {
+    const int row = wave_row();
+    if (row >= B * MMS_NBOX) return;
+    const int b = row / MMS_NBOX, n = row % MMS_NBOX;
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = wl[k];
+    Row x;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = t * 256 + lane_id() * 4 + e;
+            const float* src = E + clamp_id(labelfeat[(long long)row * MMS_LABEL_LEN + j / 96], vocab) * MMS_HIDDEN + 8 * (j % 96);
+            const float4 f0 = *reinterpret_cast<const float4*>(src);
+            const float4 f1 = *reinterpret_cast<const float4*>(src + 4);
+            // same summation order as a row-vector x [8,1] matmul: k ascending
+            float a = f0.x * w[0];
+            a += f0.y * w[1]; a += f0.z * w[2]; a += f0.w * w[3];
+            a += f1.x * w[4]; a += f1.y * w[5]; a += f1.z * w[6]; a += f1.w * w[7];
+            x.v[t * 4 + e] = a;
+        }
+    const long long off = ((long long)b * S + row_off + n) * MMS_HIDDEN;
+    row_store_planes(x, o_hi + off, o_lo + off);
+}
+void launch_lds_label(const float* E, const float* wl, const int64_t* labelfeat, int vocab, int S, int row_off,
+                      bf16* o_hi, bf16* o_lo, int B, hipStream_t st) {
+    if (B > 0)
+        hipLaunchKernelGGL(k_lds_label, row_grid((long long)B * MMS_NBOX), dim3(256), 0, st, E, wl, labelfeat, vocab, S, row_off, o_hi, o_lo, B);
+}
+
+// run_pretraining_predict_score.py:479-501: logits = pooled W^T + b, W [2,768]
+__global__ __launch_bounds__(256) void k_lds_head(const float* pooled, const float* W, const float* bias,
+                                                  float* logits, float* probs, int B) {
+    const int row = wave_row();
+    if (row >= B) return;
+    Row x, w0, w1;
+    row_load(x, pooled + (long long)row * MMS_HIDDEN);
+    row_load(w0, W);
+    row_load(w1, W + MMS_HIDDEN);
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { d0 += x.v[i] * w0.v[i]; d1 += x.v[i] * w1.v[i]; }
+    d0 = wave_sum(d0) + bias[0];
+    d1 = wave_sum(d1) + bias[1];
+    if (lane_id() == 0) {
+        const float mx = fmaxf(d0, d1), e0 = expf(d0 - mx), e1 = expf(d1 - mx), inv = 1.0f / (e0 + e1);
+        logits[row * 2] = d0; logits[row * 2 + 1] = d1;
+        if (probs) { probs[row * 2] = e0 * inv; probs[row * 2 + 1] = e1 * inv; }
+    }
+}
+void launch_lds_head(const float* pooled, const float* W, const float* b, float* logits, float* probs, int B, hipStream_t st) {
+    if (B > 0) hipLaunchKernelGGL(k_lds_head, row_grid(B), dim3(256), 0, st, pooled, W, b, logits, probs, B);
+}
+
+// ------------------------------------------------------------------------------------------------
+// lxmert
+// ------------------------------------------------------------------------------------------------
+// BertEmbeddings, modeling.py:283-297: word + position(0..T-1) + token_type(0) -> LN
+__global__ __launch_bounds__(256) void k_lx_embed_lang(const float* E, const float* pos_tab, const float* type_tab,
+                                                       const float* gamma, const float* beta, const int64_t* input_ids,
+                                                       int T, int vocab, bf16* o_hi, bf16* o_lo, int B) {
+    const int row = wave_row();
+    if (row >= B * T) return;
+    Row x;
+    row_load(x, E + clamp_id(input_ids[row], vocab) * MMS_HIDDEN);
+    row_add(x, pos_tab + (row % T) * MMS_HIDDEN);
+    row_add(x, type_tab);
+    row_ln(x, gamma, beta);
+    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+}
+void launch_lx_embed_lang(const float* E, const float* pos_tab, const float* type_tab, const float* gamma,
+                          const float* beta, const int64_t* input_ids, int T, int vocab, bf16* o_hi, bf16* o_lo,
+                          int B, hipStream_t st) {
+    if (B > 0)
+        hipLaunchKernelGGL(k_lx_embed_lang, row_grid((long long)B * T), dim3(256), 0, st, E, pos_tab, type_tab, gamma, beta,
+                           input_ids, T, vocab, o_hi, o_lo, B);
+}
+
+// modeling.py:915 + 526: per unique label text, BertEmbeddings over its 8 tokens, then
+// Conv2d(8 -> 1, k = 1) over the token-position axis: z = sum_t cw[t] * emb[t] + cb
+__global__ __launch_bounds__(256) void k_lx_label_emb(const float* E, const float* pos_tab, const float* type_tab,
+                                                      const float* gamma, const float* beta, const float* conv_w,
+                                                      const float* conv_b, const int64_t* uniq_ids, int vocab,
+                                                      bf16* o_hi, bf16* o_lo, int U) {
+    const int u = wave_row();
+    if (u >= U) return;
+    Row acc;
+    row_zero(acc);
+    for (int t = 0; t < MMS_LABEL_LEN; ++t) {
+        Row x;
+        row_load(x, E + clamp_id(uniq_ids[(long long)u * MMS_LABEL_LEN + t], vocab) * MMS_HIDDEN);
+        row_add(x, pos_tab + t * MMS_HIDDEN);
+        row_add(x, type_tab);
+        row_ln(x, gamma, beta);
+        const float w = conv_w[t];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc.v[i] += w * x.v[i];
+    }
+    const float cb = conv_b[0];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc.v[i] += cb;
+    row_store_planes(acc, o_hi + (long long)u * MMS_HIDDEN, o_lo + (long long)u * MMS_HIDDEN);
+}
+void launch_lx_label_emb(const float* E, const float* pos_tab, const float* type_tab, const float* gamma,
+                         const float* beta, const float* conv_w, const float* conv_b, const int64_t* uniq_ids,
+                         int vocab, bf16* o_hi, bf16* o_lo, int U, hipStream_t st) {
+    if (U > 0)
+        hipLaunchKernelGGL(k_lx_label_emb, row_grid(U), dim3(256), 0, st, E, pos_tab, type_tab, gamma, beta, conv_w, conv_b,
+                           uniq_ids, vocab, o_hi, o_lo, U);
+}
+
+// VisualFeatEncoder, modeling.py:519-531: (LN(Wf f) + LN(Wb b) + LN(Wl conv(label))) / 3
+__global__ __launch_bounds__(256) void k_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes,
+                                                 int box_dim, const float* Wb, const float* bb, const float* g_y,
+                                                 const float* b_y, const float* z, const int* lab_index,
+                                                 bf16* o_hi, bf16* o_lo, int rows) {
+    const int row = wave_row();
+    if (row >= rows) return;
+    Row x, y;
+    row_load(x, xf + (long long)row * MMS_HIDDEN);
+    row_ln(x, g_x, b_x);
+    row_load(y, bb);
+    for (int k = 0; k < box_dim; ++k) {
+        const float bv = boxes[(long long)row * box_dim + k];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                y.v[t * 4 + e] += bv * Wb[(t * 256 + lane_id() * 4 + e) * box_dim + k];  // torch [out, in]
+    }
+    row_ln(y, g_y, b_y);
+    Row zz;
+    row_load(zz, z + (long long)lab_index[row] * MMS_HIDDEN);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x.v[i] = (x.v[i] + y.v[i] + zz.v[i]) / 3.0f;
+    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+}
+void launch_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes, int box_dim,
+                    const float* Wb, const float* bb, const float* g_y, const float* b_y, const float* z,
+                    const int* lab_index, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st) {
+    if (rows > 0)
+        hipLaunchKernelGGL(k_lx_visn, row_grid(rows), dim3(256), 0, st, xf, g_x, b_x, boxes, box_dim, Wb, bb, g_y, b_y, z,
+                           lab_index, o_hi, o_lo, rows);
+}
+
+// modeling.py:890-910: additive masks (1 - m) * -10000 for language and visual keys
+__global__ void k_lx_masks(const int64_t* input_mask, const float* visual_mask, int T, float* lang_add,
+                           float* visn_add, int B) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B * T) lang_add[i] = (1.0f - (float)input_mask[i]) * -10000.f;
+    if (i < B * MMS_NBOX) visn_add[i] = (1.0f - visual_mask[i]) * -10000.f;
+}
+void launch_lx_masks(const int64_t* input_mask, const float* visual_mask, int T, float* lang_add, float* visn_add,
+                     int B, hipStream_t st) {
+    const int n = B * (T > MMS_NBOX ? T : MMS_NBOX);
+    if (B > 0) hipLaunchKernelGGL(k_lx_masks, dim3((n + 255) / 256), dim3(256), 0, st, input_mask, visual_mask, T, lang_add, visn_add, B);
+}
+
+// logit_fc tail, kdd_model.py:167-172: LayerNorm(1536) -> Linear(1536, 2); h = GeLU(Linear(768,1536)(pooled))
+__global__ __launch_bounds__(256) void k_lx_head(const float* h, const float* gamma, const float* beta, const float* W,
+                                                 const float* bias, float* logits, float* probs, int B) {
+    const int row = wave_row();
+    if (row >= B) return;
+    const int N = 2 * MMS_HIDDEN;
+    float v[24];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const float4 f = *reinterpret_cast<const float4*>(h + (long long)row * N + t * 256 + lane_id() * 4);
+        v[t * 4] = f.x; v[t * 4 + 1] = f.y; v[t * 4 + 2] = f.z; v[t * 4 + 3] = f.w;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) s += v[i];
+    const float mean = wave_sum(s) / N;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float inv = 1.0f / sqrtf(wave_sum(q) / N + MMS_LN_EPS);
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = t * 256 + lane_id() * 4 + e;
+            const float hn = (v[t * 4 + e] - mean) * inv * gamma[col] + beta[col];
+            d0 += hn * W[col];
+            d1 += hn * W[N + col];
+        }
+    d0 = wave_sum(d0) + bias[0];
+    d1 = wave_sum(d1) + bias[1];
+    if (lane_id() == 0) {
+        const float mx = fmaxf(d0, d1), e0 = expf(d0 - mx), e1 = expf(d1 - mx), iv = 1.0f / (e0 + e1);
+        logits[row * 2] = d0; logits[row * 2 + 1] = d1;
+        if (probs) { probs[row * 2] = e0 * iv; probs[row * 2 + 1] = e1 * iv; }
+    }
+}
+void launch_lx_head(const float* h, const float* gamma, const float* beta, const float* W, const float* b, float* logits,
+                    float* probs, int B, hipStream_t st) {
+    if (B > 0) hipLaunchKernelGGL(k_lx_head, row_grid(B), dim3(256), 0, st, h, gamma, beta, W, b, logits, probs, B);
+}

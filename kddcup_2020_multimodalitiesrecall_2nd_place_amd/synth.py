@@ -51,8 +51,11 @@ def make_class_table(n_classes: int = 33, vocab: int = 21128, seed: int = SEED) 
 
 
 def make_pairs(n_queries: int, cands, *, seed: int = SEED, vocab: int = 21128, n_classes: int = 33,
-               max_query_body: int = 18, all_boxes: bool = False, tag: str = "") -> PairSet:
-    """``cands``: int (fixed candidates/query) or (lo, hi) for ragged candidate sets."""
+               max_query_body: int = 18, all_boxes: bool = False, tag: str = "", with_feats: bool = True,
+               query_offset: int = 0) -> PairSet:
+    """``cands``: int (fixed candidates/query) or (lo, hi) for ragged candidate sets.
+    ``with_feats=False`` leaves ``feats`` None (bench generates the 2.4 GB feature block on the GPU).
+    ``query_offset`` shifts query ids (per-rank shards of one logical job)."""
     t = "pairs%s/" % tag
     if isinstance(cands, int):
         per_q = np.full(n_queries, cands, dtype=np.int64)
@@ -61,8 +64,8 @@ def make_pairs(n_queries: int, cands, *, seed: int = SEED, vocab: int = 21128, n
         per_q = lo + np.floor(uniform01(t + "cands", n_queries, seed) * (hi - lo + 1)).astype(np.int64)
     B = int(per_q.sum())
     qidx = np.repeat(np.arange(n_queries), per_q)
-    query_id = 10000 + qidx.astype(np.int64)
-    product_id = 500000 + np.arange(B, dtype=np.int64) * 7
+    query_id = 10000 + query_offset + qidx.astype(np.int64)
+    product_id = 500000 + (np.arange(B, dtype=np.int64) + 64 * query_offset) * 7
 
     qlen = 1 + np.floor(uniform01(t + "qlen", n_queries, seed) * max_query_body).astype(np.int64)
     qids = 106 + np.floor(uniform01(t + "qids", n_queries * max_query_body, seed) * (vocab - 106))
@@ -77,8 +80,10 @@ def make_pairs(n_queries: int, cands, *, seed: int = SEED, vocab: int = 21128, n
         num_boxes = np.clip(np.rint(np.exp(1.1 + 0.6 * z)), 1, N_BOX).astype(np.int32)  # mean ~3.8
     live = np.arange(N_BOX)[None, :] < num_boxes[:, None]
 
-    feats = np.maximum(normal(t + "feats", (B, N_BOX, FEAT_DIM), seed), 0.0).astype(np.float32)
-    feats *= live[:, :, None]
+    feats = None
+    if with_feats:
+        feats = np.maximum(normal(t + "feats", (B, N_BOX, FEAT_DIM), seed), 0.0).astype(np.float32)
+        feats *= live[:, :, None]
     u = uniform01(t + "corners", B * N_BOX * 4, seed).reshape(B, N_BOX, 2, 2)
     u = np.sort(u, axis=2)  # (y0,x0) <= (y1,x1)
     corners = np.stack([u[:, :, 0, 0], u[:, :, 0, 1], u[:, :, 1, 0], u[:, :, 1, 1]], -1)

@@ -1,0 +1,161 @@
+"""GPU suite, model level: the HIP scorers (through the C ABI) against the CPU oracle and against
+the reference-generated goldens.  Tolerance: per-pair ||dlogit||/||logit|| <= 1e-3 in precision
+mode 2 (the north-star bound); precision mode 1 is reported against its own looser bound."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TOL_P1, TOL_P2, lxmert_case_from_meta, load_golden, small_cfg, vecrel
+from kddcup_2020_multimodalitiesrecall_2nd_place_amd import scorers, synth, weights
+from kddcup_2020_multimodalitiesrecall_2nd_place_amd.config import LdsConfig, LxmertConfig, ZkConfig
+from oracle import np_models as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(cfg, ps, **kw):
+    return synth.batch_for(cfg, ps, **kw)
+
+
+def _hip_logits(cfg, w, b, **kw):
+    s = scorers.make_scorer(cfg, w, **kw)
+    logits, probs = scorers.score_batch(s, b)
+    torch.cuda.synchronize()
+    out = logits.cpu().numpy(), probs.cpu().numpy()
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("name", ["zk", "lds", "lxmert"])
+def test_stagewise_hidden_state_matches_oracle(name):
+    """Localises any mismatch: embedding output, then each encoder step (stop_after debug knob)."""
+    cfg = small_cfg(name)
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(3, (3, 6), vocab=cfg.vocab, tag="/stage")
+    b = _batch(cfg, ps)
+    inter = {}
+    O.forward(cfg, w, b, np.float64, inter)
+    if name == "lxmert":
+        T = cfg.text_len
+        steps = [(0, np.concatenate([inter["lang_emb"].reshape(-1, 768), inter["visn_emb"].reshape(-1, 768)]))]
+        steps.append((cfg.l_layers + cfg.r_layers,
+                      np.concatenate([inter["lang_l"].reshape(-1, 768), inter["visn_r"].reshape(-1, 768)])))
+        for i in range(cfg.x_layers):
+            steps.append((cfg.l_layers + cfg.r_layers + i + 1,
+                          np.concatenate([inter["lang_x%d" % i].reshape(-1, 768), inter["visn_x%d" % i].reshape(-1, 768)])))
+    else:
+        steps = [(0, inter["embedding_output"].reshape(-1, 768))]
+        steps += [(i + 1, inter["layer_%d" % i].reshape(-1, 768)) for i in range(cfg.layers)]
+    for stop, ref in steps:
+        s = scorers.make_scorer(cfg, w, stop_after=stop)
+        scorers.score_batch(s, b)
+        got = s.read_hidden(ref.shape[0]).cpu().numpy()
+        s.close()
+        err = np.abs(got - ref).max()
+        assert err < 2e-4 * max(1.0, np.abs(ref).max()), (name, "stop_after", stop, err)
+
+
+@pytest.mark.parametrize("name", ["zk", "lds", "lxmert"])
+@pytest.mark.parametrize("dedup", [True, False])
+def test_shallow_logits_match_oracle(name, dedup):
+    cfg = small_cfg(name)
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(5, (2, 7), vocab=cfg.vocab, tag="/shallow")
+    b = _batch(cfg, ps, labels="valid") if name == "zk" else _batch(cfg, ps)
+    ref, ref_p = O.forward(cfg, w, b, np.float64)
+    got, got_p = _hip_logits(cfg, w, b, dedup_labels=dedup)
+    assert vecrel(got, ref).max() < TOL_P2, vecrel(got, ref)
+    assert np.abs(got_p - ref_p).max() < 1e-3
+
+
+@pytest.mark.parametrize("name", ["zk", "lds", "lxmert"])
+def test_full_depth_logits_match_oracle(name):
+    """BASELINE.json config 1 shape class (full 12 / 9-5-5 depth, full width), 2 queries x 12."""
+    cfg = {"zk": ZkConfig(), "lds": LdsConfig(), "lxmert": LxmertConfig()}[name]
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(2, 12, tag="/full")
+    b = _batch(cfg, ps)
+    ref, ref_p = O.forward(cfg, w, b, np.float64)
+    got, got_p = _hip_logits(cfg, w, b)
+    e2 = vecrel(got, ref)
+    assert e2.max() < TOL_P2, e2
+    assert np.abs(got_p - ref_p).max() < 1e-3
+    got1, _ = _hip_logits(cfg, w, b, precision=1)
+    e1 = vecrel(got1, ref)
+    print("\n[%s] vec-rel logit error: precision2 max %.2e  precision1 max %.2e" % (name, e2.max(), e1.max()))
+    assert e1.max() < TOL_P1, e1
+
+
+@pytest.mark.parametrize("gname", ["lxmert_shallow.npz", "lxmert_full.npz"])
+def test_lxmert_matches_reference_golden(gname):
+    """HIP path against the REFERENCE's own fp32 outputs (tests/golden/make_lxmert_golden.py)."""
+    g, meta = load_golden(gname)
+    cfg, w, b = lxmert_case_from_meta(meta)
+    got, _ = _hip_logits(cfg, w, b)
+    assert vecrel(got, g["logit"]).max() < TOL_P2
+
+
+def test_zk_margin_branch_on_gpu():
+    cfg = small_cfg("zk", layers=1)
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(2, 4, vocab=cfg.vocab, tag="/margin")
+    b = synth.zk_batch(ps, cfg.text_len)
+    inter = {}
+    O.forward(cfg, w, b, np.float64, inter)
+    k = w["cls/seq_relationship/am_kernel"].copy()
+    k[:, 1] = inter["pooled"][0] / np.linalg.norm(inter["pooled"][0])
+    w2 = dict(w)
+    w2["cls/seq_relationship/am_kernel"] = k.astype(np.float32)
+    for lab in (0, 1):
+        bb = dict(b, labels=np.full(ps.n, lab, np.int64))
+        ref, _ = O.forward(cfg, w2, bb, np.float64)
+        got, _ = _hip_logits(cfg, w2, bb)
+        assert np.abs(got - ref).max() < 3e-2 and vecrel(got, ref).max() < TOL_P2, (lab, got, ref)
+
+
+def test_edge_cases_chunking_ragged_and_truncation():
+    """chunk_pairs < B (ragged last chunk), B == 1, num_boxes > 10 (clamped by sequence_mask),
+    over-long query (SEP truncated, load_data_v4.py:83-85), all-10-box pairs."""
+    cfg = small_cfg("zk", layers=1)
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(3, (3, 5), vocab=cfg.vocab, tag="/edge", max_query_body=25, all_boxes=True)
+    b = synth.zk_batch(ps, cfg.text_len)
+    b["num_boxes"] = b["num_boxes"] + 5
+    ref, _ = O.forward(cfg, w, b, np.float64)
+    got, _ = _hip_logits(cfg, w, b, chunk_pairs=4)
+    assert vecrel(got, ref).max() < TOL_P2
+    one = {k: v[:1] for k, v in b.items()}
+    got1, _ = _hip_logits(cfg, w, one)
+    assert vecrel(got1, ref[:1]).max() < TOL_P2
+
+
+def test_call_surfaces_numpy_in_numpy_out():
+    cfg = small_cfg("lds", layers=1)
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(2, 3, vocab=cfg.vocab, tag="/surf")
+    b = synth.lds_batch(ps, cfg.text_len)
+    s = scorers.LdsScorer(cfg, w)
+    probs = s(b)
+    assert isinstance(probs, np.ndarray) and probs.shape == (ps.n, 2)
+    _, ref_p = O.forward(cfg, w, b, np.float64)
+    assert np.abs(probs - ref_p).max() < 1e-3
+    s.close()
+    cfg = small_cfg("lxmert", l_layers=1, r_layers=1, x_layers=1)
+    w = weights.make_weights(cfg)
+    b = synth.lxmert_batch(ps, cfg.text_len)
+    s = scorers.LxmertScorer(cfg, w)
+    x_norm, mlm, logit = s(b["input_ids"], b["boxes_label_input_ids"], None, b["input_mask"], None,
+                           b["boxes_label_input_mask"], b["feats"], b["boxes"], b["visual_attention_mask"])
+    assert mlm is None and logit.shape == (ps.n, 2)
+    ref, _ = O.forward(cfg, w, b, np.float64)
+    assert vecrel(logit, ref).max() < TOL_P2
+    s.close()
+    cfg = small_cfg("zk", layers=1)
+    w = weights.make_weights(cfg)
+    b = synth.zk_batch(ps, cfg.text_len)
+    s = scorers.ZkScorer(cfg, w)
+    loss, probs, loss_list = s(b["num_boxes"], b["np_boxes_5"], b["np_images_features"], b["np_idx_class_labels"], None,
+                               b["np_idx_query_"], b["len_query_"], b["labels"], b["segment_ids"], None, None, False)
+    _, ref_p = O.forward(cfg, w, b, np.float64)
+    assert np.abs(probs - ref_p).max() < 1e-3 and len(loss_list) == 1
+    s.close()
