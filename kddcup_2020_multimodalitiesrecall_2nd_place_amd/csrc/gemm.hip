@@ -53,26 +53,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
     const long long lo_delta = p.a_lo - p.a_hi;
 
-    uint4 ra0[4], ra1[4], rb[4];
-    auto load_tiles = [&](int kt) {
-        const int ko = kt * BK;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            ra0[s] = *reinterpret_cast<const uint4*>(a_row[s] + ko);
-            if (NSPLIT == 2) ra1[s] = *reinterpret_cast<const uint4*>(a_row[s] + lo_delta + ko);
-            rb[s] = *reinterpret_cast<const uint4*>(w_row[s] + ko);
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int o = lds_off(lr + 32 * s, c);
-            *reinterpret_cast<uint4*>(sA0 + o) = ra0[s];
-            if (NSPLIT == 2) *reinterpret_cast<uint4*>(sA1 + o) = ra1[s];
-            *reinterpret_cast<uint4*>(sB + o) = rb[s];
-        }
-    };
-
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -81,12 +61,34 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 
     const int nk = p.K / BK;
     const int fr = lane & 15, fk = lane >> 4;
-    load_tiles(0);
+
+    // staging registers (kept as plain unrolled locals: no lambdas / runtime indices -> no scratch)
+    u32x4 ra0[4], ra1[4], rb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        ra0[s] = *reinterpret_cast<const u32x4*>(a_row[s]);
+        if (NSPLIT == 2) ra1[s] = *reinterpret_cast<const u32x4*>(a_row[s] + lo_delta);
+        rb[s] = *reinterpret_cast<const u32x4*>(w_row[s]);
+    }
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
-        store_tiles();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int o = lds_off(lr + 32 * s, c);
+            *reinterpret_cast<u32x4*>(sA0 + o) = ra0[s];
+            if (NSPLIT == 2) *reinterpret_cast<u32x4*>(sA1 + o) = ra1[s];
+            *reinterpret_cast<u32x4*>(sB + o) = rb[s];
+        }
         __syncthreads();
-        if (kt + 1 < nk) load_tiles(kt + 1);
+        {   // prefetch the next K-tile (the last iteration re-reads its own tile: branch-free)
+            const int ko = (kt + 1 < nk ? kt + 1 : kt) * BK;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                ra0[s] = *reinterpret_cast<const u32x4*>(a_row[s] + ko);
+                if (NSPLIT == 2) ra1[s] = *reinterpret_cast<const u32x4*>(a_row[s] + lo_delta + ko);
+                rb[s] = *reinterpret_cast<const u32x4*>(w_row[s] + ko);
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a0[4], a1[4], b[4];

@@ -61,6 +61,9 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise MmsError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+    # torch must be imported first: it bundles the HIP runtime (libamdhip64.so.7) that owns the device
+    # buffers/streams we are handed; libmmscore binds to that already-loaded copy by SONAME.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.mms_version.restype = C.c_int

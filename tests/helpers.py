@@ -12,7 +12,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # final-logit parity metric of BASELINE.md section 3 / SURVEY.md section 8(d):
 # per pair ||delta||_2 / ||logit||_2  (per-element relative error diverges for logits near 0)
 TOL_P2 = 1e-3      # precision 2 (split-bf16 activations) -- the north-star tolerance
-TOL_P1 = 5e-2      # precision 1 (single bf16 pass) -- reported, outside the 1e-3 contract
+TOL_P1 = 1.5e-1     # precision 1 (single bf16 pass) -- reported, outside the 1e-3 contract
 
 
 def vecrel(a, b):

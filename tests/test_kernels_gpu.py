@@ -80,7 +80,8 @@ def test_gemm_transpose_detecting():
     a[np.arange(M), np.arange(M)] = 1.0
     w = weights.round_to_bf16((np.arange(N)[:, None] * 0.25 + np.arange(K)[None, :] * 2.0).astype(np.float32))
     out = torch.empty((M, N), device="cuda", dtype=torch.float32)
-    rc = l.mms_dbg_gemm(_dev(a).data_ptr(), M, K, K, _dev(w).data_ptr(), N, None, None, 0, 2, 0, out.data_ptr(), None)
+    da, dw = _dev(a), _dev(w)  # keep the device buffers alive across the call
+    rc = l.mms_dbg_gemm(da.data_ptr(), M, K, K, dw.data_ptr(), N, None, None, 0, 2, 0, out.data_ptr(), None)
     assert rc == 0
     assert np.array_equal(out.cpu().numpy(), w.T)
 
@@ -118,7 +119,13 @@ def test_attention_matches_fp64(case):
     p /= p.sum(-1, keepdims=True)
     ref = (p @ V).transpose(0, 2, 1, 3).reshape(B * Sq, 768)
     got = out.cpu().numpy().astype(np.float64)
-    assert np.abs(got - ref).max() < 3e-5 * max(1.0, np.abs(ref).max()), case
+    scale = max(1.0, np.abs(ref).max())
+    lo = Sq if masked else 0
+    assert np.abs(got[lo:] - ref[lo:]).max() < 3e-5 * scale, case
+    if masked:
+        # pair 0 has EVERY key at -10000: fp32 scores near 1e4 are quantised to ~1e-3 (in the fp32
+        # reference too), so only a loose bound is meaningful there
+        assert np.abs(got[:lo] - ref[:lo]).max() < 5e-3 * scale, case
 
 
 def test_layernorm_matches_fp64():
@@ -128,7 +135,8 @@ def test_layernorm_matches_fp64():
     g = weights.normal("kt/lng", (768,), 3, 0.1, 1.0)
     b = weights.normal("kt/lnb", (768,), 3, 0.1)
     out = torch.empty((M, 768), device="cuda", dtype=torch.float32)
-    rc = l.mms_dbg_layernorm(_dev(x).data_ptr(), _dev(g).data_ptr(), _dev(b).data_ptr(), M, out.data_ptr(), None)
+    dx, dg, db = _dev(x), _dev(g), _dev(b)
+    rc = l.mms_dbg_layernorm(dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, out.data_ptr(), None)
     assert rc == 0
     x64 = x.astype(np.float64)
     mu = x64.mean(-1, keepdims=True)
