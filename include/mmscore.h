@@ -126,6 +126,10 @@ int mms_debug_read_x(mms_handle* h, float* dst_dev, int64_t rows, void* stream);
 int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const float* w_f32_nk, int64_t N,
                  const float* bias, const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes,
                  float* c_f32, void* stream);
+/* experiments: select the GEMM kernel configuration (0 = default) / time one GEMM shape on random data */
+int mms_set_gemm_variant(int32_t variant);
+int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t act, int32_t out_planes, int32_t resid,
+                       int32_t variant, int32_t iters, float* ms_out);
 int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B, int32_t Sq, int32_t Sk,
                       const float* key_add, float* out_f32, void* stream);
 int mms_dbg_layernorm(const float* x, const float* gamma, const float* beta, int64_t M, float* out_f32, void* stream);

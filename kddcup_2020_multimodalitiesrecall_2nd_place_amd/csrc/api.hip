@@ -789,6 +789,60 @@ int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const fl
     return MMS_OK;
 }
 
+__global__ void k_fill_random(float* p, long long n, unsigned seed) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        unsigned x = (unsigned)(i * 2654435761u) ^ seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = (float)(int)x * (1.0f / 2147483648.0f);   // uniform [-1, 1)
+    }
+}
+
+int mms_set_gemm_variant(int32_t v) { set_gemm_variant(v); return MMS_OK; }
+
+// GEMM micro-benchmark on random operands: returns the average kernel time (ms) over `iters` launches.
+int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t act, int32_t out_planes, int32_t resid,
+                       int32_t variant, int32_t iters, float* ms_out) {
+    if (M <= 0 || N % 128 || K % 64 || iters <= 0 || !ms_out) { g_err = "mms_dbg_gemm_bench: bad argument"; return MMS_ERR_ARG; }
+    float *af = nullptr, *wf = nullptr, *rf = nullptr, *bias = nullptr, *cf = nullptr;
+    bf16 *ap = nullptr, *wp = nullptr, *rp = nullptr, *cp = nullptr;
+    DBG_TRY(hipMalloc((void**)&af, (size_t)M * K * 4)); DBG_TRY(hipMalloc((void**)&wf, (size_t)N * K * 4));
+    DBG_TRY(hipMalloc((void**)&rf, (size_t)M * N * 4)); DBG_TRY(hipMalloc((void**)&bias, (size_t)N * 4));
+    DBG_TRY(hipMalloc((void**)&ap, (size_t)M * K * 4)); DBG_TRY(hipMalloc((void**)&wp, (size_t)N * K * 4));
+    DBG_TRY(hipMalloc((void**)&rp, (size_t)M * N * 4)); DBG_TRY(hipMalloc((void**)&cp, (size_t)M * N * 4));
+    DBG_TRY(hipMalloc((void**)&cf, (size_t)M * N * 4));
+    hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, af, M * K, 1u);
+    hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, wf, N * K, 2u);
+    hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, rf, M * N, 3u);
+    hipLaunchKernelGGL(k_fill_random, dim3(64), dim3(256), 0, 0, bias, N, 4u);
+    launch_split_f32(af, ap, ap + M * K, M * K, 0);
+    launch_split_f32(wf, wp, wp + N * K, N * K, 0);
+    launch_split_f32(rf, rp, rp + M * N, M * N, 0);
+    GemmParams p{};
+    p.a_hi = ap; p.a_lo = ap + M * K; p.lda = (int)K; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
+    p.w = wp; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
+    if (resid) { p.r_hi = rp; p.r_lo = rp + M * N; p.ldr = (int)N; }
+    if (out_planes) { p.out_kind = OUT_PLANES; p.c_hi = cp; p.c_lo = cp + M * N; p.ldp = (int)N; }
+    else { p.out_kind = OUT_F32; p.c_f32 = cf; p.ldc = (int)N; }
+    const int saved = get_gemm_variant();
+    set_gemm_variant(variant);
+    hipEvent_t e0, e1;
+    DBG_TRY(hipEventCreate(&e0)); DBG_TRY(hipEventCreate(&e1));
+    launch_gemm(p, nsplit, 0);
+    launch_gemm(p, nsplit, 0);
+    DBG_TRY(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) launch_gemm(p, nsplit, 0);
+    DBG_TRY(hipEventRecord(e1, 0));
+    DBG_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    DBG_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    set_gemm_variant(saved);
+    DBG_TRY(hipGetLastError());
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    for (void* q : {(void*)af, (void*)wf, (void*)rf, (void*)bias, (void*)cf, (void*)ap, (void*)wp, (void*)rp, (void*)cp}) (void)hipFree(q);
+    return MMS_OK;
+}
+
 int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B, int32_t Sq, int32_t Sk, const float* key_add,
                       float* out_f32, void* stream) {
     if (!q || !k || !v || !out_f32 || B <= 0 || Sq <= 0 || Sk <= 0 || Sq > 48 || Sk > 48) { g_err = "mms_dbg_attention: bad argument"; return MMS_ERR_ARG; }

@@ -13,6 +13,8 @@
 // lo activation planes are two MFMA passes sharing one weight fragment (2x MFMA, 1x weight traffic).
 // Workgroup ids are remapped so each XCD (private L2) walks a contiguous range of tiles: the N/128
 // column tiles that share one A row-panel hit the same L2.
+#include <cstdlib>
+
 #include "kernels.h"
 
 #define BM 128
@@ -158,9 +160,22 @@ static void launch_ns(const GemmParams& p, int nblk, hipStream_t st) {
     }
 }
 
+static int g_variant = -1;
+void set_gemm_variant(int v) { g_variant = v; }
+int get_gemm_variant() {
+    if (g_variant < 0) {
+        const char* e = getenv("MMS_GEMM_VARIANT");
+        g_variant = e ? atoi(e) : 4;   // 128x256 tile, 8 waves, register-staged: best measured (profiles/r01c_gemm_variants.txt)
+    }
+    return g_variant;
+}
+
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
     if (nblk <= 0) return;
+    const int variant = get_gemm_variant();
+    if (variant > 0 && launch_gemm_tile(p, nsplit, variant, st)) return;
+    if (variant > 0 && launch_gemm_tile(p, nsplit, 1, st)) return;   // N % 256 != 0: 128x128 tile
     if (nsplit == 2) launch_ns<2>(p, nblk, st);
     else launch_ns<1>(p, nblk, st);
 }

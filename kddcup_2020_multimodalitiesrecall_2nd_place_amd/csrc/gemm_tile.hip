@@ -1,0 +1,250 @@
+// Generalised bf16 MFMA GEMM tile kernel (gfx950): configurable workgroup tile / wave grid, LDS-DMA
+// (global_load_lds) double-buffered operand staging, LDS-staged vectorised epilogue.
+//
+// Same contract as gemm.hip (GemmParams): C = act(A W^T + bias (+ residual)), A in split planes.
+//
+//  * STAGE_GLDS = 1: operand tiles go HBM/L2 -> LDS directly with `global_load_lds_dwordx4` (no VGPR
+//    round trip, no ds_write).  The LDS image is lane-linear per wave instruction (1 KiB = 8 rows of
+//    128 B), so the bank-conflict swizzle is applied on the per-lane SOURCE address: LDS slot cpos of
+//    row r is filled from global chunk cpos ^ ((r>>1)&7); fragment reads use the same involution.
+//    Two stage buffers: tile k+1 streams in while tile k feeds the MFMAs; one barrier per K-step.
+//  * STAGE_GLDS = 0: global -> VGPR -> LDS, single buffer (the round-1a structure, kept for A/B).
+//  * Epilogue: each wave bounces its accumulators through a private LDS strip 16 rows at a time and
+//    re-reads them row-contiguous, so bias / residual / activation / split run on float4 and global
+//    stores are 16 B (fp32) or 8 B (bf16x4 per plane) per lane, 256 / 128 contiguous bytes per row.
+#include "kernels.h"
+
+#define BK 64
+
+__device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int NSPLIT, int ACT, int BM, int BN, int WAVES_M, int WAVES_N, int STAGE_GLDS>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const GemmParams p) {
+    constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
+    constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, FM = TM / 16, FN = TN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int STAGE_BYTES = NSPLIT * A_BYTES + B_BYTES;
+    constexpr int NBUF = STAGE_GLDS ? 2 : 1;
+    constexpr int EPI_BYTES = NW * 16 * (TN + 4) * 4;
+    constexpr int SMEM_BYTES = NBUF * STAGE_BYTES > EPI_BYTES ? NBUF * STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int nbn = p.N / BN, nbm = (p.M + BM - 1) / BM, nblk = nbm * nbn;
+    int bid = blockIdx.x;
+    {   // bijective XCD remap (block b runs on XCD b % 8; speed only)
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int bm = bid / nbn, bn = bid % nbn;
+    const long long lo_delta = p.a_lo - p.a_hi;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    const int fr = lane & 15, fk = lane >> 4;
+
+    auto compute = [&](const unsigned char* sb) {
+        const unsigned char* sA0 = sb;
+        const unsigned char* sA1 = sb + A_BYTES;
+        const unsigned char* sB = sb + NSPLIT * A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a0[FM], a1[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int o = lds_off(wm * TM + i * 16 + fr, ks * 4 + fk);
+                a0[i] = *reinterpret_cast<const bf16x8*>(sA0 + o);
+                if (NSPLIT == 2) a1[i] = *reinterpret_cast<const bf16x8*>(sA1 + o);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * TN + j * 16 + fr, ks * 4 + fk));
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b[j], acc[i][j], 0, 0, 0);
+                    if (NSPLIT == 2)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    if constexpr (STAGE_GLDS) {
+        // one wave instruction fills one 1-KiB row group (8 rows x 128 B): lane -> (row g*8 + lane/8, slot lane%8)
+        constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;  // row groups per wave
+        static_assert(GA >= 1 && GB >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile/wave mismatch");
+        const bf16* a_src[GA];
+        const bf16* w_src[GB];
+#pragma unroll
+        for (int s = 0; s < GA; ++s) {
+            const int r = (wave + NW * s) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gr = bm * BM + r;
+            gr = gr < p.M ? gr : p.M - 1;
+            a_src[s] = p.a_hi + p.amap(gr) * (long long)p.lda + c * 8;
+        }
+#pragma unroll
+        for (int s = 0; s < GB; ++s) {
+            const int r = (wave + NW * s) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            w_src[s] = p.w + (long long)(bn * BN + r) * p.K + c * 8;
+        }
+        auto issue = [&](int kt, unsigned char* sb) {
+            const int ko = kt * BK;
+#pragma unroll
+            for (int s = 0; s < GA; ++s) {
+                unsigned char* d = sb + (wave + NW * s) * 1024;
+                __builtin_amdgcn_global_load_lds((glb_void*)(a_src[s] + ko), (lds_void*)d, 16, 0, 0);
+                if (NSPLIT == 2)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(a_src[s] + lo_delta + ko), (lds_void*)(d + A_BYTES), 16, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < GB; ++s) {
+                unsigned char* d = sb + NSPLIT * A_BYTES + (wave + NW * s) * 1024;
+                __builtin_amdgcn_global_load_lds((glb_void*)(w_src[s] + ko), (lds_void*)d, 16, 0, 0);
+            }
+        };
+        issue(0, smem);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt have landed
+            __syncthreads();                                    // ... everyone's have; buffer (kt+1)&1 is free
+            if (kt + 1 < nk) issue(kt + 1, smem + ((kt + 1) & 1) * STAGE_BYTES);
+            compute(smem + (kt & 1) * STAGE_BYTES);
+        }
+    } else {
+        constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;  // 16-B chunks per thread per tile
+        static_assert(CA >= 1 && CB >= 1, "tile/thread mismatch");
+        const int c = tid & 7, lr = tid >> 3;
+        const bf16* a_row[CA];
+        const bf16* w_row[CB];
+#pragma unroll
+        for (int s = 0; s < CA; ++s) {
+            int r = bm * BM + lr + (NT / 8) * s;
+            r = r < p.M ? r : p.M - 1;
+            a_row[s] = p.a_hi + p.amap(r) * (long long)p.lda + c * 8;
+        }
+#pragma unroll
+        for (int s = 0; s < CB; ++s) w_row[s] = p.w + (long long)(bn * BN + lr + (NT / 8) * s) * p.K + c * 8;
+        u32x4 ra0[CA], ra1[CA], rb[CB];
+#pragma unroll
+        for (int s = 0; s < CA; ++s) {
+            ra0[s] = *reinterpret_cast<const u32x4*>(a_row[s]);
+            if (NSPLIT == 2) ra1[s] = *reinterpret_cast<const u32x4*>(a_row[s] + lo_delta);
+        }
+#pragma unroll
+        for (int s = 0; s < CB; ++s) rb[s] = *reinterpret_cast<const u32x4*>(w_row[s]);
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < CA; ++s) {
+                const int o = lds_off(lr + (NT / 8) * s, c);
+                *reinterpret_cast<u32x4*>(smem + o) = ra0[s];
+                if (NSPLIT == 2) *reinterpret_cast<u32x4*>(smem + A_BYTES + o) = ra1[s];
+            }
+#pragma unroll
+            for (int s = 0; s < CB; ++s)
+                *reinterpret_cast<u32x4*>(smem + NSPLIT * A_BYTES + lds_off(lr + (NT / 8) * s, c)) = rb[s];
+            __syncthreads();
+            const int ko = (kt + 1 < nk ? kt + 1 : kt) * BK;
+#pragma unroll
+            for (int s = 0; s < CA; ++s) {
+                ra0[s] = *reinterpret_cast<const u32x4*>(a_row[s] + ko);
+                if (NSPLIT == 2) ra1[s] = *reinterpret_cast<const u32x4*>(a_row[s] + lo_delta + ko);
+            }
+#pragma unroll
+            for (int s = 0; s < CB; ++s) rb[s] = *reinterpret_cast<const u32x4*>(w_row[s] + ko);
+            compute(smem);
+        }
+    }
+
+    // ---- epilogue: accumulators -> per-wave LDS strip (16 rows) -> row-contiguous float4 ----
+    __syncthreads();  // all waves are done reading operand tiles
+    constexpr int ES = TN + 4;                      // strip row stride in floats
+    float* strip = reinterpret_cast<float*>(smem) + wave * 16 * ES;
+    constexpr int V4_PER_ROW = TN / 4, ROWS_PER_IT = 64 / V4_PER_ROW, ITERS = 16 / ROWS_PER_IT;
+    const int er = lane / V4_PER_ROW, ec = (lane % V4_PER_ROW) * 4;
+    const int col = bn * BN + wn * TN + ec;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) strip[(fk * 4 + r) * ES + j * 16 + fr] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < ITERS; ++t) {
+            const int lrow = t * ROWS_PER_IT + er;
+            const int row = bm * BM + wm * TM + i * 16 + lrow;
+            f32x4 v = *reinterpret_cast<const f32x4*>(strip + lrow * ES + ec);
+            if (row < p.M) {
+                v += bias4;
+                if (p.r_hi) {
+                    const long long ro = (long long)row * p.ldr + col;
+                    const bf16x4 rh = *reinterpret_cast<const bf16x4*>(p.r_hi + ro);
+                    const bf16x4 rl = *reinterpret_cast<const bf16x4*>(p.r_lo + ro);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += join_bf16(rh[e], rl[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT);
+                const long long orow = p.cmap(row);
+                if (p.out_kind == OUT_F32) {
+                    *reinterpret_cast<f32x4*>(p.c_f32 + orow * p.ldc + col) = v;
+                } else {
+                    bf16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bf16 a, c2; split_bf16(v[e], a, c2); h[e] = a; l[e] = c2; }
+                    *reinterpret_cast<bf16x4*>(p.c_hi + orow * p.ldp + col) = h;
+                    *reinterpret_cast<bf16x4*>(p.c_lo + orow * p.ldp + col) = l;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+template <int NSPLIT, int BM, int BN, int WM, int WN, int G>
+static void launch_cfg(const GemmParams& p, hipStream_t st) {
+    const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
+    const dim3 grid(nblk), block(WM * WN * 64);
+    switch (p.act) {
+        case ACT_RELU: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_RELU, BM, BN, WM, WN, G>), grid, block, 0, st, p); break;
+        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_GELU_TANH, BM, BN, WM, WN, G>), grid, block, 0, st, p); break;
+        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_GELU_ERF, BM, BN, WM, WN, G>), grid, block, 0, st, p); break;
+        case ACT_TANH: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_TANH, BM, BN, WM, WN, G>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_NONE, BM, BN, WM, WN, G>), grid, block, 0, st, p); break;
+    }
+}
+
+template <int NSPLIT>
+static bool launch_variant(const GemmParams& p, int variant, hipStream_t st) {
+    switch (variant) {
+        case 1: launch_cfg<NSPLIT, 128, 128, 2, 2, 0>(p, st); return true;                          // reg-staged 128x128
+        case 3: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1>(p, st); return true;  // LDS-DMA, double buffered
+        case 4: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 0>(p, st); return true;  // reg-staged 128x256 (default)
+        default: return false;
+    }
+}
+
+bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st) {
+    if (p.M <= 0) return true;
+    return nsplit == 2 ? launch_variant<2>(p, variant, st) : launch_variant<1>(p, variant, st);
+}

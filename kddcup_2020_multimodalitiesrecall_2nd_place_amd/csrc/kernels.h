@@ -20,6 +20,9 @@ struct GemmParams {
     const bf16* r_hi; const bf16* r_lo; int ldr;  // residual planes (logical rows) or nullptr
 };
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
+bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
+void set_gemm_variant(int v);   // 0 = gemm.hip kernel, >0 = gemm_tile.hip configurations
+int get_gemm_variant();
 
 // ---------------------------------------------------------------------------------------------
 // Attention for one (pair, head) per wavefront, S <= 48               (attn.hip)

@@ -49,7 +49,8 @@ class LxmertBatch(C.Structure):
 
 EXPORTS = ("mms_version", "mms_global_error", "mms_create", "mms_destroy", "mms_last_error", "mms_load_weight",
            "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_gemm_timing",
-           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_attention", "mms_dbg_layernorm")
+           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_attention", "mms_dbg_layernorm", "mms_set_gemm_variant",
+           "mms_dbg_gemm_bench")
 
 _lib = None
 
@@ -83,6 +84,8 @@ def load():
     lib.mms_dbg_gemm.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, i32, i32, i32, vp, vp]
     lib.mms_dbg_attention.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     lib.mms_dbg_layernorm.argtypes = [vp, vp, vp, i64, vp, vp]
+    lib.mms_set_gemm_variant.argtypes = [i32]
+    lib.mms_dbg_gemm_bench.argtypes = [i64, i64, i64, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float)]
     _lib = lib
     return lib
 

@@ -42,9 +42,21 @@ GEMM_CASES = [
 ]
 
 
+GEMM_VARIANTS = [0, 1, 3, 4]
+
+
+@pytest.fixture
+def gemm_variant(request):
+    l = lib.load()
+    l.mms_set_gemm_variant(request.param)
+    yield request.param
+    l.mms_set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("gemm_variant", GEMM_VARIANTS, indirect=True)
 @pytest.mark.parametrize("nsplit", [2, 1])
 @pytest.mark.parametrize("case", GEMM_CASES)
-def test_gemm_matches_fp64(case, nsplit):
+def test_gemm_matches_fp64(case, nsplit, gemm_variant):
     M, K, N, act, resid, planes = case
     l = lib.load()
     a = weights.normal("kt/a/%d/%d" % (M, K), (M, K), 1)
@@ -69,10 +81,11 @@ def test_gemm_matches_fp64(case, nsplit):
     err = np.abs(got - ref).max() / np.abs(ref).max()
     # nsplit 2: activations carried as hi+lo (>= 16 bits); nsplit 1 reference already uses bf16(a)
     tol = 3e-5 if nsplit == 2 else 2e-5
-    assert err < tol, (case, nsplit, err)
+    assert err < tol, (case, nsplit, gemm_variant, err)
 
 
-def test_gemm_transpose_detecting():
+@pytest.mark.parametrize("gemm_variant", GEMM_VARIANTS, indirect=True)
+def test_gemm_transpose_detecting(gemm_variant):
     """A = [I | 0]: C must reproduce W^T rows (asymmetric W) -- catches row/col swaps."""
     l = lib.load()
     M, K, N = 128, 128, 128

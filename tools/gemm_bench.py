@@ -1,0 +1,27 @@
+"""GEMM micro-benchmark over the hot shapes of one 4096-pair zk chunk (random operands).
+usage: python tools/gemm_bench.py [variants...]   (on the GPU box)"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kddcup_2020_multimodalitiesrecall_2nd_place_amd import lib  # noqa: E402
+
+M = int(os.environ.get("GB_M", 122880))
+SHAPES = [  # name, N, K, act, planes, resid
+    ("qkv", 2304, 768, 0, 0, 0),
+    ("attout", 768, 768, 0, 0, 1),
+    ("ffn_up", 3072, 768, 2, 1, 0),
+    ("ffn_down", 768, 3072, 0, 0, 1),
+]
+l = lib.load()
+variants = [int(v) for v in sys.argv[1:]] or [0, 1, 3, 4]
+for nsplit in (2, 1):
+    for name, N, K, act, planes, resid in SHAPES:
+        row = []
+        for v in variants:
+            ms = C.c_float(0)
+            rc = l.mms_dbg_gemm_bench(M, N, K, nsplit, act, planes, resid, v, 10, C.byref(ms))
+            assert rc == 0, l.mms_global_error()
+            row.append("v%d %7.3fms %6.0fTF" % (v, ms.value, 2.0 * M * N * K / ms.value / 1e9))
+        print("nsplit=%d %-9s %s" % (nsplit, name, " | ".join(row)), flush=True)
