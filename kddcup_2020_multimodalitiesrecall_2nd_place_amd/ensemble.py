@@ -1,0 +1,80 @@
+"""Score ensemble + product-uniqueness post-process + top-5 submission.
+
+Restates ``code/main.py:41-104`` of the reference:
+* merge: ``0.2*zk + 0.2*zk_sen2forest + 0.3*lds + 0.3*lxmert`` per (query, product) (:59); a product missing
+  from one of the first three tables falls back to the lxmert score (:49-57);
+* per product, the best merged score over ALL queries and the sorted list of its merged scores (:64-71);
+* uniqueness filter (:76-86): a (query, product) survives only if it is that product's best-scoring query
+  (|score - best| < 1e-5) and, when the product appears under >= 2 queries, its best beats its
+  second best by >= 0.92;
+* top-5 per query by merged score; a query left with < 5 survivors falls back to its unfiltered
+  merged ranking (:93-104).
+The filter is global over queries, so under query sharding it runs on rank 0 after the score gather.
+Pure host-side dict work (29 k entries), exactly as in the reference.
+"""
+from __future__ import annotations
+
+import csv
+from collections import OrderedDict
+
+WEIGHTS = (0.2, 0.2, 0.3, 0.3)
+GAP = 0.92
+TIE = 1e-5
+
+
+def merge_scores(zk, zk_s2f, lds, lxmert, weights=WEIGHTS):
+    merged: OrderedDict = OrderedDict()
+    for q in zk:
+        r1, r2, r3, r4 = zk[q], zk_s2f[q], lds[q], lxmert[q]
+        mq = merged.setdefault(q, OrderedDict())
+        for p, s4 in r4.items():
+            s1, s2, s3 = r1.get(p, s4), r2.get(p, s4), r3.get(p, s4)
+            mq[p] = weights[0] * s1 + weights[1] * s2 + weights[2] * s3 + weights[3] * s4
+    return merged
+
+
+def uniqueness_filter(merged, gap=GAP, tie=TIE):
+    scores_of = {}
+    for q, d in merged.items():
+        for p, s in d.items():
+            scores_of.setdefault(p, []).append(s)
+    best, keep_product = {}, {}
+    for p, lst in scores_of.items():
+        lst.sort(reverse=True)
+        best[p] = lst[0]
+        keep_product[p] = len(lst) < 2 or not (lst[0] - lst[1] < gap)
+    out: OrderedDict = OrderedDict()
+    for q, d in merged.items():
+        for p, s in d.items():
+            if keep_product[p] and abs(s - best[p]) < tie:
+                out.setdefault(q, OrderedDict())[p] = s
+    return out
+
+
+def top5(merged, filtered):
+    """{query: [p1..p5]}: filtered ranking when it has >= 5 entries, else the unfiltered one (main.py:93-104)."""
+    rows: OrderedDict = OrderedDict()
+    short = []
+    for q in filtered:
+        r = sorted(filtered[q].items(), key=lambda kv: kv[1], reverse=True)
+        if len(r) < 5:
+            short.append(q)
+            continue
+        rows[q] = [p for p, _ in r[:5]]
+    for q in short:
+        r = sorted(merged[q].items(), key=lambda kv: kv[1], reverse=True)
+        rows[q] = [p for p, _ in r[:5]]
+    return rows
+
+
+def ensemble(zk, zk_s2f, lds, lxmert):
+    merged = merge_scores(zk, zk_s2f, lds, lxmert)
+    return top5(merged, uniqueness_filter(merged))
+
+
+def write_submission(path, rows):
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["query-id", "product1", "product2", "product3", "product4", "product5"])
+        for q, ps in rows.items():
+            w.writerow([q] + list(ps))
