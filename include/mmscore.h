@@ -59,6 +59,9 @@ typedef struct mms_config {
     int32_t chunk_pairs;      /* pairs per internal launch wave (0 = default 4096) */
     int32_t stop_after;       /* debug: run only the first n encoder layers (-1 = all) and skip nothing else */
     int32_t device;           /* HIP device ordinal */
+    int32_t pack_tokens;      /* zk/lxmert: 1 = drop padded tokens whose keys are masked (identical logits: a masked
+                                 key's softmax weight is exactly 0 in fp32); 0 = dense padded rows like the reference.
+                                 lds has no mask (pixelmodel.py:189-190) and must use 0 */
 } mms_config;
 
 /* zk feed, code/imagebert_zk/evaluate_normal.py:141-152.  np_idx_class_labels [B,10,8] is passed

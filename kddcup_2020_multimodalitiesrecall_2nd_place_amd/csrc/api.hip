@@ -70,6 +70,10 @@ struct mms_handle {
     Planes x, ctx, y, mid;
     float *qkv = nullptr, *t = nullptr, *key_add = nullptr, *key_add2 = nullptr, *pooled = nullptr, *hbuf = nullptr;
     int64_t x_rows = 0;  // rows of the hidden state per pair-chunk (for mms_debug_read_x)
+    // packed (ragged) execution plan of the current chunk: per-pair first row / live count, per-row source
+    // token, device-side live row totals (stream 0: zk tokens or lxmert language, stream 1: lxmert vision)
+    int *pk_off[2] = {nullptr, nullptr}, *pk_cnt[2] = {nullptr, nullptr}, *pk_src[2] = {nullptr, nullptr}, *pk_rows = nullptr;
+    unsigned long long* flop_counter = nullptr;
     // label-text workspace, sized for lab_cap unique labels
     int64_t lab_cap = 0;
     Planes lab_planes; float *lab_f32 = nullptr, *lab_feat = nullptr; int64_t lab_feat_cap = 0;
@@ -78,7 +82,6 @@ struct mms_handle {
     bool timing = false;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
-    double gemm_flops = 0;
     int64_t gemm_launches = 0;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -355,6 +358,16 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     h->pooled = (float*)p;
     if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)pairs * 2 * H * 4)) return rc;
     h->hbuf = (float*)p;
+    for (int s = 0; s < 2; ++s) {
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)pairs * 4)) return rc;
+        h->pk_off[s] = (int*)p;
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)pairs * 4)) return rc;
+        h->pk_cnt[s] = (int*)p;
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * 4)) return rc;
+        h->pk_src[s] = (int*)p;
+    }
+    if (int rc = dev_alloc(h, h->ws_allocs, &p, 16)) return rc;
+    h->pk_rows = (int*)p;
     h->ws_pairs = pairs;
     return MMS_OK;
 }
@@ -390,7 +403,8 @@ struct GemmOut {
 };
 
 int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf16* w, const float* bias, int64_t M,
-         int N, int K, int act, const GemmOut& out, const Planes* resid = nullptr) {
+         int N, int K, int act, const GemmOut& out, const Planes* resid = nullptr, const int* m_dev = nullptr,
+         const int* a_index = nullptr) {
     if (M <= 0) return MMS_OK;
     if (N % 128 || K % 64) return h->fail(MMS_ERR_ARG, "gemm: N % 128 or K % 64 != 0");
     GemmParams p{};
@@ -401,17 +415,18 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     p.c_f32 = out.f32; p.ldc = out.ldc;
     p.c_hi = out.pl.hi; p.c_lo = out.pl.lo; p.ldp = out.ldp; p.cmap = out.cmap;
     if (resid) { p.r_hi = resid->hi; p.r_lo = resid->lo; p.ldr = H; }
-    if (h && h->timing) {
+    p.m_dev = m_dev; p.a_index = a_index;
+    if (h->timing) {
         if (h->ev_used + 2 > h->ev.size()) {
             h->ev.resize(h->ev_used + 2);
             HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used]));
             HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used + 1]));
         }
+        p.flop_counter = h->flop_counter;   // executed algorithmic FLOPs (2*M_live*N*K), counted on the device
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
         launch_gemm(p, h->nsplit, st);
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
         h->ev_used += 2;
-        h->gemm_flops += 2.0 * (double)M * N * K;
         h->gemm_launches += 1;
     } else {
         launch_gemm(p, h->nsplit, st);
@@ -423,38 +438,41 @@ GemmOut to_f32(float* p, int ldc) { GemmOut o; o.f32 = p; o.ldc = ldc; return o;
 GemmOut to_planes(Planes p, int ldp, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.pl = p; o.ldp = ldp; o.cmap = m; return o; }
 const RowMap ID{0, 0, 0};
 
+// Packed-stream descriptor: per-pair first row / live count (relative to the stream's first row) and the
+// device-side number of live rows.  off == nullptr: dense layout (row of (b, s) = b * S + s).
+struct Pack { const int* off = nullptr; const int* cnt = nullptr; const int* rows = nullptr; };
+
 // attention sub-layer: out = LN(dense(attn(in_q, in_kv)) + in_q)    (pixelbert.py:932-966, modeling.py:355-392)
-// All row offsets are in rows of the [rows, 768] hidden-state buffers; qkv rows mirror them.
-int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes out, int64_t q_row0, int Sq, int64_t kv_row0,
-              int Sk, int64_t B, const float* key_add, bool qkv_ready = false, int64_t proj_row0 = 0, int64_t proj_rows = 0) {
-    if (!qkv_ready) {
-        // self-attention: one fused QKV projection over the q rows (q rows == kv rows)
-        if (int rc = gemm(h, st, in.at(q_row0 * H), H, ID, w.wqkv, w.bqkv, B * Sq, 3 * H, H, ACT_NONE,
-                          to_f32(h->qkv + q_row0 * 3 * H, 3 * H))) return rc;
-    }
-    (void)proj_row0; (void)proj_rows;
+// self-attention over one stream whose first row is row0; S = (maximum) tokens per pair.
+int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes out, int64_t row0, int S, int64_t B,
+              const float* key_add, const Pack& pk = Pack()) {
+    const int64_t M = B * S;
+    if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wqkv, w.bqkv, M, 3 * H, H, ACT_NONE,
+                      to_f32(h->qkv + row0 * 3 * H, 3 * H), nullptr, pk.rows)) return rc;
     AttnParams a{};
-    a.q = h->qkv + q_row0 * 3 * H; a.ldq = 3 * H;
-    a.k = h->qkv + kv_row0 * 3 * H + H; a.v = h->qkv + kv_row0 * 3 * H + 2 * H; a.ldkv = 3 * H;
-    a.q_base = 0; a.Sq = Sq; a.kv_base = 0; a.Sk = Sk;
+    a.q = h->qkv + row0 * 3 * H; a.ldq = 3 * H;
+    a.k = a.q + H; a.v = a.q + 2 * H; a.ldkv = 3 * H;
+    a.q_base = 0; a.Sq = S; a.kv_base = 0; a.Sk = S;
     a.key_add = key_add;
-    a.o_hi = h->ctx.hi + q_row0 * H; a.o_lo = h->ctx.lo + q_row0 * H; a.ldo = H;
+    a.o_hi = h->ctx.hi + row0 * H; a.o_lo = h->ctx.lo + row0 * H; a.ldo = H;
     a.B = (int)B;
+    a.q_off = a.kv_off = pk.off; a.q_cnt = a.kv_cnt = pk.cnt;
     launch_attention(a, st);
-    const Planes resid = in.at(q_row0 * H);
-    if (int rc = gemm(h, st, h->ctx.at(q_row0 * H), H, ID, w.wo, w.bo, B * Sq, H, H, ACT_NONE,
-                      to_f32(h->t + q_row0 * H, H), &resid)) return rc;
-    launch_ln_to_planes(h->t + q_row0 * H, H, w.g, w.b, out.hi + q_row0 * H, out.lo + q_row0 * H, H, (int)(B * Sq), st);
+    const Planes resid = in.at(row0 * H);
+    if (int rc = gemm(h, st, h->ctx.at(row0 * H), H, ID, w.wo, w.bo, M, H, H, ACT_NONE,
+                      to_f32(h->t + row0 * H, H), &resid, pk.rows)) return rc;
+    launch_ln_to_planes(h->t + row0 * H, H, w.g, w.b, out.hi + row0 * H, out.lo + row0 * H, H, (int)M, st, pk.rows);
     return MMS_OK;
 }
 
 // feed-forward sub-layer: out = LN(dense(act(dense(in))) + in)      (pixelbert.py:969-985, modeling.py:395-420)
-int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes out, int64_t row0, int64_t M, int act) {
+int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes out, int64_t row0, int64_t M, int act,
+              const Pack& pk = Pack()) {
     const int I = h->cfg.inter;
-    if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I))) return rc;
+    if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I), nullptr, pk.rows)) return rc;
     const Planes resid = in.at(row0 * H);
-    if (int rc = gemm(h, st, h->mid, I, ID, w.wd, w.bd, M, H, I, ACT_NONE, to_f32(h->t + row0 * H, H), &resid)) return rc;
-    launch_ln_to_planes(h->t + row0 * H, H, w.g, w.b, out.hi + row0 * H, out.lo + row0 * H, H, (int)M, st);
+    if (int rc = gemm(h, st, h->mid, I, ID, w.wd, w.bd, M, H, I, ACT_NONE, to_f32(h->t + row0 * H, H), &resid, pk.rows)) return rc;
+    launch_ln_to_planes(h->t + row0 * H, H, w.g, w.b, out.hi + row0 * H, out.lo + row0 * H, H, (int)M, st, pk.rows);
     return MMS_OK;
 }
 
@@ -500,18 +518,28 @@ int zk_chunk(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, i
     launch_zk_tokpre(h->lab_feat, b->label_index + p0 * MMS_NBOX, b->boxes_5 + p0 * MMS_NBOX * 5, h->w_dense1, h->b_dense1,
                      img, h->ctx.hi, h->ctx.lo, (int)NB, st);
     if (int rc = gemm(h, st, h->ctx, H, ID, h->w_femb, h->b_femb, NB, H, H, ACT_NONE, to_f32(tok, H))) return rc;
-    // --- embeddings + mask ---
-    launch_zk_embed(h->E, h->type_tab, h->pos_tab, h->emb_g, h->emb_b, b->query_ids + p0 * T, b->segment_ids + p0 * S, tok, T,
-                    c.vocab, h->x.hi, h->x.lo, (int)n, st);
-    launch_zk_mask(b->len_query + p0, b->num_boxes + p0, T, h->key_add, (int)n, st);
+    // --- embeddings + mask (packed: live tokens only, laid out contiguously) ---
+    Pack pk;
+    if (c.pack_tokens) {
+        launch_zk_pack_plan(b->len_query + p0, b->num_boxes + p0, T, (int)n, h->pk_off[0], h->pk_cnt[0], h->pk_src[0], h->key_add,
+                            h->pk_rows, st);
+        pk.off = h->pk_off[0]; pk.cnt = h->pk_cnt[0]; pk.rows = h->pk_rows;
+        launch_zk_embed_packed(h->E, h->type_tab, h->pos_tab, h->emb_g, h->emb_b, b->query_ids + p0 * T, b->segment_ids + p0 * S, tok,
+                               T, c.vocab, h->pk_src[0], h->pk_rows, (int)(n * S), h->x.hi, h->x.lo, st);
+    } else {
+        launch_zk_embed(h->E, h->type_tab, h->pos_tab, h->emb_g, h->emb_b, b->query_ids + p0 * T, b->segment_ids + p0 * S, tok, T,
+                        c.vocab, h->x.hi, h->x.lo, (int)n, st);
+        launch_zk_mask(b->len_query + p0, b->num_boxes + p0, T, h->key_add, (int)n, st);
+    }
     // --- encoder ---
     const int nl = (c.stop_after >= 0 && c.stop_after < c.layers) ? c.stop_after : c.layers;
     for (int i = 0; i < nl; ++i) {
-        if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, 0, S, n, h->key_add)) return rc;
-        if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * S, ACT_GELU_TANH)) return rc;
+        if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, n, h->key_add, pk)) return rc;
+        if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * S, ACT_GELU_TANH, pk)) return rc;
     }
     // --- pooler on the CLS rows + AM-softmax head ---
-    if (int rc = gemm(h, st, h->x, H, RowMap{1, S, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H))) return rc;
+    if (int rc = gemm(h, st, h->x, H, RowMap{1, S, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H), nullptr,
+                      nullptr, pk.off)) return rc;
     launch_zk_head(h->pooled, h->am_kernel, b->labels + p0, 30.0f, 0.35f, logits + p0 * 2, probs ? probs + p0 * 2 : nullptr, (int)n, st);
     return MMS_OK;
 }
@@ -530,7 +558,7 @@ int lds_chunk(mms_handle* h, hipStream_t st, const mms_lds_batch* b, int64_t p0,
     launch_lds_label(h->E, h->w_lab8, b->labelfeat + p0 * MMS_NBOX * MMS_LABEL_LEN, c.vocab, S, T + MMS_NBOX, h->x.hi, h->x.lo, (int)n, st);
     const int nl = (c.stop_after >= 0 && c.stop_after < c.layers) ? c.stop_after : c.layers;
     for (int i = 0; i < nl; ++i) {
-        if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, 0, S, n, nullptr)) return rc;
+        if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, n, nullptr)) return rc;
         if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * S, ACT_GELU_TANH)) return rc;
     }
     if (int rc = gemm(h, st, h->x, H, RowMap{1, S, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H))) return rc;
@@ -553,51 +581,80 @@ int lx_label_features(mms_handle* h, hipStream_t st, const int64_t* uniq_ids, in
 int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p0, int64_t n, float* logits, float* probs) {
     const mms_config& c = h->cfg;
     const int T = c.text_len, V = MMS_NBOX;
-    const int64_t ML = n * T, MV = n * V, R = ML + MV;  // language rows [0, ML), vision rows [ML, R)
+    // language rows start at 0 (at most ML of them), vision rows start at ML (at most MV of them)
+    const int64_t ML = n * T, MV = n * V, R = ML + MV;
     float* lang_add = h->key_add;
     float* visn_add = h->key_add2;
-    launch_lx_masks(b->input_mask + p0 * T, b->visual_attention_mask + p0 * V, T, lang_add, visn_add, (int)n, st);
-    launch_lx_embed_lang(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->x.hi, h->x.lo, (int)n, st);
+    Pack pl, pv;
     Planes featp = h->mid;
     launch_split_f32(b->feats + p0 * V * MMS_FEAT, featp.hi, featp.lo, MV * MMS_FEAT, st);
     float* xf = h->qkv;
     if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_visn, h->b_visn, MV, H, MMS_FEAT, ACT_NONE, to_f32(xf, H))) return rc;
-    launch_lx_visn(xf, h->g_visn, h->be_visn, b->boxes + p0 * V * 4, 4, h->w_box, h->b_box, h->g_box, h->be_box, h->lab_feat,
-                   b->label_index + p0 * V, h->x.hi + ML * H, h->x.lo + ML * H, (int)MV, st);
+    if (c.pack_tokens) {
+        launch_lx_pack_plan(b->input_mask + p0 * T, b->visual_attention_mask + p0 * V, T, (int)n, h->pk_off[0], h->pk_cnt[0],
+                            h->pk_src[0], lang_add, h->pk_rows, h->pk_off[1], h->pk_cnt[1], h->pk_src[1], visn_add, h->pk_rows + 1, st);
+        pl.off = h->pk_off[0]; pl.cnt = h->pk_cnt[0]; pl.rows = h->pk_rows;
+        pv.off = h->pk_off[1]; pv.cnt = h->pk_cnt[1]; pv.rows = h->pk_rows + 1;
+        launch_lx_embed_lang_packed(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->pk_src[0],
+                                    h->pk_rows, (int)ML, h->x.hi, h->x.lo, st);
+        launch_lx_visn(xf, h->g_visn, h->be_visn, b->boxes + p0 * V * 4, 4, h->w_box, h->b_box, h->g_box, h->be_box, h->lab_feat,
+                       b->label_index + p0 * V, h->x.hi + ML * H, h->x.lo + ML * H, (int)MV, st, h->pk_src[1], h->pk_rows + 1);
+    } else {
+        launch_lx_masks(b->input_mask + p0 * T, b->visual_attention_mask + p0 * V, T, lang_add, visn_add, (int)n, st);
+        launch_lx_embed_lang(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->x.hi, h->x.lo, (int)n, st);
+        launch_lx_visn(xf, h->g_visn, h->be_visn, b->boxes + p0 * V * 4, 4, h->w_box, h->b_box, h->g_box, h->be_box, h->lab_feat,
+                       b->label_index + p0 * V, h->x.hi + ML * H, h->x.lo + ML * H, (int)MV, st);
+    }
     int budget = c.stop_after >= 0 ? c.stop_after : (1 << 30);
     for (int i = 0; i < c.layers && budget > 0; ++i, --budget) {
-        if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, T, 0, T, n, lang_add)) return rc;
-        if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, ML, ACT_GELU_ERF)) return rc;
+        if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, T, n, lang_add, pl)) return rc;
+        if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, ML, ACT_GELU_ERF, pl)) return rc;
     }
     for (int i = 0; i < c.r_layers && budget > 0; ++i, --budget) {
-        if (int rc = att_block(h, st, h->r_layers[i].att, h->x, h->y, ML, V, ML, V, n, visn_add)) return rc;
-        if (int rc = ffn_block(h, st, h->r_layers[i].ffn, h->y, h->x, ML, MV, ACT_GELU_ERF)) return rc;
+        if (int rc = att_block(h, st, h->r_layers[i].att, h->x, h->y, ML, V, n, visn_add, pv)) return rc;
+        if (int rc = ffn_block(h, st, h->r_layers[i].ffn, h->y, h->x, ML, MV, ACT_GELU_ERF, pv)) return rc;
     }
     for (int i = 0; i < c.x_layers && budget > 0; ++i, --budget) {
         const XLayerW& w = h->x_layers[i];
-        // cross attention, both directions with the SAME weights (modeling.py:460-464): one QKV
-        // projection over all R rows, two attention launches, one output dense + LN over all R rows
-        if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, R, 3 * H, H, ACT_NONE, to_f32(h->qkv, 3 * H))) return rc;
+        // cross attention, both directions with the SAME weights (modeling.py:460-464): the QKV projection and
+        // the output dense + LN run over both streams (one launch when dense, one per stream when packed)
+        if (c.pack_tokens) {
+            if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, ML, 3 * H, H, ACT_NONE, to_f32(h->qkv, 3 * H), nullptr, pl.rows)) return rc;
+            if (int rc = gemm(h, st, h->x.at(ML * H), H, ID, w.cross.wqkv, w.cross.bqkv, MV, 3 * H, H, ACT_NONE,
+                              to_f32(h->qkv + ML * 3 * H, 3 * H), nullptr, pv.rows)) return rc;
+        } else {
+            if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, R, 3 * H, H, ACT_NONE, to_f32(h->qkv, 3 * H))) return rc;
+        }
         AttnParams a{};
         a.ldq = a.ldkv = 3 * H; a.ldo = H; a.B = (int)n; a.q_base = a.kv_base = 0;
         a.q = h->qkv; a.Sq = T;                                   // lang <- visn
         a.k = h->qkv + ML * 3 * H + H; a.v = h->qkv + ML * 3 * H + 2 * H; a.Sk = V; a.key_add = visn_add;
         a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo;
+        a.q_off = pl.off; a.q_cnt = pl.cnt; a.kv_off = pv.off; a.kv_cnt = pv.cnt;
         launch_attention(a, st);
         a.q = h->qkv + ML * 3 * H; a.Sq = V;                      // visn <- lang
         a.k = h->qkv + H; a.v = h->qkv + 2 * H; a.Sk = T; a.key_add = lang_add;
         a.o_hi = h->ctx.hi + ML * H; a.o_lo = h->ctx.lo + ML * H;
+        a.q_off = pv.off; a.q_cnt = pv.cnt; a.kv_off = pl.off; a.kv_cnt = pl.cnt;
         launch_attention(a, st);
-        if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, R, H, H, ACT_NONE, to_f32(h->t, H), &h->x)) return rc;
-        launch_ln_to_planes(h->t, H, w.cross.g, w.cross.b, h->y.hi, h->y.lo, H, (int)R, st);
+        if (c.pack_tokens) {
+            if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
+            const Planes rv = h->x.at(ML * H);
+            if (int rc = gemm(h, st, h->ctx.at(ML * H), H, ID, w.cross.wo, w.cross.bo, MV, H, H, ACT_NONE, to_f32(h->t + ML * H, H), &rv, pv.rows)) return rc;
+            launch_ln_to_planes(h->t, H, w.cross.g, w.cross.b, h->y.hi, h->y.lo, H, (int)ML, st, pl.rows);
+            launch_ln_to_planes(h->t + ML * H, H, w.cross.g, w.cross.b, h->y.hi + ML * H, h->y.lo + ML * H, H, (int)MV, st, pv.rows);
+        } else {
+            if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, R, H, H, ACT_NONE, to_f32(h->t, H), &h->x)) return rc;
+            launch_ln_to_planes(h->t, H, w.cross.g, w.cross.b, h->y.hi, h->y.lo, H, (int)R, st);
+        }
         // per-stream self attention (y -> x), then per-stream FFN (x -> x)
-        if (int rc = att_block(h, st, w.lang_self, h->y, h->x, 0, T, 0, T, n, lang_add)) return rc;
-        if (int rc = att_block(h, st, w.visn_self, h->y, h->x, ML, V, ML, V, n, visn_add)) return rc;
-        if (int rc = ffn_block(h, st, w.lang_ffn, h->x, h->x, 0, ML, ACT_GELU_ERF)) return rc;
-        if (int rc = ffn_block(h, st, w.visn_ffn, h->x, h->x, ML, MV, ACT_GELU_ERF)) return rc;
+        if (int rc = att_block(h, st, w.lang_self, h->y, h->x, 0, T, n, lang_add, pl)) return rc;
+        if (int rc = att_block(h, st, w.visn_self, h->y, h->x, ML, V, n, visn_add, pv)) return rc;
+        if (int rc = ffn_block(h, st, w.lang_ffn, h->x, h->x, 0, ML, ACT_GELU_ERF, pl)) return rc;
+        if (int rc = ffn_block(h, st, w.visn_ffn, h->x, h->x, ML, MV, ACT_GELU_ERF, pv)) return rc;
     }
     // pooler (modeling.py:596-608) -> logit_fc (kdd_model.py:167-172)
-    if (int rc = gemm(h, st, h->x, H, RowMap{1, T, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_planes(h->ctx, H))) return rc;
+    if (int rc = gemm(h, st, h->x, H, RowMap{1, T, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_planes(h->ctx, H), nullptr, nullptr, pl.off)) return rc;
     if (int rc = gemm(h, st, h->ctx, H, ID, h->w_fc0, h->b_fc0, n, 2 * H, H, ACT_GELU_ERF, to_f32(h->hbuf, 2 * H))) return rc;
     launch_lx_head(h->hbuf, h->g_fc2, h->be_fc2, h->w_fc3, h->b_fc3, logits + p0 * 2, probs ? probs + p0 * 2 : nullptr, (int)n, st);
     return MMS_OK;
@@ -627,6 +684,7 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
     if (cfg->precision != 1 && cfg->precision != 2) { g_err = "precision must be 1 or 2"; return MMS_ERR_ARG; }
     if (cfg->text_len <= 0 || cfg->text_len > 32 || cfg->text_len + 1 > cfg->max_pos) { g_err = "bad text_len"; return MMS_ERR_ARG; }
     if (cfg->layers < 0 || cfg->vocab <= 0 || cfg->type_vocab <= 0) { g_err = "bad layer/vocab config"; return MMS_ERR_ARG; }
+    if (cfg->pack_tokens && cfg->model == MMS_MODEL_LDS) { g_err = "lds has no attention mask: every token is live, pack_tokens must be 0"; return MMS_ERR_ARG; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) { g_err = std::string("no HIP device: ") + hipGetErrorString(e); return MMS_ERR_HIP; }
@@ -728,6 +786,12 @@ int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, fl
 int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out, int64_t* launches_out, double* flops_out) {
     if (!h) return MMS_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->flop_counter) {
+        void* p;
+        if (int rc = dev_alloc(h, h->w_allocs, &p, 8)) return rc;
+        h->flop_counter = (unsigned long long*)p;
+        HIP_TRY(h, hipMemset(p, 0, 8));
+    }
     if (ms_out || launches_out || flops_out) {
         double ms = 0;
         if (h->ev_used) HIP_TRY(h, hipEventSynchronize(h->ev[h->ev_used - 1]));
@@ -736,11 +800,13 @@ int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out
             HIP_TRY(h, hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
             ms += t;
         }
+        unsigned long long fl = 0;
+        HIP_TRY(h, hipMemcpy(&fl, h->flop_counter, 8, hipMemcpyDeviceToHost));
         if (ms_out) *ms_out = ms;
         if (launches_out) *launches_out = h->gemm_launches;
-        if (flops_out) *flops_out = h->gemm_flops;
+        if (flops_out) *flops_out = (double)fl;
     }
-    if (reset) { h->ev_used = 0; h->gemm_flops = 0; h->gemm_launches = 0; }
+    if (reset) { h->ev_used = 0; h->gemm_launches = 0; HIP_TRY(h, hipMemset(h->flop_counter, 0, 8)); }
     h->timing = enable != 0;
     return MMS_OK;
 }

@@ -26,22 +26,27 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     if (unit >= p.B * MMS_HEADS) return;
     const int b = unit / MMS_HEADS, h = unit % MMS_HEADS;
     const int fr = lane & 15, fk = lane >> 4;
+    // dense: rows b*S .. ; packed (ragged): per-pair row offset / live-token count
+    const int q0 = p.q_base + (p.q_off ? p.q_off[b] : b * p.Sq);
+    const int kv0 = p.kv_base + (p.kv_off ? p.kv_off[b] : b * p.Sk);
+    const int Sq = p.q_cnt ? p.q_cnt[b] : p.Sq;
+    const int Sk = p.kv_cnt ? p.kv_cnt[b] : p.Sk;
 
     // ---- S^T = K Q^T ----
     float4 kf[KT][4], qf[QT][4];
 #pragma unroll
     for (int jt = 0; jt < KT; ++jt) {
         int j = jt * 16 + fr;
-        j = j < p.Sk ? j : p.Sk - 1;
-        const float* kr = p.k + (long long)(p.kv_base + b * p.Sk + j) * p.ldkv + h * MMS_HEAD_DIM + fk * 4;
+        j = j < Sk ? j : Sk - 1;
+        const float* kr = p.k + (long long)(kv0 + j) * p.ldkv + h * MMS_HEAD_DIM + fk * 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) kf[jt][s] = *reinterpret_cast<const float4*>(kr + s * 16);
     }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         int i = qt * 16 + fr;
-        i = i < p.Sq ? i : p.Sq - 1;
-        const float* qr = p.q + (long long)(p.q_base + b * p.Sq + i) * p.ldq + h * MMS_HEAD_DIM + fk * 4;
+        i = i < Sq ? i : Sq - 1;
+        const float* qr = p.q + (long long)(q0 + i) * p.ldq + h * MMS_HEAD_DIM + fk * 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[qt][s] = *reinterpret_cast<const float4*>(qr + s * 16);
     }
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = jt * 16 + fk * 4 + r;
-            add[jt][r] = j < p.Sk ? (p.key_add ? p.key_add[(long long)b * p.Sk + j] : 0.f) : -INFINITY;
+            add[jt][r] = j < Sk ? (p.key_add ? p.key_add[kv0 - p.kv_base + j] : 0.f) : -INFINITY;
         }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -112,9 +117,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int j = jt * 16 + fk * 4 + r;
-            j = j < p.Sk ? j : p.Sk - 1;  // P is exactly 0 there; keep the load in bounds and finite
+            j = j < Sk ? j : Sk - 1;  // P is exactly 0 there; keep the load in bounds and finite
             const float4 vf = *reinterpret_cast<const float4*>(
-                p.v + (long long)(p.kv_base + b * p.Sk + j) * p.ldkv + h * MMS_HEAD_DIM + fr * 4);
+                p.v + (long long)(kv0 + j) * p.ldkv + h * MMS_HEAD_DIM + fr * 4);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const float pv = sc[jt][qt][r];
@@ -131,8 +136,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = qt * 16 + fk * 4 + r;
-            if (i >= p.Sq) continue;
-            const long long off = (long long)(p.q_base + b * p.Sq + i) * p.ldo + h * MMS_HEAD_DIM + fr * 4;
+            if (i >= Sq) continue;
+            const long long off = (long long)(q0 + i) * p.ldo + h * MMS_HEAD_DIM + fr * 4;
             bf16x4 hi, lo;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {

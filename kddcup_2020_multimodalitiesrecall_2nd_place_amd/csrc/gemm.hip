@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     for (int s = 0; s < 4; ++s) {
         int r = bm * BM + lr + 32 * s;
         r = r < p.M ? r : p.M - 1;
-        a_row[s] = p.a_hi + p.amap(r) * (long long)p.lda + c * 8;
+        a_row[s] = p.a_hi + (p.a_index ? (long long)p.a_index[r] : p.amap(r)) * (long long)p.lda + c * 8;
         w_row[s] = p.w + (long long)(bn * BN + lr + 32 * s) * p.K + c * 8;
     }
     const long long lo_delta = p.a_lo - p.a_hi;
@@ -173,7 +173,8 @@ int get_gemm_variant() {
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
     if (nblk <= 0) return;
-    const int variant = get_gemm_variant();
+    int variant = get_gemm_variant();
+    if (variant == 0 && (p.m_dev || p.flop_counter)) variant = 1;   // the v0 kernel has no device-side row count
     if (variant > 0 && launch_gemm_tile(p, nsplit, variant, st)) return;
     if (variant > 0 && launch_gemm_tile(p, nsplit, 1, st)) return;   // N % 256 != 0: 128x128 tile
     if (nsplit == 2) launch_ns<2>(p, nblk, st);

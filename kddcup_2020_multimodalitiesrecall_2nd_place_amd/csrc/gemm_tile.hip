@@ -36,6 +36,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+    int Meff = p.M;
+    if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
+    if (p.flop_counter && blockIdx.x == 0 && tid == 0)
+        atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
     const int nbn = p.N / BN, nbm = (p.M + BM - 1) / BM, nblk = nbm * nbn;
     int bid = blockIdx.x;
     {   // bijective XCD remap (block b runs on XCD b % 8; speed only)
@@ -43,6 +47,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int bm = bid / nbn, bn = bid % nbn;
+    if (bm * BM >= Meff) return;   // packed mode: this row panel holds no live rows (block-uniform exit)
     const long long lo_delta = p.a_lo - p.a_hi;
 
     f32x4 acc[FM][FN];
@@ -92,8 +97,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
             const int r = (wave + NW * s) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((r >> 1) & 7);
             int gr = bm * BM + r;
-            gr = gr < p.M ? gr : p.M - 1;
-            a_src[s] = p.a_hi + p.amap(gr) * (long long)p.lda + c * 8;
+            gr = gr < Meff ? gr : Meff - 1;
+            a_src[s] = p.a_hi + (p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda + c * 8;
         }
 #pragma unroll
         for (int s = 0; s < GB; ++s) {
@@ -132,8 +137,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
 #pragma unroll
         for (int s = 0; s < CA; ++s) {
             int r = bm * BM + lr + (NT / 8) * s;
-            r = r < p.M ? r : p.M - 1;
-            a_row[s] = p.a_hi + p.amap(r) * (long long)p.lda + c * 8;
+            r = r < Meff ? r : Meff - 1;
+            a_row[s] = p.a_hi + (p.a_index ? (long long)p.a_index[r] : p.amap(r)) * (long long)p.lda + c * 8;
         }
 #pragma unroll
         for (int s = 0; s < CB; ++s) w_row[s] = p.w + (long long)(bn * BN + lr + (NT / 8) * s) * p.K + c * 8;
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
             const int lrow = t * ROWS_PER_IT + er;
             const int row = bm * BM + wm * TM + i * 16 + lrow;
             f32x4 v = *reinterpret_cast<const f32x4*>(strip + lrow * ES + ec);
-            if (row < p.M) {
+            if (row < Meff) {
                 v += bias4;
                 if (p.r_hi) {
                     const long long ro = (long long)row * p.ldr + col;

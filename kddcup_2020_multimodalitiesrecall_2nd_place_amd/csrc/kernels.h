@@ -18,6 +18,9 @@ struct GemmParams {
     bf16* c_hi; bf16* c_lo; int ldp;  // OUT_PLANES
     RowMap cmap;                 // logical row -> output row
     const bf16* r_hi; const bf16* r_lo; int ldr;  // residual planes (logical rows) or nullptr
+    const int* m_dev;            // optional device-side row count: M_eff = min(M, *m_dev) (packed mode)
+    const int* a_index;          // optional row gather: logical row r reads A row a_index[r]
+    unsigned long long* flop_counter;  // optional: block 0 adds 2*M_eff*N*K (executed algorithmic FLOPs)
 };
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
@@ -32,9 +35,12 @@ struct AttnParams {
     const float* q; int ldq;
     const float* k; const float* v; int ldkv;
     int q_base, Sq, kv_base, Sk;
-    const float* key_add;        // [B][Sk] additive mask or nullptr
+    const float* key_add;        // additive mask indexed by kv row (relative to kv_base) or nullptr
     bf16* o_hi; bf16* o_lo; int ldo;
     int B;
+    // packed (ragged) mode: per-pair first row and live-token count; nullptr = dense (b*S, S).
+    // Sq / Sk are then the MAXIMUM lengths (tile selection).
+    const int* q_off; const int* q_cnt; const int* kv_off; const int* kv_cnt;
 };
 void launch_attention(const AttnParams& p, hipStream_t st);
 
@@ -42,7 +48,7 @@ void launch_attention(const AttnParams& p, hipStream_t st);
 // Row-wise kernels (one wavefront per 768-wide row)                   (rowops.hip)
 // ---------------------------------------------------------------------------------------------
 void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta,
-                         bf16* o_hi, bf16* o_lo, int ldo, int M, hipStream_t st);
+                         bf16* o_hi, bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev = nullptr);
 void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipStream_t st);
 void launch_planes_to_f32(const bf16* hi, const bf16* lo, float* out, long long n, hipStream_t st);
 void launch_mean8(const float* in, float* out, int U, hipStream_t st);
@@ -54,6 +60,20 @@ void launch_zk_tokpre(const float* labfeat, const int* lab_index, const float* b
 void launch_zk_embed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
                      const float* beta, const int* query_ids, const int* segment_ids, const float* tok,
                      int T, int vocab, bf16* o_hi, bf16* o_lo, int B, hipStream_t st);
+// packed (ragged) execution: drop padded tokens whose keys are masked (results are identical: a
+// masked key's softmax weight underflows to exactly 0 in fp32)
+void launch_zk_pack_plan(const int* len_query, const int* num_boxes, int T, int n, int* off, int* cnt, int* tok_src,
+                         float* key_add, int* rows_dev, hipStream_t st);
+void launch_zk_embed_packed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
+                            const float* beta, const int* query_ids, const int* segment_ids, const float* tok,
+                            int T, int vocab, const int* tok_src, const int* rows_dev, int max_rows,
+                            bf16* o_hi, bf16* o_lo, hipStream_t st);
+void launch_lx_pack_plan(const int64_t* input_mask, const float* visual_mask, int T, int n, int* l_off, int* l_cnt,
+                         int* l_src, float* l_add, int* l_rows, int* v_off, int* v_cnt, int* v_src, float* v_add,
+                         int* v_rows, hipStream_t st);
+void launch_lx_embed_lang_packed(const float* E, const float* pos_tab, const float* type_tab, const float* gamma,
+                                 const float* beta, const int64_t* input_ids, int T, int vocab, const int* src,
+                                 const int* rows_dev, int max_rows, bf16* o_hi, bf16* o_lo, hipStream_t st);
 void launch_zk_mask(const int* len_query, const int* num_boxes, int T, float* key_add, int B, hipStream_t st);
 void launch_zk_head(const float* pooled, const float* am_kernel, const int64_t* labels, float scale,
                     float margin, float* logits, float* probs, int B, hipStream_t st);
@@ -76,7 +96,8 @@ void launch_lx_label_emb(const float* E, const float* pos_tab, const float* type
                          const int64_t* uniq_ids, int vocab, bf16* o_hi, bf16* o_lo, int U, hipStream_t st);
 void launch_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes, int box_dim,
                     const float* Wb, const float* bb, const float* g_y, const float* b_y, const float* z,
-                    const int* lab_index, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st);
+                    const int* lab_index, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st,
+                    const int* src = nullptr, const int* rows_dev = nullptr);
 void launch_ln_f32(const float* in, const float* gamma, const float* beta, float* out, int M, hipStream_t st);
 void launch_lx_masks(const int64_t* input_mask, const float* visual_mask, int T, float* lang_add,
                      float* visn_add, int B, hipStream_t st);

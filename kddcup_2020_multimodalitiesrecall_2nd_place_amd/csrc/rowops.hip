@@ -88,17 +88,18 @@ static inline dim3 row_grid(long long rows) { return dim3((unsigned)((rows + ROW
 // generic
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ln_to_planes(const float* in, int ld, const float* gamma,
-                                                      const float* beta, bf16* o_hi, bf16* o_lo, int ldo, int M) {
+                                                      const float* beta, bf16* o_hi, bf16* o_lo, int ldo, int M,
+                                                      const int* m_dev) {
     const int row = wave_row();
-    if (row >= M) return;
+    if (row >= M || (m_dev && row >= *m_dev)) return;
     Row x;
     row_load(x, in + (long long)row * ld);
     row_ln(x, gamma, beta);
     row_store_planes(x, o_hi + (long long)row * ldo, o_lo + (long long)row * ldo);
 }
 void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta, bf16* o_hi,
-                         bf16* o_lo, int ldo, int M, hipStream_t st) {
-    if (M > 0) hipLaunchKernelGGL(k_ln_to_planes, row_grid(M), dim3(256), 0, st, in, ld, gamma, beta, o_hi, o_lo, ldo, M);
+                         bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev) {
+    if (M > 0) hipLaunchKernelGGL(k_ln_to_planes, row_grid(M), dim3(256), 0, st, in, ld, gamma, beta, o_hi, o_lo, ldo, M, m_dev);
 }
 
 __global__ __launch_bounds__(256) void k_ln_f32(const float* in, const float* gamma, const float* beta,
@@ -426,9 +427,10 @@ void launch_lx_label_emb(const float* E, const float* pos_tab, const float* type
 __global__ __launch_bounds__(256) void k_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes,
                                                  int box_dim, const float* Wb, const float* bb, const float* g_y,
                                                  const float* b_y, const float* z, const int* lab_index,
-                                                 bf16* o_hi, bf16* o_lo, int rows) {
-    const int row = wave_row();
-    if (row >= rows) return;
+                                                 bf16* o_hi, bf16* o_lo, int rows, const int* src_map, const int* rows_dev) {
+    const int orow = wave_row();
+    if (orow >= rows || (rows_dev && orow >= *rows_dev)) return;
+    const int row = src_map ? src_map[orow] : orow;   // packed mode: output row orow <- box row src_map[orow]
     Row x, y;
     row_load(x, xf + (long long)row * MMS_HIDDEN);
     row_ln(x, g_x, b_x);
@@ -446,14 +448,15 @@ __global__ __launch_bounds__(256) void k_lx_visn(const float* xf, const float* g
     row_load(zz, z + (long long)lab_index[row] * MMS_HIDDEN);
 #pragma unroll
     for (int i = 0; i < 12; ++i) x.v[i] = (x.v[i] + y.v[i] + zz.v[i]) / 3.0f;
-    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+    row_store_planes(x, o_hi + (long long)orow * MMS_HIDDEN, o_lo + (long long)orow * MMS_HIDDEN);
 }
 void launch_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes, int box_dim,
                     const float* Wb, const float* bb, const float* g_y, const float* b_y, const float* z,
-                    const int* lab_index, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st) {
+                    const int* lab_index, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st, const int* src,
+                    const int* rows_dev) {
     if (rows > 0)
         hipLaunchKernelGGL(k_lx_visn, row_grid(rows), dim3(256), 0, st, xf, g_x, b_x, boxes, box_dim, Wb, bb, g_y, b_y, z,
-                           lab_index, o_hi, o_lo, rows);
+                           lab_index, o_hi, o_lo, rows, src, rows_dev);
 }
 
 // modeling.py:890-910: additive masks (1 - m) * -10000 for language and visual keys
@@ -510,4 +513,176 @@ __global__ __launch_bounds__(256) void k_lx_head(const float* h, const float* ga
 void launch_lx_head(const float* h, const float* gamma, const float* beta, const float* W, const float* b, float* logits,
                     float* probs, int B, hipStream_t st) {
     if (B > 0) hipLaunchKernelGGL(k_lx_head, row_grid(B), dim3(256), 0, st, h, gamma, beta, W, b, logits, probs, B);
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed (ragged) execution plans
+// ------------------------------------------------------------------------------------------------
+// One workgroup scans the per-pair live-token counts and lays the live tokens out contiguously.
+// A token is dropped only if it is masked as a KEY and is not the CLS row; its own outputs are
+// never read by a live row (keys masked, pooler reads CLS), so logits are unchanged.  A pair whose
+// keys are ALL masked keeps every token (the reference's softmax is then uniform over all of them).
+#define PLAN_THREADS 1024
+
+__device__ __forceinline__ int plan_scan(int local, int* sh, int* total) {
+    const int tid = threadIdx.x;
+    sh[tid] = local;
+    __syncthreads();
+    for (int o = 1; o < PLAN_THREADS; o <<= 1) {
+        const int v = tid >= o ? sh[tid - o] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    const int incl = sh[tid];
+    if (total) *total = sh[PLAN_THREADS - 1];
+    __syncthreads();
+    return incl - local;
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_zk_pack_plan(const int* len_query, const int* num_boxes, int T, int n,
+                                                               int* off, int* cnt, int* tok_src, float* key_add, int* rows_dev) {
+    __shared__ int sh[PLAN_THREADS];
+    const int S = T + MMS_NBOX, tid = threadIdx.x;
+    const int per = (n + PLAN_THREADS - 1) / PLAN_THREADS;
+    const int b0 = tid * per, b1 = (b0 + per) < n ? (b0 + per) : n;
+    int local = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int lq = min(max(len_query[b], 0), T), nb = min(max(num_boxes[b], 0), MMS_NBOX);
+        local += (lq + nb == 0) ? S : (max(lq, 1) + nb);
+    }
+    int total;
+    int base = plan_scan(local, sh, &total);
+    for (int b = b0; b < b1; ++b) {
+        const int lq = min(max(len_query[b], 0), T), nb = min(max(num_boxes[b], 0), MMS_NBOX);
+        const bool dense = (lq + nb == 0);
+        const int nt = dense ? T : max(lq, 1), nv = dense ? MMS_NBOX : nb;
+        off[b] = base;
+        cnt[b] = nt + nv;
+        for (int s = 0; s < nt; ++s) { tok_src[base + s] = b * S + s; key_add[base + s] = s < lq ? 0.f : -10000.f; }
+        for (int j = 0; j < nv; ++j) { tok_src[base + nt + j] = b * S + T + j; key_add[base + nt + j] = j < nb ? 0.f : -10000.f; }
+        base += nt + nv;
+    }
+    if (tid == 0) *rows_dev = total;
+}
+void launch_zk_pack_plan(const int* len_query, const int* num_boxes, int T, int n, int* off, int* cnt, int* tok_src,
+                         float* key_add, int* rows_dev, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_zk_pack_plan, dim3(1), dim3(PLAN_THREADS), 0, st, len_query, num_boxes, T, n, off, cnt, tok_src, key_add, rows_dev);
+}
+
+__global__ __launch_bounds__(256) void k_zk_embed_packed(const float* E, const float* type_tab, const float* pos_tab,
+                                                         const float* gamma, const float* beta, const int* query_ids,
+                                                         const int* segment_ids, const float* tok, int T, int vocab,
+                                                         const int* tok_src, const int* rows_dev, int max_rows,
+                                                         bf16* o_hi, bf16* o_lo) {
+    const int S = T + MMS_NBOX;
+    const int row = wave_row();
+    if (row >= max_rows || row >= *rows_dev) return;
+    const int src = tok_src[row], b = src / S, s = src % S;
+    Row x;
+    if (s < T) row_load(x, E + clamp_id(query_ids[b * T + s], vocab) * MMS_HIDDEN);
+    else row_load(x, tok + ((long long)b * MMS_NBOX + (s - T)) * MMS_HIDDEN);
+    row_add(x, type_tab + clamp_id(segment_ids[src], 2) * MMS_HIDDEN);
+    row_add(x, pos_tab + (s < T ? s : T) * MMS_HIDDEN);
+    row_ln(x, gamma, beta);
+    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+}
+void launch_zk_embed_packed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
+                            const float* beta, const int* query_ids, const int* segment_ids, const float* tok, int T,
+                            int vocab, const int* tok_src, const int* rows_dev, int max_rows, bf16* o_hi, bf16* o_lo,
+                            hipStream_t st) {
+    if (max_rows > 0)
+        hipLaunchKernelGGL(k_zk_embed_packed, row_grid(max_rows), dim3(256), 0, st, E, type_tab, pos_tab, gamma, beta, query_ids,
+                           segment_ids, tok, T, vocab, tok_src, rows_dev, max_rows, o_hi, o_lo);
+}
+
+// lxmert: language stream keeps positions with input_mask != 0 plus position 0 (CLS feeds the pooler);
+// vision stream keeps boxes with visual_attention_mask != 0; an all-masked stream is kept whole.
+__global__ __launch_bounds__(PLAN_THREADS) void k_lx_pack_plan(const int64_t* input_mask, const float* visual_mask, int T, int n,
+                                                               int* l_off, int* l_cnt, int* l_src, float* l_add, int* l_rows,
+                                                               int* v_off, int* v_cnt, int* v_src, float* v_add, int* v_rows) {
+    __shared__ int sh[PLAN_THREADS];
+    const int tid = threadIdx.x, V = MMS_NBOX;
+    const int per = (n + PLAN_THREADS - 1) / PLAN_THREADS;
+    const int b0 = tid * per, b1 = (b0 + per) < n ? (b0 + per) : n;
+    // ---- language ----
+    int local = 0;
+    for (int b = b0; b < b1; ++b) {
+        int live = 0;
+        for (int s = 0; s < T; ++s) live += input_mask[(long long)b * T + s] != 0;
+        local += live == 0 ? T : live + (input_mask[(long long)b * T] == 0 ? 1 : 0);
+    }
+    int total;
+    int base = plan_scan(local, sh, &total);
+    for (int b = b0; b < b1; ++b) {
+        int live = 0;
+        for (int s = 0; s < T; ++s) live += input_mask[(long long)b * T + s] != 0;
+        l_off[b] = base;
+        int c = 0;
+        for (int s = 0; s < T; ++s) {
+            const int64_t m = input_mask[(long long)b * T + s];
+            if (live == 0 || m != 0 || s == 0) {
+                l_src[base + c] = b * T + s;
+                l_add[base + c] = (1.0f - (float)m) * -10000.f;
+                ++c;
+            }
+        }
+        l_cnt[b] = c;
+        base += c;
+    }
+    if (tid == 0) *l_rows = total;
+    __syncthreads();
+    // ---- vision ----
+    local = 0;
+    for (int b = b0; b < b1; ++b) {
+        int live = 0;
+        for (int j = 0; j < V; ++j) live += visual_mask[(long long)b * V + j] != 0.f;
+        local += live == 0 ? V : live;
+    }
+    base = plan_scan(local, sh, &total);
+    for (int b = b0; b < b1; ++b) {
+        int live = 0;
+        for (int j = 0; j < V; ++j) live += visual_mask[(long long)b * V + j] != 0.f;
+        v_off[b] = base;
+        int c = 0;
+        for (int j = 0; j < V; ++j) {
+            const float m = visual_mask[(long long)b * V + j];
+            if (live == 0 || m != 0.f) {
+                v_src[base + c] = b * V + j;
+                v_add[base + c] = (1.0f - m) * -10000.f;
+                ++c;
+            }
+        }
+        v_cnt[b] = c;
+        base += c;
+    }
+    if (tid == 0) *v_rows = total;
+}
+void launch_lx_pack_plan(const int64_t* input_mask, const float* visual_mask, int T, int n, int* l_off, int* l_cnt, int* l_src,
+                         float* l_add, int* l_rows, int* v_off, int* v_cnt, int* v_src, float* v_add, int* v_rows, hipStream_t st) {
+    if (n > 0)
+        hipLaunchKernelGGL(k_lx_pack_plan, dim3(1), dim3(PLAN_THREADS), 0, st, input_mask, visual_mask, T, n, l_off, l_cnt, l_src, l_add,
+                           l_rows, v_off, v_cnt, v_src, v_add, v_rows);
+}
+
+__global__ __launch_bounds__(256) void k_lx_embed_lang_packed(const float* E, const float* pos_tab, const float* type_tab,
+                                                              const float* gamma, const float* beta, const int64_t* input_ids,
+                                                              int T, int vocab, const int* src, const int* rows_dev,
+                                                              int max_rows, bf16* o_hi, bf16* o_lo) {
+    const int row = wave_row();
+    if (row >= max_rows || row >= *rows_dev) return;
+    const int sp = src[row];
+    Row x;
+    row_load(x, E + clamp_id(input_ids[sp], vocab) * MMS_HIDDEN);
+    row_add(x, pos_tab + (sp % T) * MMS_HIDDEN);
+    row_add(x, type_tab);
+    row_ln(x, gamma, beta);
+    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+}
+void launch_lx_embed_lang_packed(const float* E, const float* pos_tab, const float* type_tab, const float* gamma,
+                                 const float* beta, const int64_t* input_ids, int T, int vocab, const int* src,
+                                 const int* rows_dev, int max_rows, bf16* o_hi, bf16* o_lo, hipStream_t st) {
+    if (max_rows > 0)
+        hipLaunchKernelGGL(k_lx_embed_lang_packed, row_grid(max_rows), dim3(256), 0, st, E, pos_tab, type_tab, gamma, beta, input_ids,
+                           T, vocab, src, rows_dev, max_rows, o_hi, o_lo);
 }

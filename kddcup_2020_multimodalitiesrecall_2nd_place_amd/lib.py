@@ -26,7 +26,7 @@ class MmsError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "model", "layers", "r_layers", "x_layers", "vocab", "inter", "max_pos", "type_vocab", "text_len",
-        "precision", "chunk_pairs", "stop_after", "device")]
+        "precision", "chunk_pairs", "stop_after", "device", "pack_tokens")]
 
 
 class ZkBatch(C.Structure):
@@ -93,7 +93,8 @@ def load():
 class Handle:
     """Owns one ``mms_handle`` (one model on one GPU)."""
 
-    def __init__(self, cfg, precision: int = 2, device: int = 0, chunk_pairs: int = 0, stop_after: int = -1):
+    def __init__(self, cfg, precision: int = 2, device: int = 0, chunk_pairs: int = 0, stop_after: int = -1,
+                 pack_tokens: bool = True):
         self.lib = load()
         self.cfg = cfg
         c = Config()
@@ -104,6 +105,7 @@ class Handle:
             c.layers, c.r_layers, c.x_layers = cfg.layers, 0, 0
         c.vocab, c.inter, c.max_pos, c.type_vocab, c.text_len = cfg.vocab, cfg.inter, cfg.max_pos, cfg.type_vocab, cfg.text_len
         c.precision, c.chunk_pairs, c.stop_after, c.device = precision, chunk_pairs, stop_after, device
+        c.pack_tokens = int(bool(pack_tokens) and cfg.name != "lds")
         self._h = C.c_void_p()
         rc = self.lib.mms_create(C.byref(c), C.byref(self._h))
         if rc != 0:

@@ -28,14 +28,15 @@ def _is_np(x):
 
 class _Base:
     def __init__(self, cfg, weights: dict, precision: int = 2, device: int = 0, chunk_pairs: int = 0,
-                 stop_after: int = -1, dedup_labels: bool = True):
+                 stop_after: int = -1, dedup_labels: bool = True, pack_tokens: bool = True):
         if not torch.cuda.is_available():
             raise _lib.MmsError("no HIP device visible: the scorers have no CPU path")
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         self.dedup_labels = dedup_labels
         self.precision = precision
-        self.handle = _lib.Handle(cfg, precision=precision, device=device, chunk_pairs=chunk_pairs, stop_after=stop_after)
+        self.handle = _lib.Handle(cfg, precision=precision, device=device, chunk_pairs=chunk_pairs, stop_after=stop_after,
+                                  pack_tokens=pack_tokens)
         self.handle.load_weights(weights)
         self.logits = None
 

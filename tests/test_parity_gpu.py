@@ -47,7 +47,7 @@ def test_stagewise_hidden_state_matches_oracle(name):
         steps = [(0, inter["embedding_output"].reshape(-1, 768))]
         steps += [(i + 1, inter["layer_%d" % i].reshape(-1, 768)) for i in range(cfg.layers)]
     for stop, ref in steps:
-        s = scorers.make_scorer(cfg, w, stop_after=stop)
+        s = scorers.make_scorer(cfg, w, stop_after=stop, pack_tokens=False)  # dense rows: directly comparable
         scorers.score_batch(s, b)
         got = s.read_hidden(ref.shape[0]).cpu().numpy()
         s.close()
@@ -57,15 +57,46 @@ def test_stagewise_hidden_state_matches_oracle(name):
 
 @pytest.mark.parametrize("name", ["zk", "lds", "lxmert"])
 @pytest.mark.parametrize("dedup", [True, False])
-def test_shallow_logits_match_oracle(name, dedup):
+@pytest.mark.parametrize("pack", [True, False])
+def test_shallow_logits_match_oracle(name, dedup, pack):
     cfg = small_cfg(name)
     w = weights.make_weights(cfg)
     ps = synth.make_pairs(5, (2, 7), vocab=cfg.vocab, tag="/shallow")
     b = _batch(cfg, ps, labels="valid") if name == "zk" else _batch(cfg, ps)
     ref, ref_p = O.forward(cfg, w, b, np.float64)
-    got, got_p = _hip_logits(cfg, w, b, dedup_labels=dedup)
+    got, got_p = _hip_logits(cfg, w, b, dedup_labels=dedup, pack_tokens=pack)
     assert vecrel(got, ref).max() < TOL_P2, vecrel(got, ref)
     assert np.abs(got_p - ref_p).max() < 1e-3
+
+
+@pytest.mark.parametrize("name", ["zk", "lxmert"])
+def test_packed_equals_dense_and_mask_edge_cases(name):
+    """Dropping padded tokens must not change a single logit: a masked key's softmax weight is exactly 0.
+    Edge cases: every key masked (pair kept whole, uniform softmax), CLS masked as a key but still a query
+    row, non-prefix masks (lxmert), no live box."""
+    cfg = small_cfg(name)
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(4, (3, 5), vocab=cfg.vocab, tag="/packedge")
+    b = _batch(cfg, ps)
+    if name == "zk":
+        b["len_query_"][0] = 0; b["num_boxes"][0] = 0          # nothing live: reference attends uniformly to all 30
+        b["len_query_"][1] = 0                                  # CLS masked as key, boxes live
+        b["num_boxes"][2] = 0                                   # text only
+        b["len_query_"][3] = 20; b["num_boxes"][3] = 13         # everything live, num_boxes > 10
+    else:
+        b["input_mask"][0] = 0; b["visual_attention_mask"][0] = 0
+        b["input_mask"][1] = 0; b["input_mask"][1, [2, 5, 9]] = 1     # non-prefix mask, CLS masked
+        b["visual_attention_mask"][2] = 0; b["visual_attention_mask"][2, [1, 7]] = 1
+        b["input_mask"][3] = 1; b["visual_attention_mask"][3] = 1
+    ref, _ = O.forward(cfg, w, b, np.float64)
+    dense, _ = _hip_logits(cfg, w, b, pack_tokens=False)
+    packed, _ = _hip_logits(cfg, w, b, pack_tokens=True)
+    assert vecrel(dense, ref).max() < TOL_P2, vecrel(dense, ref)
+    assert vecrel(packed, ref).max() < TOL_P2, vecrel(packed, ref)
+    # fully masked pairs differ at fp32-roundoff level only (scores near -1e4 are quantised to ~1e-3)
+    assert np.abs(packed[1:] - dense[1:]).max() < 1e-5, np.abs(packed - dense).max(0)
+    packed_chunked, _ = _hip_logits(cfg, w, b, pack_tokens=True, chunk_pairs=5)
+    assert np.abs(packed_chunked - packed).max() < 1e-6
 
 
 @pytest.mark.parametrize("name", ["zk", "lds", "lxmert"])
