@@ -40,14 +40,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
     if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
     if (p.flop_counter && blockIdx.x == 0 && tid == 0)
         atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
-    const int nbn = p.N / BN, nbm = (p.M + BM - 1) / BM, nblk = nbm * nbn;
+    // the grid is sized for the padded row bound; only the first nblk workgroups own live row panels
+    const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM, nblk = nbm * nbn;
     int bid = blockIdx.x;
-    {   // bijective XCD remap (block b runs on XCD b % 8; speed only)
+    if (bid >= nblk) return;   // block-uniform exit (packed mode: fewer live rows than the bound)
+    {   // bijective XCD remap over the LIVE workgroups (block b runs on XCD b % 8; speed only)
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int bm = bid / nbn, bn = bid % nbn;
-    if (bm * BM >= Meff) return;   // packed mode: this row panel holds no live rows (block-uniform exit)
     const long long lo_delta = p.a_lo - p.a_hi;
 
     f32x4 acc[FM][FN];

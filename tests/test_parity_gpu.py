@@ -93,8 +93,9 @@ def test_packed_equals_dense_and_mask_edge_cases(name):
     packed, _ = _hip_logits(cfg, w, b, pack_tokens=True)
     assert vecrel(dense, ref).max() < TOL_P2, vecrel(dense, ref)
     assert vecrel(packed, ref).max() < TOL_P2, vecrel(packed, ref)
-    # fully masked pairs differ at fp32-roundoff level only (scores near -1e4 are quantised to ~1e-3)
-    assert np.abs(packed[1:] - dense[1:]).max() < 1e-5, np.abs(packed - dense).max(0)
+    # not bitwise: dropping masked keys changes which lanes hold the live keys, i.e. the fp32 summation
+    # ORDER of softmax / P.V (the dropped terms themselves are exact zeros) -> roundoff-level differences
+    assert np.abs(packed - dense).max() < 1e-4, np.abs(packed - dense).max(0)
     packed_chunked, _ = _hip_logits(cfg, w, b, pack_tokens=True, chunk_pairs=5)
     assert np.abs(packed_chunked - packed).max() < 1e-6
 
