@@ -56,7 +56,7 @@ typedef struct mms_config {
     int32_t type_vocab;       /* 2 */
     int32_t text_len;         /* zk/lds 20, lxmert 23 */
     int32_t precision;        /* 1: bf16 activations, one MFMA pass; 2: split-bf16 (hi+lo), two passes */
-    int32_t chunk_pairs;      /* pairs per internal launch wave (0 = default 4096) */
+    int32_t chunk_pairs;      /* pairs per internal launch wave (0 = default 8192) */
     int32_t stop_after;       /* debug: run only the first n encoder layers (-1 = all) and skip nothing else */
     int32_t device;           /* HIP device ordinal */
     int32_t pack_tokens;      /* zk/lxmert: 1 = drop padded tokens whose keys are masked (identical logits: a masked

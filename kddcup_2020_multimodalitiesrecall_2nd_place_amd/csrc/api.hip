@@ -404,7 +404,7 @@ struct GemmOut {
 
 int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf16* w, const float* bias, int64_t M,
          int N, int K, int act, const GemmOut& out, const Planes* resid = nullptr, const int* m_dev = nullptr,
-         const int* a_index = nullptr) {
+         const int* a_index = nullptr, RowMap rmap = RowMap{0, 0, 0}, const int* r_index = nullptr) {
     if (M <= 0) return MMS_OK;
     if (N % 128 || K % 64) return h->fail(MMS_ERR_ARG, "gemm: N % 128 or K % 64 != 0");
     GemmParams p{};
@@ -415,7 +415,7 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     p.c_f32 = out.f32; p.ldc = out.ldc;
     p.c_hi = out.pl.hi; p.c_lo = out.pl.lo; p.ldp = out.ldp; p.cmap = out.cmap;
     if (resid) { p.r_hi = resid->hi; p.r_lo = resid->lo; p.ldr = H; }
-    p.m_dev = m_dev; p.a_index = a_index;
+    p.m_dev = m_dev; p.a_index = a_index; p.rmap = rmap; p.r_index = r_index;
     if (h->timing) {
         if (h->ev_used + 2 > h->ev.size()) {
             h->ev.resize(h->ev_used + 2);
@@ -476,6 +476,32 @@ int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes ou
     return MMS_OK;
 }
 
+// Last encoder layer of the single-stream models (zk, lds): only the CLS row feeds the pooler
+// (pixelbert.py:258-266), so K/V are projected for every live row but Q, attention, the attention-output
+// dense, both LayerNorms and the FFN run on the n CLS rows only.  Result (compact [n,768]) lands in x rows 0..n.
+int last_layer_cls(mms_handle* h, hipStream_t st, const LayerW& w, int S, int64_t n, const float* key_add, const Pack& pk) {
+    const int64_t M = n * S;
+    const RowMap cls = RowMap{1, S, 0};                 // dense: CLS of pair b is row b*S; packed: row pk.off[b]
+    // K,V for every live row -> columns [768, 2304) of the qkv buffer
+    if (int rc = gemm(h, st, h->x, H, ID, w.att.wqkv + (long long)H * H, w.att.bqkv + H, M, 2 * H, H, ACT_NONE,
+                      to_f32(h->qkv + H, 3 * H), nullptr, pk.rows)) return rc;
+    // Q for the CLS rows only -> compact fp32 [n,768] (the pooled buffer is idle until the pooler)
+    if (int rc = gemm(h, st, h->x, H, cls, w.att.wqkv, w.att.bqkv, n, H, H, ACT_NONE, to_f32(h->pooled, H), nullptr, nullptr, pk.off)) return rc;
+    AttnParams a{};
+    a.q = h->pooled; a.ldq = H; a.q_stride = 1; a.Sq = 1; a.o_compact = 1;
+    a.k = h->qkv + H; a.v = h->qkv + 2 * H; a.ldkv = 3 * H; a.Sk = S;
+    a.key_add = key_add; a.kv_off = pk.off; a.kv_cnt = pk.cnt;
+    a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo; a.ldo = H; a.B = (int)n;
+    launch_attention(a, st);
+    if (int rc = gemm(h, st, h->ctx, H, ID, w.att.wo, w.att.bo, n, H, H, ACT_NONE, to_f32(h->t, H), &h->x, nullptr, nullptr, cls, pk.off)) return rc;
+    launch_ln_to_planes(h->t, H, w.att.g, w.att.b, h->y.hi, h->y.lo, H, (int)n, st);
+    const int I = h->cfg.inter;
+    if (int rc = gemm(h, st, h->y, H, ID, w.ffn.wi, w.ffn.bi, n, I, H, ACT_GELU_TANH, to_planes(h->mid, I))) return rc;
+    if (int rc = gemm(h, st, h->mid, I, ID, w.ffn.wd, w.ffn.bd, n, H, I, ACT_NONE, to_f32(h->t, H), &h->y)) return rc;
+    launch_ln_to_planes(h->t, H, w.ffn.g, w.ffn.b, h->x.hi, h->x.lo, H, (int)n, st);
+    return MMS_OK;
+}
+
 int check_ready(mms_handle* h, int model, const void* batch, const float* logits) {
     if (!h) return MMS_ERR_ARG;
     if (!h->finalized) return h->fail(MMS_ERR_STATE, "mms_finalize has not been called");
@@ -533,13 +559,20 @@ int zk_chunk(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, i
     }
     // --- encoder ---
     const int nl = (c.stop_after >= 0 && c.stop_after < c.layers) ? c.stop_after : c.layers;
+    const bool cls_only = c.stop_after < 0 && c.layers > 0;   // debug runs keep the full hidden state
     for (int i = 0; i < nl; ++i) {
+        if (cls_only && i == nl - 1) {
+            if (int rc = last_layer_cls(h, st, h->layers[i], S, n, h->key_add, pk)) return rc;
+            break;
+        }
         if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, n, h->key_add, pk)) return rc;
         if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * S, ACT_GELU_TANH, pk)) return rc;
     }
     // --- pooler on the CLS rows + AM-softmax head ---
-    if (int rc = gemm(h, st, h->x, H, RowMap{1, S, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H), nullptr,
-                      nullptr, pk.off)) return rc;
+    if (cls_only) {
+        if (int rc = gemm(h, st, h->x, H, ID, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H))) return rc;
+    } else if (int rc = gemm(h, st, h->x, H, RowMap{1, S, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H), nullptr,
+                             nullptr, pk.off)) return rc;
     launch_zk_head(h->pooled, h->am_kernel, b->labels + p0, 30.0f, 0.35f, logits + p0 * 2, probs ? probs + p0 * 2 : nullptr, (int)n, st);
     return MMS_OK;
 }
@@ -557,11 +590,16 @@ int lds_chunk(mms_handle* h, hipStream_t st, const mms_lds_batch* b, int64_t p0,
                       to_planes(h->x, H, RowMap{MMS_NBOX, S, T}))) return rc;
     launch_lds_label(h->E, h->w_lab8, b->labelfeat + p0 * MMS_NBOX * MMS_LABEL_LEN, c.vocab, S, T + MMS_NBOX, h->x.hi, h->x.lo, (int)n, st);
     const int nl = (c.stop_after >= 0 && c.stop_after < c.layers) ? c.stop_after : c.layers;
+    const bool cls_only = c.stop_after < 0 && c.layers > 0;
     for (int i = 0; i < nl; ++i) {
+        if (cls_only && i == nl - 1) {
+            if (int rc = last_layer_cls(h, st, h->layers[i], S, n, nullptr, Pack())) return rc;
+            break;
+        }
         if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, n, nullptr)) return rc;
         if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * S, ACT_GELU_TANH)) return rc;
     }
-    if (int rc = gemm(h, st, h->x, H, RowMap{1, S, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H))) return rc;
+    if (int rc = gemm(h, st, h->x, H, cls_only ? ID : RowMap{1, S, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H))) return rc;
     launch_lds_head(h->pooled, h->w_cls, h->b_cls, logits + p0 * 2, probs ? probs + p0 * 2 : nullptr, (int)n, st);
     return MMS_OK;
 }
@@ -661,7 +699,7 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
 }
 
 int chunk_size(const mms_handle* h, int64_t B) {
-    int64_t c = h->cfg.chunk_pairs > 0 ? h->cfg.chunk_pairs : 4096;
+    int64_t c = h->cfg.chunk_pairs > 0 ? h->cfg.chunk_pairs : 8192;
     return (int)(B < c ? B : c);
 }
 

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int b = unit / MMS_HEADS, h = unit % MMS_HEADS;
     const int fr = lane & 15, fk = lane >> 4;
     // dense: rows b*S .. ; packed (ragged): per-pair row offset / live-token count
-    const int q0 = p.q_base + (p.q_off ? p.q_off[b] : b * p.Sq);
+    const int q0 = p.q_base + (p.q_off ? p.q_off[b] : b * (p.q_stride ? p.q_stride : p.Sq));
     const int kv0 = p.kv_base + (p.kv_off ? p.kv_off[b] : b * p.Sk);
     const int Sq = p.q_cnt ? p.q_cnt[b] : p.Sq;
     const int Sk = p.kv_cnt ? p.kv_cnt[b] : p.Sk;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         for (int r = 0; r < 4; ++r) {
             const int i = qt * 16 + fk * 4 + r;
             if (i >= Sq) continue;
-            const long long off = (long long)(q0 + i) * p.ldo + h * MMS_HEAD_DIM + fr * 4;
+            const long long off = (long long)(p.o_compact ? b : q0 + i) * p.ldo + h * MMS_HEAD_DIM + fr * 4;
             bf16x4 hi, lo;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             for (int j = 0; j < 4; ++j) {
                 float v = acc[i][j][r] + bj[j];
                 if (p.r_hi) {
-                    const long long ro = (long long)row * p.ldr + colj[j];
+                    const long long ro = (p.r_index ? (long long)p.r_index[row] : p.rmap(row)) * (long long)p.ldr + colj[j];
                     v += join_bf16(p.r_hi[ro], p.r_lo[ro]);
                 }
                 v = apply_act(v, ACT);

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
             if (row < Meff) {
                 v += bias4;
                 if (p.r_hi) {
-                    const long long ro = (long long)row * p.ldr + col;
+                    const long long ro = (p.r_index ? (long long)p.r_index[row] : p.rmap(row)) * (long long)p.ldr + col;
                     const bf16x4 rh = *reinterpret_cast<const bf16x4*>(p.r_hi + ro);
                     const bf16x4 rl = *reinterpret_cast<const bf16x4*>(p.r_lo + ro);
 #pragma unroll

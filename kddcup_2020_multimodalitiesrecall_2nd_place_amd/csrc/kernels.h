@@ -20,6 +20,7 @@ struct GemmParams {
     const bf16* r_hi; const bf16* r_lo; int ldr;  // residual planes (logical rows) or nullptr
     const int* m_dev;            // optional device-side row count: M_eff = min(M, *m_dev) (packed mode)
     const int* a_index;          // optional row gather: logical row r reads A row a_index[r]
+    RowMap rmap; const int* r_index;  // residual row of logical row r: r_index ? r_index[r] : rmap(r)
     unsigned long long* flop_counter;  // optional: block 0 adds 2*M_eff*N*K (executed algorithmic FLOPs)
 };
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
@@ -41,6 +42,8 @@ struct AttnParams {
     // packed (ragged) mode: per-pair first row and live-token count; nullptr = dense (b*S, S).
     // Sq / Sk are then the MAXIMUM lengths (tile selection).
     const int* q_off; const int* q_cnt; const int* kv_off; const int* kv_cnt;
+    int q_stride;                // dense q rows: q_base + b * q_stride (0 -> Sq)
+    int o_compact;               // 1: Sq == 1 and the output row is b (CLS-only last layer)
 };
 void launch_attention(const AttnParams& p, hipStream_t st);
 

@@ -1,0 +1,30 @@
+#!/bin/bash
+# usage (GPU box): tools/pmc_traffic.sh <tag> [bench args]  -- HBM traffic of the GEMM kernels over one bench pass.
+# Two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md prescribes; the gfx950 FETCH_SIZE
+# x2 correction for wide coalesced reads is applied in the summary (WRITE_SIZE is reported uncorrected).
+R=${GRAFT_REPO_ROOT:-/root/repo}
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp
+mkdir -p $R/gpurun_out/pmc
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc -o ${tag}_$c -- python $R/bench.py --steps 1 --warmup 0 --no-cpu "$@" > $R/gpurun_out/pmc/${tag}_$c.log 2>&1
+done
+python - <<PY
+import csv, json, collections
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg = collections.defaultdict(float); n = collections.Counter()
+    for r in csv.DictReader(open("$R/gpurun_out/pmc/${tag}_%s_counter_collection.csv" % c)):
+        k = "gemm" if "gemm" in r["Kernel_Name"] else ("attn" if "attn" in r["Kernel_Name"] else ("ln" if "k_ln" in r["Kernel_Name"] else "other"))
+        agg[k] += float(r["Counter_Value"]); n[k] += 1
+    out[c] = {k: {"sum_kb": agg[k], "dispatches": n[k]} for k in agg}
+g_f, g_w = out["FETCH_SIZE"]["gemm"], out["WRITE_SIZE"]["gemm"]
+res = {"tag": "$tag", "gemm_launches": g_f["dispatches"],
+       "fetch_bytes_per_launch_raw": g_f["sum_kb"] * 1024 / g_f["dispatches"],
+       "fetch_bytes_per_launch_x2_corrected": 2 * g_f["sum_kb"] * 1024 / g_f["dispatches"],
+       "write_bytes_per_launch_uncalibrated": g_w["sum_kb"] * 1024 / g_w["dispatches"],
+       "all": out}
+res["hbm_bytes_per_launch"] = res["fetch_bytes_per_launch_x2_corrected"] + res["write_bytes_per_launch_uncalibrated"]
+json.dump(res, open("$R/gpurun_out/pmc/${tag}_traffic.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "all"}))
+PY
