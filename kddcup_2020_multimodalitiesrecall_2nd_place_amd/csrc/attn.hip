@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     float4 kf[KT][4], qf[QT][4];
 #pragma unroll
     for (int jt = 0; jt < KT; ++jt) {
+        if (jt * 16 >= Sk) continue;   // wave-uniform: this key tile holds no live key (ragged pairs)
         int j = jt * 16 + fr;
         j = j < Sk ? j : Sk - 1;
         const float* kr = p.k + (long long)(kv0 + j) * p.ldkv + h * MMS_HEAD_DIM + fk * 4;
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+        if (qt * 16 >= Sq) continue;
         int i = qt * 16 + fr;
         i = i < Sq ? i : Sq - 1;
         const float* qr = p.q + (long long)(q0 + i) * p.ldq + h * MMS_HEAD_DIM + fk * 4;
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (jt * 16 < Sk && qt * 16 < Sq)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[jt][s].x, qf[qt][s].x, a, 0, 0, 0);
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+        if (qt * 16 >= Sq) continue;
         float m = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < KT; ++jt)
@@ -116,12 +120,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (jt * 16 >= Sk) continue;   // whole tile has P == 0
             int j = jt * 16 + fk * 4 + r;
             j = j < Sk ? j : Sk - 1;  // P is exactly 0 there; keep the load in bounds and finite
             const float4 vf = *reinterpret_cast<const float4*>(
                 p.v + (long long)(kv0 + j) * p.ldkv + h * MMS_HEAD_DIM + fr * 4);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
+                if (qt * 16 >= Sq) continue;
                 const float pv = sc[jt][qt][r];
                 o[qt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.x, o[qt][0], 0, 0, 0);
                 o[qt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.y, o[qt][1], 0, 0, 0);
