@@ -21,7 +21,7 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int NSPLIT, int ACT, int BM, int BN, int WAVES_M, int WAVES_N, int STAGE_GLDS>
+template <int NSPLIT, int ACT, int BM, int BN, int WAVES_M, int WAVES_N, int STAGE_GLDS, int OPT>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const GemmParams p) {
     constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, FM = TM / 16, FN = TN / 16;
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
     const int nk = p.K / BK;
     const int fr = lane & 15, fk = lane >> 4;
 
-    auto compute = [&](const unsigned char* sb) {
+    // `hook(g)` runs after MFMA group g = ks * FM + i (used to interleave the next tile's LDS-DMA issue)
+    auto compute = [&](const unsigned char* sb, auto&& hook) {
         const unsigned char* sA0 = sb;
         const unsigned char* sA1 = sb + A_BYTES;
         const unsigned char* sB = sb + NSPLIT * A_BYTES;
@@ -77,15 +78,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
             for (int j = 0; j < FN; ++j)
                 b[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * TN + j * 16 + fr, ks * 4 + fk));
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+            for (int i = 0; i < FM; ++i) {
+                if (OPT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b[j], acc[i][j], 0, 0, 0);
                     if (NSPLIT == 2)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b[j], acc[i][j], 0, 0, 0);
                 }
+                if (OPT & 2) __builtin_amdgcn_s_setprio(0);
+                hook(ks * FM + i);
+            }
         }
     };
+    auto no_hook = [](int) {};
 
     if constexpr (STAGE_GLDS) {
         // one wave instruction fills one 1-KiB row group (8 rows x 128 B): lane -> (row g*8 + lane/8, slot lane%8)
@@ -107,27 +113,44 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
             const int c = (lane & 7) ^ ((r >> 1) & 7);
             w_src[s] = p.w + (long long)(bn * BN + r) * p.K + c * 8;
         }
-        auto issue = [&](int kt, unsigned char* sb) {
+        // piece q of a stage: q < GA*NSPLIT -> A planes, else B; one global_load_lds (1 KiB) per piece per wave
+        constexpr int NPIECE = GA * NSPLIT + GB;
+        auto issue_piece = [&](int q, int kt, unsigned char* sb) {
             const int ko = kt * BK;
-#pragma unroll
-            for (int s = 0; s < GA; ++s) {
-                unsigned char* d = sb + (wave + NW * s) * 1024;
-                __builtin_amdgcn_global_load_lds((glb_void*)(a_src[s] + ko), (lds_void*)d, 16, 0, 0);
-                if (NSPLIT == 2)
-                    __builtin_amdgcn_global_load_lds((glb_void*)(a_src[s] + lo_delta + ko), (lds_void*)(d + A_BYTES), 16, 0, 0);
-            }
-#pragma unroll
-            for (int s = 0; s < GB; ++s) {
+            if (q < GA * NSPLIT) {
+                const int s = q / NSPLIT, pl = q % NSPLIT;
+                unsigned char* d = sb + pl * A_BYTES + (wave + NW * s) * 1024;
+                __builtin_amdgcn_global_load_lds((glb_void*)(a_src[s] + (pl ? lo_delta : 0) + ko), (lds_void*)d, 16, 0, 0);
+            } else {
+                const int s = q - GA * NSPLIT;
                 unsigned char* d = sb + NSPLIT * A_BYTES + (wave + NW * s) * 1024;
                 __builtin_amdgcn_global_load_lds((glb_void*)(w_src[s] + ko), (lds_void*)d, 16, 0, 0);
             }
         };
-        issue(0, smem);
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) issue_piece(q, 0, smem);
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt have landed
             __syncthreads();                                    // ... everyone's have; buffer (kt+1)&1 is free
-            if (kt + 1 < nk) issue(kt + 1, smem + ((kt + 1) & 1) * STAGE_BYTES);
-            compute(smem + (kt & 1) * STAGE_BYTES);
+            unsigned char* nb = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            const bool more = kt + 1 < nk;
+            if (OPT & 1) {
+                // spread the next tile's LDS-DMA issue over the MFMA groups (issue cost hides under MFMA execution)
+                constexpr int NG = 2 * FM;
+                compute(smem + (kt & 1) * STAGE_BYTES, [&](int g) {
+                    if (more) {
+#pragma unroll
+                        for (int q = 0; q < NPIECE; ++q)
+                            if (q * NG / NPIECE == g) issue_piece(q, kt + 1, nb);
+                    }
+                });
+            } else {
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < NPIECE; ++q) issue_piece(q, kt + 1, nb);
+                }
+                compute(smem + (kt & 1) * STAGE_BYTES, no_hook);
+            }
         }
     } else {
         constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;  // 16-B chunks per thread per tile
@@ -171,7 +194,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
             }
 #pragma unroll
             for (int s = 0; s < CB; ++s) rb[s] = *reinterpret_cast<const u32x4*>(w_row[s] + ko);
-            compute(smem);
+            compute(smem, no_hook);
         }
     }
 
@@ -227,25 +250,28 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
     }
 }
 
-template <int NSPLIT, int BM, int BN, int WM, int WN, int G>
+template <int NSPLIT, int BM, int BN, int WM, int WN, int G, int OPT>
 static void launch_cfg(const GemmParams& p, hipStream_t st) {
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
     const dim3 grid(nblk), block(WM * WN * 64);
     switch (p.act) {
-        case ACT_RELU: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_RELU, BM, BN, WM, WN, G>), grid, block, 0, st, p); break;
-        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_GELU_TANH, BM, BN, WM, WN, G>), grid, block, 0, st, p); break;
-        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_GELU_ERF, BM, BN, WM, WN, G>), grid, block, 0, st, p); break;
-        case ACT_TANH: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_TANH, BM, BN, WM, WN, G>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_NONE, BM, BN, WM, WN, G>), grid, block, 0, st, p); break;
+        case ACT_RELU: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_RELU, BM, BN, WM, WN, G, OPT>), grid, block, 0, st, p); break;
+        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_GELU_TANH, BM, BN, WM, WN, G, OPT>), grid, block, 0, st, p); break;
+        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_GELU_ERF, BM, BN, WM, WN, G, OPT>), grid, block, 0, st, p); break;
+        case ACT_TANH: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_TANH, BM, BN, WM, WN, G, OPT>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_NONE, BM, BN, WM, WN, G, OPT>), grid, block, 0, st, p); break;
     }
 }
 
 template <int NSPLIT>
 static bool launch_variant(const GemmParams& p, int variant, hipStream_t st) {
     switch (variant) {
-        case 1: launch_cfg<NSPLIT, 128, 128, 2, 2, 0>(p, st); return true;                          // reg-staged 128x128
-        case 3: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1>(p, st); return true;  // LDS-DMA, double buffered
-        case 4: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 0>(p, st); return true;  // reg-staged 128x256 (default)
+        case 1: launch_cfg<NSPLIT, 128, 128, 2, 2, 0, 0>(p, st); return true;                          // reg-staged 128x128
+        case 3: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 0>(p, st); return true;  // LDS-DMA, double buffered
+        case 4: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 0, 0>(p, st); return true;  // reg-staged 128x256 (default)
+        case 5: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 1>(p, st); return true;  // v3 + interleaved DMA issue
+        case 6: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 3>(p, st); return true;  // v5 + setprio
+        case 7: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 0, 2>(p, st); return true;  // v4 + setprio
         default: return false;
     }
 }
