@@ -272,6 +272,9 @@ static bool launch_variant(const GemmParams& p, int variant, hipStream_t st) {
         case 5: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 1>(p, st); return true;  // v3 + interleaved DMA issue
         case 6: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 3>(p, st); return true;  // v5 + setprio
         case 7: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 0, 2>(p, st); return true;  // v4 + setprio
+        case 8: if (p.N % 256) return false; launch_cfg<NSPLIT, 256, 256, 4, 2, 0, 0>(p, st); return true;  // 256x256, wave tile 64x128
+        case 9: if (p.N % 256) return false; launch_cfg<NSPLIT, 256, 256, 2, 4, 0, 0>(p, st); return true;  // 256x256, wave tile 128x64
+        case 10: launch_cfg<NSPLIT, 256, 128, 4, 2, 0, 0>(p, st); return true;                           // 256x128, wave tile 64x64
         default: return false;
     }
 }

@@ -209,3 +209,100 @@ def make_lxmert_weights(cfg: LxmertConfig = LxmertConfig(), seed: int = 20200823
 def make_weights(cfg, seed: int = 20200823, bf16_matrices: bool = True):
     return {"zk": make_zk_weights, "lds": make_lds_weights, "lxmert": make_lxmert_weights}[cfg.name](
         cfg, seed, bf16_matrices)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# checkpoint importers.  The container's tensor names ARE the reference's checkpoint
+# names, so importing is a filtered dict copy plus validation; nothing here needs TensorFlow or the checkpoints
+# themselves (which are not shipped: README.md:47-48).
+# ------------------------------------------------------------------------------------------------------------------
+def expected_shapes(cfg) -> dict:
+    """{name: shape} the scorer of ``cfg`` requires (what ``mms_finalize`` checks on the C side)."""
+    return _shapes_from_generator(cfg)
+
+
+def _shapes_from_generator(cfg):
+    class _Rec(_Gen):
+        def mat(self, name, shape, std):
+            self.out[name] = tuple(shape)
+
+        def vec(self, name, shape, std, mean=0.0):
+            self.out[name] = tuple(shape)
+    g = _Rec(0, False)
+    mod = globals()
+    saved = mod["_Gen"]
+    mod["_Gen"] = lambda seed, bf16: g       # the make_* functions only use .mat/.vec/.ln_* of the generator object
+    try:
+        {"zk": make_zk_weights, "lds": make_lds_weights, "lxmert": make_lxmert_weights}[cfg.name](cfg)
+    finally:
+        mod["_Gen"] = saved
+    return dict(g.out)
+
+
+def from_torch_state_dict(cfg, state_dict) -> dict:
+    """lxmert: ``torch.load('BEST.pth')`` / ``KDDModel.state_dict()`` (code/lxmert/src/tasks/kdd_model.py:131-152) ->
+    container.  Unused heads (``cls.*``, ``logit_W``) and DataParallel ``module.`` prefixes are dropped."""
+    want = _shapes_from_generator(cfg)
+    out = {}
+    for k, v in state_dict.items():
+        k = k[7:] if k.startswith("module.") else k
+        if k in want:
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            out[k] = np.ascontiguousarray(a, dtype=np.float32)
+    validate(cfg, out)
+    return out
+
+
+def from_tf_variables(cfg, reader, ema: bool = None) -> dict:
+    """zk / lds: ``reader`` is anything with ``get_tensor(name)`` and ``has_tensor(name)`` (a
+    ``tf.train.load_checkpoint`` reader, or a dict wrapper).  zk restores the EMA shadow variables
+    (code/imagebert_zk/evaluate_normal.py:204-206,212): ``<name>/ExponentialMovingAverage`` is preferred when present
+    (``ema=None``) or required (``ema=True``); lds restores the raw variables (run_pretraining_predict_score.py:558-563)."""
+    want = _shapes_from_generator(cfg)
+    out = {}
+    for name in want:
+        shadow = name + "/ExponentialMovingAverage"
+        if ema is not False and reader.has_tensor(shadow):
+            src = shadow
+        elif ema is True:
+            raise KeyError("EMA shadow variable missing: " + shadow)
+        else:
+            src = name
+        out[name] = np.ascontiguousarray(reader.get_tensor(src), dtype=np.float32)
+    validate(cfg, out)
+    return out
+
+
+class DictReader:
+    """Minimal ``get_tensor`` / ``has_tensor`` adapter over a {name: array} dict (e.g. an .npz export of a checkpoint)."""
+
+    def __init__(self, d):
+        self.d = d
+
+    def has_tensor(self, name):
+        return name in self.d
+
+    def get_tensor(self, name):
+        return self.d[name]
+
+
+def validate(cfg, weights: dict):
+    want = _shapes_from_generator(cfg)
+    missing = sorted(set(want) - set(weights))
+    bad = sorted(k for k in want if k in weights and tuple(weights[k].shape) != want[k])
+    if missing or bad:
+        raise ValueError("checkpoint does not match %s: missing %s; wrong shape %s" % (
+            cfg.name, missing[:5] + (["..."] if len(missing) > 5 else []),
+            [(k, tuple(weights[k].shape), want[k]) for k in bad[:5]]))
+
+
+def bf16_rounding_report(weights: dict) -> dict:
+    """How far a real fp32 checkpoint is from this build's bf16 GEMM-weight storage format: max relative rounding
+    step per matrix (2^-9 worst case).  DESIGN.md 'precision modes' explains what that means for logit parity."""
+    rep = {}
+    for k, v in weights.items():
+        if v.ndim >= 2 and v.size >= 768 * 2:
+            r = round_to_bf16(v)
+            denom = np.maximum(np.abs(v), 1e-30)
+            rep[k] = float(np.max(np.abs(r - v) / denom))
+    return rep
