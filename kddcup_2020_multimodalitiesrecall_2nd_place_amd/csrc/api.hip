@@ -48,6 +48,8 @@ struct mms_handle {
     std::vector<void*> w_allocs, ws_allocs, lab_allocs;
     bool finalized = false;
     int nsplit = 2;
+    struct WPlane { const bf16* base; long long elems; };
+    std::vector<WPlane> w_planes;   // precision 3: hi plane [base, base+elems), lo plane right behind it
 
     // ---- weights (device) ----
     float *E = nullptr, *type_tab = nullptr, *pos_tab = nullptr, *emb_g = nullptr, *emb_b = nullptr;
@@ -151,18 +153,28 @@ struct MatSrc { const float* p; int64_t n; bool in_out; };
 int upload_mat(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, bf16** out) {
     int64_t N = 0;
     for (auto& s : srcs) N += s.n;
-    std::vector<uint16_t> buf((size_t)(N * K));
+    // precision mode 3 keeps a second plane lo = bf16(w - bf16(w)) right behind the hi plane
+    const bool with_lo = h->nsplit == 3;
+    std::vector<uint16_t> buf((size_t)(N * K) * (with_lo ? 2 : 1));
     int64_t r0 = 0;
     for (auto& s : srcs) {
         for (int64_t n = 0; n < s.n; ++n)
-            for (int64_t k = 0; k < K; ++k)
-                buf[(size_t)((r0 + n) * K + k)] = f2bf(s.in_out ? s.p[k * s.n + n] : s.p[n * K + k]);
+            for (int64_t k = 0; k < K; ++k) {
+                const float w = s.in_out ? s.p[k * s.n + n] : s.p[n * K + k];
+                const uint16_t hi = f2bf(w);
+                buf[(size_t)((r0 + n) * K + k)] = hi;
+                if (with_lo) {
+                    uint32_t u = (uint32_t)hi << 16; float hf; std::memcpy(&hf, &u, 4);
+                    buf[(size_t)(N * K + (r0 + n) * K + k)] = f2bf(w - hf);
+                }
+            }
         r0 += s.n;
     }
     void* p;
     if (int rc = dev_alloc(h, h->w_allocs, &p, buf.size() * 2)) return rc;
     HIP_TRY(h, hipMemcpy(p, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
     *out = (bf16*)p;
+    if (with_lo) h->w_planes.push_back({(const bf16*)p, N * K});
     return MMS_OK;
 }
 int mat(mms_handle* h, const std::string& name, int64_t N, int64_t K, bool in_out, bf16** out,
@@ -410,6 +422,11 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     GemmParams p{};
     p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.amap = amap;
     p.w = w; p.bias = bias; p.M = (int)M; p.N = N; p.K = K;
+    if (h->nsplit == 3) {   // locate the lo plane of (a view into) this weight matrix
+        for (const auto& wp : h->w_planes)
+            if (w >= wp.base && w < wp.base + wp.elems) { p.w_lo = w + wp.elems; break; }
+        if (!p.w_lo) return h->fail(MMS_ERR_STATE, "gemm: weight has no lo plane");
+    }
     p.act = act;
     p.out_kind = out.f32 ? OUT_F32 : OUT_PLANES;
     p.c_f32 = out.f32; p.ldc = out.ldc;
@@ -719,7 +736,7 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
     *out = nullptr;
     if (cfg->model < 0 || cfg->model > 2) { g_err = "bad model id"; return MMS_ERR_ARG; }
     if (cfg->inter <= 0 || cfg->inter % 128) { g_err = "inter must be a positive multiple of 128"; return MMS_ERR_ARG; }
-    if (cfg->precision != 1 && cfg->precision != 2) { g_err = "precision must be 1 or 2"; return MMS_ERR_ARG; }
+    if (cfg->precision < 1 || cfg->precision > 3) { g_err = "precision must be 1, 2 or 3"; return MMS_ERR_ARG; }
     if (cfg->text_len <= 0 || cfg->text_len > 32 || cfg->text_len + 1 > cfg->max_pos) { g_err = "bad text_len"; return MMS_ERR_ARG; }
     if (cfg->layers < 0 || cfg->vocab <= 0 || cfg->type_vocab <= 0) { g_err = "bad layer/vocab config"; return MMS_ERR_ARG; }
     if (cfg->pack_tokens && cfg->model == MMS_MODEL_LDS) { g_err = "lds has no attention mask: every token is live, pack_tokens must be 0"; return MMS_ERR_ARG; }
@@ -873,7 +890,7 @@ int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const fl
     launch_split_f32(w_f32_nk, wp, wp + N * K, N * K, st);  // hi plane == RNE bf16 of the weights
     GemmParams p{};
     p.a_hi = ap; p.a_lo = ap + M * lda; p.lda = (int)lda; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
-    p.w = wp; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
+    p.w = wp; p.w_lo = wp + N * K; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
     if (resid_f32) {
         DBG_TRY(hipMalloc((void**)&rp, (size_t)M * N * 4));
         launch_split_f32(resid_f32, rp, rp + M * N, M * N, st);
@@ -923,7 +940,7 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     launch_split_f32(rf, rp, rp + M * N, M * N, 0);
     GemmParams p{};
     p.a_hi = ap; p.a_lo = ap + M * K; p.lda = (int)K; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
-    p.w = wp; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
+    p.w = wp; p.w_lo = wp + N * K; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
     if (resid) { p.r_hi = rp; p.r_lo = rp + M * N; p.ldr = (int)N; }
     if (out_planes) { p.out_kind = OUT_PLANES; p.c_hi = cp; p.c_lo = cp + M * N; p.ldp = (int)N; }
     else { p.out_kind = OUT_F32; p.c_f32 = cf; p.ldc = (int)N; }

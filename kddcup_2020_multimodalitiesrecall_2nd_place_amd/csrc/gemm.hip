@@ -174,6 +174,7 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
     if (nblk <= 0) return;
     int variant = get_gemm_variant();
+    if (nsplit == 3) { launch_gemm_tile(p, 3, 1, st); return; }
     if (variant == 0 && (p.m_dev || p.flop_counter)) variant = 1;   // the v0 kernel has no device-side row count
     if (variant > 0 && launch_gemm_tile(p, nsplit, variant, st)) return;
     if (variant > 0 && launch_gemm_tile(p, nsplit, 1, st)) return;   // N % 256 != 0: 128x128 tile

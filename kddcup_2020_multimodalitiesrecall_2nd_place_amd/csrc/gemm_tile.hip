@@ -25,8 +25,10 @@ template <int NSPLIT, int ACT, int BM, int BN, int WAVES_M, int WAVES_N, int STA
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const GemmParams p) {
     constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, FM = TM / 16, FN = TN / 16;
+    constexpr int NA = NSPLIT >= 2 ? 2 : 1, NB = NSPLIT == 3 ? 2 : 1;   // operand planes staged per K-tile
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-    constexpr int STAGE_BYTES = NSPLIT * A_BYTES + B_BYTES;
+    constexpr int STAGE_BYTES = NA * A_BYTES + NB * B_BYTES;
+    static_assert(!(STAGE_GLDS && NSPLIT == 3), "LDS-DMA path stages one weight plane only");
     constexpr int NBUF = STAGE_GLDS ? 2 : 1;
     constexpr int EPI_BYTES = NW * 16 * (TN + 4) * 4;
     constexpr int SMEM_BYTES = NBUF * STAGE_BYTES > EPI_BYTES ? NBUF * STAGE_BYTES : EPI_BYTES;
@@ -50,6 +52,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
     }
     const int bm = bid / nbn, bn = bid % nbn;
     const long long lo_delta = p.a_lo - p.a_hi;
+    const long long wlo_delta = p.w_lo - p.w;
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -64,27 +67,33 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
     auto compute = [&](const unsigned char* sb, auto&& hook) {
         const unsigned char* sA0 = sb;
         const unsigned char* sA1 = sb + A_BYTES;
-        const unsigned char* sB = sb + NSPLIT * A_BYTES;
+        const unsigned char* sB = sb + NA * A_BYTES;
+        const unsigned char* sB1 = sB + B_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a0[FM], a1[FM], b[FN];
+            bf16x8 a0[FM], a1[FM], b[FN], b1[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int o = lds_off(wm * TM + i * 16 + fr, ks * 4 + fk);
                 a0[i] = *reinterpret_cast<const bf16x8*>(sA0 + o);
-                if (NSPLIT == 2) a1[i] = *reinterpret_cast<const bf16x8*>(sA1 + o);
+                if (NA == 2) a1[i] = *reinterpret_cast<const bf16x8*>(sA1 + o);
             }
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
-                b[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * TN + j * 16 + fr, ks * 4 + fk));
+            for (int j = 0; j < FN; ++j) {
+                const int o = lds_off(wn * TN + j * 16 + fr, ks * 4 + fk);
+                b[j] = *reinterpret_cast<const bf16x8*>(sB + o);
+                if (NB == 2) b1[j] = *reinterpret_cast<const bf16x8*>(sB1 + o);
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 if (OPT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b[j], acc[i][j], 0, 0, 0);
-                    if (NSPLIT == 2)
+                    if (NA == 2)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b[j], acc[i][j], 0, 0, 0);
+                    if (NB == 2)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b1[j], acc[i][j], 0, 0, 0);
                 }
                 if (OPT & 2) __builtin_amdgcn_s_setprio(0);
                 hook(ks * FM + i);
@@ -114,16 +123,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
             w_src[s] = p.w + (long long)(bn * BN + r) * p.K + c * 8;
         }
         // piece q of a stage: q < GA*NSPLIT -> A planes, else B; one global_load_lds (1 KiB) per piece per wave
-        constexpr int NPIECE = GA * NSPLIT + GB;
+        constexpr int NPIECE = GA * NA + GB;
         auto issue_piece = [&](int q, int kt, unsigned char* sb) {
             const int ko = kt * BK;
-            if (q < GA * NSPLIT) {
-                const int s = q / NSPLIT, pl = q % NSPLIT;
+            if (q < GA * NA) {
+                const int s = q / NA, pl = q % NA;
                 unsigned char* d = sb + pl * A_BYTES + (wave + NW * s) * 1024;
                 __builtin_amdgcn_global_load_lds((glb_void*)(a_src[s] + (pl ? lo_delta : 0) + ko), (lds_void*)d, 16, 0, 0);
             } else {
-                const int s = q - GA * NSPLIT;
-                unsigned char* d = sb + NSPLIT * A_BYTES + (wave + NW * s) * 1024;
+                const int s = q - GA * NA;
+                unsigned char* d = sb + NA * A_BYTES + (wave + NW * s) * 1024;
                 __builtin_amdgcn_global_load_lds((glb_void*)(w_src[s] + ko), (lds_void*)d, 16, 0, 0);
             }
         };
@@ -166,34 +175,43 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
         }
 #pragma unroll
         for (int s = 0; s < CB; ++s) w_row[s] = p.w + (long long)(bn * BN + lr + (NT / 8) * s) * p.K + c * 8;
-        u32x4 ra0[CA], ra1[CA], rb[CB];
+        u32x4 ra0[CA], ra1[CA], rb[CB], rb1[CB];
 #pragma unroll
         for (int s = 0; s < CA; ++s) {
             ra0[s] = *reinterpret_cast<const u32x4*>(a_row[s]);
-            if (NSPLIT == 2) ra1[s] = *reinterpret_cast<const u32x4*>(a_row[s] + lo_delta);
+            if (NA == 2) ra1[s] = *reinterpret_cast<const u32x4*>(a_row[s] + lo_delta);
         }
 #pragma unroll
-        for (int s = 0; s < CB; ++s) rb[s] = *reinterpret_cast<const u32x4*>(w_row[s]);
+        for (int s = 0; s < CB; ++s) {
+            rb[s] = *reinterpret_cast<const u32x4*>(w_row[s]);
+            if (NB == 2) rb1[s] = *reinterpret_cast<const u32x4*>(w_row[s] + wlo_delta);
+        }
         for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < CA; ++s) {
                 const int o = lds_off(lr + (NT / 8) * s, c);
                 *reinterpret_cast<u32x4*>(smem + o) = ra0[s];
-                if (NSPLIT == 2) *reinterpret_cast<u32x4*>(smem + A_BYTES + o) = ra1[s];
+                if (NA == 2) *reinterpret_cast<u32x4*>(smem + A_BYTES + o) = ra1[s];
             }
 #pragma unroll
-            for (int s = 0; s < CB; ++s)
-                *reinterpret_cast<u32x4*>(smem + NSPLIT * A_BYTES + lds_off(lr + (NT / 8) * s, c)) = rb[s];
+            for (int s = 0; s < CB; ++s) {
+                const int o = NA * A_BYTES + lds_off(lr + (NT / 8) * s, c);
+                *reinterpret_cast<u32x4*>(smem + o) = rb[s];
+                if (NB == 2) *reinterpret_cast<u32x4*>(smem + B_BYTES + o) = rb1[s];
+            }
             __syncthreads();
             const int ko = (kt + 1 < nk ? kt + 1 : kt) * BK;
 #pragma unroll
             for (int s = 0; s < CA; ++s) {
                 ra0[s] = *reinterpret_cast<const u32x4*>(a_row[s] + ko);
-                if (NSPLIT == 2) ra1[s] = *reinterpret_cast<const u32x4*>(a_row[s] + lo_delta + ko);
+                if (NA == 2) ra1[s] = *reinterpret_cast<const u32x4*>(a_row[s] + lo_delta + ko);
             }
 #pragma unroll
-            for (int s = 0; s < CB; ++s) rb[s] = *reinterpret_cast<const u32x4*>(w_row[s] + ko);
+            for (int s = 0; s < CB; ++s) {
+                rb[s] = *reinterpret_cast<const u32x4*>(w_row[s] + ko);
+                if (NB == 2) rb1[s] = *reinterpret_cast<const u32x4*>(w_row[s] + wlo_delta + ko);
+            }
             compute(smem, no_hook);
         }
     }
@@ -281,5 +299,10 @@ static bool launch_variant(const GemmParams& p, int variant, hipStream_t st) {
 
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st) {
     if (p.M <= 0) return true;
+    if (nsplit == 3) {   // A and W both split: 128x128 tile (4 operand planes x 16 KiB = 64 KiB, 2 workgroups / CU)
+        if (!p.w_lo) return false;
+        launch_cfg<3, 128, 128, 2, 2, 0, 0>(p, st);
+        return true;
+    }
     return nsplit == 2 ? launch_variant<2>(p, variant, st) : launch_variant<1>(p, variant, st);
 }

@@ -5,12 +5,14 @@
 // ---------------------------------------------------------------------------------------------
 // GEMM  C[M,N] = act(A[M,K] * W[N,K]^T + bias (+ residual))      (gemm.hip)
 // A is a split-plane activation (hi/lo bf16), W is bf16 [N][K] (K contiguous), N % 128 == 0,
-// K % 64 == 0.  nsplit 1: hi plane only (1 MFMA pass), 2: hi + lo (2 passes, parity mode).
+// K % 64 == 0.  nsplit 1: hi plane only (1 MFMA pass), 2: A hi+lo (2 passes, parity mode for bf16-exact
+// weights), 3: A hi+lo and W hi+lo (3 passes a_hi*w_hi + a_lo*w_hi + a_hi*w_lo: fp32-checkpoint-faithful).
 // ---------------------------------------------------------------------------------------------
 struct GemmParams {
     const bf16* a_hi; const bf16* a_lo; int lda;
     RowMap amap;                 // logical row -> A row
     const bf16* w;
+    const bf16* w_lo;            // lo plane of the weights (precision mode 3) or nullptr
     const float* bias;           // [N] or nullptr
     int M, N, K;
     int out_kind, act;

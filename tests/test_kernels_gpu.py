@@ -85,6 +85,35 @@ def test_gemm_matches_fp64(case, nsplit, gemm_variant):
 
 
 @pytest.mark.parametrize("gemm_variant", GEMM_VARIANTS, indirect=True)
+@pytest.mark.parametrize("case", GEMM_CASES[:5])
+def test_gemm_precision3_follows_fp32_weights(case):
+    """nsplit 3: weights split hi+lo as well -> an arbitrary fp32 W is followed to ~2^-16."""
+    M, K, N, act, resid, planes = case
+    l = lib.load()
+    a = weights.normal("kt3/a/%d/%d" % (M, K), (M, K), 1)
+    w = weights.normal("kt3/w/%d/%d" % (N, K), (N, K), 1, 1.0 / np.sqrt(K))      # NOT bf16-representable
+    bias = weights.normal("kt3/b/%d" % N, (N,), 1, 0.1)
+    r = weights.normal("kt3/r/%d/%d" % (M, N), (M, N), 1) if resid else None
+    da, dw, db = _dev(a), _dev(w), _dev(bias)
+    dr = _dev(r) if resid else None
+    out = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    rc = l.mms_dbg_gemm(da.data_ptr(), M, K, K, dw.data_ptr(), N, db.data_ptr(), dr.data_ptr() if resid else None,
+                        act, 3, int(planes), out.data_ptr(), None)
+    assert rc == 0, l.mms_global_error()
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    if resid:
+        ref = ref + r
+    ref = _act(ref, act)
+    err = np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 5e-5, (case, err)
+    out2 = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    l.mms_dbg_gemm(da.data_ptr(), M, K, K, dw.data_ptr(), N, db.data_ptr(), dr.data_ptr() if resid else None, act, 2, int(planes),
+                   out2.data_ptr(), None)
+    err2 = np.abs(out2.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err2 > 3 * err          # mode 2 rounds W to bf16: visibly worse on non-representable weights
+
+
+@pytest.mark.parametrize("gemm_variant", GEMM_VARIANTS, indirect=True)
 def test_gemm_transpose_detecting(gemm_variant):
     """A = [I | 0]: C must reproduce W^T rows (asymmetric W) -- catches row/col swaps."""
     l = lib.load()

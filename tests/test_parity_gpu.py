@@ -216,3 +216,21 @@ def test_tsv_to_score_file_pipeline(tmp_path):
         back = scorefile.read_scores(str(out))
         for q, p_, sc in zip(qid, pid, score):
             assert abs(back[str(q)][str(p_)] - sc) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["zk", "lxmert"])
+def test_precision3_follows_unrounded_fp32_checkpoint(name):
+    """Real checkpoints are not bf16-representable.  Mode 3 (activations and weights split, 3 MFMA passes) must
+    stay inside 1e-3 against the fp64 oracle on the UNROUNDED fp32 weights; mode 2 (weights stored as bf16) is
+    reported next to it (~5e-3 from the weight rounding alone)."""
+    cfg = {"zk": ZkConfig(layers=4), "lxmert": LxmertConfig(l_layers=3, r_layers=2, x_layers=2)}[name]
+    w = weights.make_weights(cfg, bf16_matrices=False)
+    ps = synth.make_pairs(2, 8, tag="/p3")
+    b = _batch(cfg, ps)
+    ref, _ = O.forward(cfg, w, b, np.float64)
+    got3, _ = _hip_logits(cfg, w, b, precision=3)
+    got2, _ = _hip_logits(cfg, w, b, precision=2)
+    e3, e2 = vecrel(got3, ref).max(), vecrel(got2, ref).max()
+    print("\n[%s, fp32 weights] vec-rel logit error: precision3 %.2e  precision2 %.2e" % (name, e3, e2))
+    assert e3 < TOL_P2, e3
+    assert e2 < TOL_P1
