@@ -84,7 +84,6 @@ def test_gemm_matches_fp64(case, nsplit, gemm_variant):
     assert err < tol, (case, nsplit, gemm_variant, err)
 
 
-@pytest.mark.parametrize("gemm_variant", GEMM_VARIANTS, indirect=True)
 @pytest.mark.parametrize("case", GEMM_CASES[:5])
 def test_gemm_precision3_follows_fp32_weights(case):
     """nsplit 3: weights split hi+lo as well -> an arbitrary fp32 W is followed to ~2^-16."""
