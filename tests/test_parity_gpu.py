@@ -234,3 +234,49 @@ def test_precision3_follows_unrounded_fp32_checkpoint(name):
     print("\n[%s, fp32 weights] vec-rel logit error: precision3 %.2e  precision2 %.2e" % (name, e3, e2))
     assert e3 < TOL_P2, e3
     assert e2 < TOL_P1
+
+
+def test_full_size_workload_properties():
+    """BASELINE.json's headline size (1000 queries x 30 candidates, full 12-layer zk): size-independent properties
+    -- a random 24-pair subset against the oracle, permutation equivariance over pairs, independence from the
+    internal chunk size, idempotence, duplicated pairs scoring identically."""
+    cfg = ZkConfig()
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(1000, 30, tag="/fullsize", with_feats=False)
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(123)
+    feats = torch.randn((ps.n, 10, 2048), device=dev, generator=g).clamp_(min=0)
+    feats *= (torch.arange(10, device=dev)[None, :] < torch.as_tensor(ps.num_boxes, device=dev)[:, None])[:, :, None]
+    ps.feats = feats
+    b = synth.zk_batch(ps, cfg.text_len)
+    # duplicate pair 7 into slot 29999
+    for k in b:
+        if torch.is_tensor(b[k]):
+            b[k][-1] = b[k][7]
+        else:
+            b[k][-1] = b[k][7]
+    s = scorers.ZkScorer(cfg, w, chunk_pairs=8192)
+    l1, p1 = scorers.score_batch(s, b)
+    l1b, _ = scorers.score_batch(s, b)
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l1b)                                   # idempotent / deterministic
+    assert torch.equal(l1[-1], l1[7])                             # identical inputs -> identical logits
+    assert torch.isfinite(l1).all() and (p1.sum(1) - 1).abs().max() < 1e-6
+    l1 = l1.cpu().numpy()
+    # oracle on a random subset
+    idx = np.sort(np.random.RandomState(0).choice(ps.n, 24, replace=False))
+    sub = {k: (v[torch.as_tensor(idx, device=dev)].cpu().numpy() if torch.is_tensor(v) else v[idx]) for k, v in b.items()}
+    ref, _ = O.forward(cfg, w, sub, np.float64)
+    assert vecrel(l1[idx], ref).max() < TOL_P2
+    # permutation equivariance (the packed layout, row tiles and attention offsets all change)
+    perm = np.random.RandomState(1).permutation(ps.n)
+    bp = {k: (v[torch.as_tensor(perm, device=dev)] if torch.is_tensor(v) else v[perm]) for k, v in b.items()}
+    lp, _ = scorers.score_batch(s, bp)
+    assert np.abs(lp.cpu().numpy() - l1[perm]).max() < 2e-4
+    s.close()
+    # chunk-size independence
+    s2 = scorers.ZkScorer(cfg, w, chunk_pairs=3001)
+    l2, _ = scorers.score_batch(s2, b)
+    assert np.abs(l2.cpu().numpy() - l1).max() < 2e-4
+    s2.close()
