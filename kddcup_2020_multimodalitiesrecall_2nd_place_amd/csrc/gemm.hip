@@ -176,6 +176,8 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     int variant = get_gemm_variant();
     if (nsplit == 3) { launch_gemm_tile(p, 3, 1, st); return; }
     if (variant == 0 && (p.m_dev || p.flop_counter)) variant = 1;   // the v0 kernel has no device-side row count
+    if (variant == 11 && launch_gemm_ring(p, nsplit, 4, st)) return;
+    if (variant == 12 && launch_gemm_ring(p, nsplit, 2, st)) return;
     if (variant > 0 && launch_gemm_tile(p, nsplit, variant, st)) return;
     if (variant > 0 && launch_gemm_tile(p, nsplit, 1, st)) return;   // N % 256 != 0: 128x128 tile
     if (nsplit == 2) launch_ns<2>(p, nblk, st);

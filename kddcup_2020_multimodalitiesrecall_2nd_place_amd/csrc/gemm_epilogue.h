@@ -1,0 +1,60 @@
+// Shared GEMM epilogue (gemm_tile.hip, gemm_ring.hip): accumulators -> per-wave LDS strip (16 rows at a time) ->
+// row-contiguous float4, so bias / residual / activation / split run vectorised and global stores are 16 B (fp32)
+// or 8 B (bf16x4 per plane) per lane, 256 / 128 contiguous bytes per row.
+#pragma once
+#include "kernels.h"
+
+template <int ACT, int BM, int BN, int TM, int TN, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], unsigned char* smem, int bm, int bn,
+                                              int wm, int wn, int wave, int lane, int Meff) {
+    const int fr = lane & 15, fk = lane >> 4;
+    __syncthreads();  // all waves are done reading operand tiles
+    constexpr int ES = TN + 4;                      // strip row stride in floats
+    float* strip = reinterpret_cast<float*>(smem) + wave * 16 * ES;
+    constexpr int V4_PER_ROW = TN / 4, ROWS_PER_IT = 64 / V4_PER_ROW, ITERS = 16 / ROWS_PER_IT;
+    const int er = lane / V4_PER_ROW, ec = (lane % V4_PER_ROW) * 4;
+    const int col = bn * BN + wn * TN + ec;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) strip[(fk * 4 + r) * ES + j * 16 + fr] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < ITERS; ++t) {
+            const int lrow = t * ROWS_PER_IT + er;
+            const int row = bm * BM + wm * TM + i * 16 + lrow;
+            f32x4 v = *reinterpret_cast<const f32x4*>(strip + lrow * ES + ec);
+            if (row < Meff) {
+                v += bias4;
+                if (p.r_hi) {
+                    const long long ro = (p.r_index ? (long long)p.r_index[row] : p.rmap(row)) * (long long)p.ldr + col;
+                    const bf16x4 rh = *reinterpret_cast<const bf16x4*>(p.r_hi + ro);
+                    const bf16x4 rl = *reinterpret_cast<const bf16x4*>(p.r_lo + ro);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += join_bf16(rh[e], rl[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT);
+                const long long orow = p.cmap(row);
+                if (p.out_kind == OUT_F32) {
+                    *reinterpret_cast<f32x4*>(p.c_f32 + orow * p.ldc + col) = v;
+                } else {
+                    bf16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bf16 a, c2; split_bf16(v[e], a, c2); h[e] = a; l[e] = c2; }
+                    *reinterpret_cast<bf16x4*>(p.c_hi + orow * p.ldp + col) = h;
+                    *reinterpret_cast<bf16x4*>(p.c_lo + orow * p.ldp + col) = l;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}

@@ -13,6 +13,7 @@
 //    re-reads them row-contiguous, so bias / residual / activation / split run on float4 and global
 //    stores are 16 B (fp32) or 8 B (bf16x4 per plane) per lane, 256 / 128 contiguous bytes per row.
 #include "kernels.h"
+#include "gemm_epilogue.h"
 
 #define BK 64
 
@@ -216,56 +217,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
         }
     }
 
-    // ---- epilogue: accumulators -> per-wave LDS strip (16 rows) -> row-contiguous float4 ----
-    __syncthreads();  // all waves are done reading operand tiles
-    constexpr int ES = TN + 4;                      // strip row stride in floats
-    float* strip = reinterpret_cast<float*>(smem) + wave * 16 * ES;
-    constexpr int V4_PER_ROW = TN / 4, ROWS_PER_IT = 64 / V4_PER_ROW, ITERS = 16 / ROWS_PER_IT;
-    const int er = lane / V4_PER_ROW, ec = (lane % V4_PER_ROW) * 4;
-    const int col = bn * BN + wn * TN + ec;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) strip[(fk * 4 + r) * ES + j * 16 + fr] = acc[i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int t = 0; t < ITERS; ++t) {
-            const int lrow = t * ROWS_PER_IT + er;
-            const int row = bm * BM + wm * TM + i * 16 + lrow;
-            f32x4 v = *reinterpret_cast<const f32x4*>(strip + lrow * ES + ec);
-            if (row < Meff) {
-                v += bias4;
-                if (p.r_hi) {
-                    const long long ro = (p.r_index ? (long long)p.r_index[row] : p.rmap(row)) * (long long)p.ldr + col;
-                    const bf16x4 rh = *reinterpret_cast<const bf16x4*>(p.r_hi + ro);
-                    const bf16x4 rl = *reinterpret_cast<const bf16x4*>(p.r_lo + ro);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += join_bf16(rh[e], rl[e]);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT);
-                const long long orow = p.cmap(row);
-                if (p.out_kind == OUT_F32) {
-                    *reinterpret_cast<f32x4*>(p.c_f32 + orow * p.ldc + col) = v;
-                } else {
-                    bf16x4 h, l;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { bf16 a, c2; split_bf16(v[e], a, c2); h[e] = a; l[e] = c2; }
-                    *reinterpret_cast<bf16x4*>(p.c_hi + orow * p.ldp + col) = h;
-                    *reinterpret_cast<bf16x4*>(p.c_lo + orow * p.ldp + col) = l;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    gemm_epilogue<ACT, BM, BN, TM, TN, FM, FN>(p, acc, smem, bm, bn, wm, wn, wave, lane, Meff);
 }
 
 template <int NSPLIT, int BM, int BN, int WM, int WN, int G, int OPT>
@@ -284,15 +236,9 @@ static void launch_cfg(const GemmParams& p, hipStream_t st) {
 template <int NSPLIT>
 static bool launch_variant(const GemmParams& p, int variant, hipStream_t st) {
     switch (variant) {
-        case 1: launch_cfg<NSPLIT, 128, 128, 2, 2, 0, 0>(p, st); return true;                          // reg-staged 128x128
-        case 3: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 0>(p, st); return true;  // LDS-DMA, double buffered
+        case 1: launch_cfg<NSPLIT, 128, 128, 2, 2, 0, 0>(p, st); return true;                               // reg-staged 128x128 (N % 256 != 0)
+        case 3: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 0>(p, st); return true;  // LDS-DMA, double buffered, 1 WG/CU
         case 4: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 0, 0>(p, st); return true;  // reg-staged 128x256 (default)
-        case 5: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 1>(p, st); return true;  // v3 + interleaved DMA issue
-        case 6: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 3>(p, st); return true;  // v5 + setprio
-        case 7: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 0, 2>(p, st); return true;  // v4 + setprio
-        case 8: if (p.N % 256) return false; launch_cfg<NSPLIT, 256, 256, 4, 2, 0, 0>(p, st); return true;  // 256x256, wave tile 64x128
-        case 9: if (p.N % 256) return false; launch_cfg<NSPLIT, 256, 256, 2, 4, 0, 0>(p, st); return true;  // 256x256, wave tile 128x64
-        case 10: launch_cfg<NSPLIT, 256, 128, 4, 2, 0, 0>(p, st); return true;                           // 256x128, wave tile 64x64
         default: return false;
     }
 }

@@ -15,7 +15,7 @@ SHAPES = [  # name, N, K, act, planes, resid
     ("ffn_down", 768, 3072, 0, 0, 1),
 ]
 l = lib.load()
-variants = [int(v) for v in sys.argv[1:]] or [0, 1, 3, 4, 5, 6, 7]
+variants = [int(v) for v in sys.argv[1:]] or [0, 1, 3, 4, 11, 12]
 for nsplit in (2, 1):
     for name, N, K, act, planes, resid in SHAPES:
         row = []
