@@ -493,29 +493,31 @@ int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes ou
     return MMS_OK;
 }
 
-// Last encoder layer of the single-stream models (zk, lds): only the CLS row feeds the pooler
-// (pixelbert.py:258-266), so K/V are projected for every live row but Q, attention, the attention-output
-// dense, both LayerNorms and the FFN run on the n CLS rows only.  Result (compact [n,768]) lands in x rows 0..n.
-int last_layer_cls(mms_handle* h, hipStream_t st, const LayerW& w, int S, int64_t n, const float* key_add, const Pack& pk) {
+// Last self-attention + FFN block before the pooler: only the CLS row feeds the pooler (pixelbert.py:258-266,
+// modeling.py:602-608), so K/V are projected for every live row of the stream but Q, attention, the attention-output
+// dense, both LayerNorms and the FFN run on the n CLS rows only.  `in` holds the block input (stream rows start at
+// row 0), `tmp` is the other hidden-state buffer; the result (compact [n,768]) is left in `in` rows 0..n.
+int last_block_cls(mms_handle* h, hipStream_t st, const AttW& att, const FfnW& ffn, int act, Planes in, Planes tmp, int S,
+                   int64_t n, const float* key_add, const Pack& pk) {
     const int64_t M = n * S;
     const RowMap cls = RowMap{1, S, 0};                 // dense: CLS of pair b is row b*S; packed: row pk.off[b]
     // K,V for every live row -> columns [768, 2304) of the qkv buffer
-    if (int rc = gemm(h, st, h->x, H, ID, w.att.wqkv + (long long)H * H, w.att.bqkv + H, M, 2 * H, H, ACT_NONE,
+    if (int rc = gemm(h, st, in, H, ID, att.wqkv + (long long)H * H, att.bqkv + H, M, 2 * H, H, ACT_NONE,
                       to_f32(h->qkv + H, 3 * H), nullptr, pk.rows)) return rc;
     // Q for the CLS rows only -> compact fp32 [n,768] (the pooled buffer is idle until the pooler)
-    if (int rc = gemm(h, st, h->x, H, cls, w.att.wqkv, w.att.bqkv, n, H, H, ACT_NONE, to_f32(h->pooled, H), nullptr, nullptr, pk.off)) return rc;
+    if (int rc = gemm(h, st, in, H, cls, att.wqkv, att.bqkv, n, H, H, ACT_NONE, to_f32(h->pooled, H), nullptr, nullptr, pk.off)) return rc;
     AttnParams a{};
     a.q = h->pooled; a.ldq = H; a.q_stride = 1; a.Sq = 1; a.o_compact = 1;
     a.k = h->qkv + H; a.v = h->qkv + 2 * H; a.ldkv = 3 * H; a.Sk = S;
     a.key_add = key_add; a.kv_off = pk.off; a.kv_cnt = pk.cnt;
     a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo; a.ldo = H; a.B = (int)n;
     launch_attention(a, st);
-    if (int rc = gemm(h, st, h->ctx, H, ID, w.att.wo, w.att.bo, n, H, H, ACT_NONE, to_f32(h->t, H), &h->x, nullptr, nullptr, cls, pk.off)) return rc;
-    launch_ln_to_planes(h->t, H, w.att.g, w.att.b, h->y.hi, h->y.lo, H, (int)n, st);
+    if (int rc = gemm(h, st, h->ctx, H, ID, att.wo, att.bo, n, H, H, ACT_NONE, to_f32(h->t, H), &in, nullptr, nullptr, cls, pk.off)) return rc;
+    launch_ln_to_planes(h->t, H, att.g, att.b, tmp.hi, tmp.lo, H, (int)n, st);
     const int I = h->cfg.inter;
-    if (int rc = gemm(h, st, h->y, H, ID, w.ffn.wi, w.ffn.bi, n, I, H, ACT_GELU_TANH, to_planes(h->mid, I))) return rc;
-    if (int rc = gemm(h, st, h->mid, I, ID, w.ffn.wd, w.ffn.bd, n, H, I, ACT_NONE, to_f32(h->t, H), &h->y)) return rc;
-    launch_ln_to_planes(h->t, H, w.ffn.g, w.ffn.b, h->x.hi, h->x.lo, H, (int)n, st);
+    if (int rc = gemm(h, st, tmp, H, ID, ffn.wi, ffn.bi, n, I, H, act, to_planes(h->mid, I))) return rc;
+    if (int rc = gemm(h, st, h->mid, I, ID, ffn.wd, ffn.bd, n, H, I, ACT_NONE, to_f32(h->t, H), &tmp)) return rc;
+    launch_ln_to_planes(h->t, H, ffn.g, ffn.b, in.hi, in.lo, H, (int)n, st);
     return MMS_OK;
 }
 
@@ -579,7 +581,7 @@ int zk_chunk(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, i
     const bool cls_only = c.stop_after < 0 && c.layers > 0;   // debug runs keep the full hidden state
     for (int i = 0; i < nl; ++i) {
         if (cls_only && i == nl - 1) {
-            if (int rc = last_layer_cls(h, st, h->layers[i], S, n, h->key_add, pk)) return rc;
+            if (int rc = last_block_cls(h, st, h->layers[i].att, h->layers[i].ffn, ACT_GELU_TANH, h->x, h->y, S, n, h->key_add, pk)) return rc;
             break;
         }
         if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, n, h->key_add, pk)) return rc;
@@ -610,7 +612,7 @@ int lds_chunk(mms_handle* h, hipStream_t st, const mms_lds_batch* b, int64_t p0,
     const bool cls_only = c.stop_after < 0 && c.layers > 0;
     for (int i = 0; i < nl; ++i) {
         if (cls_only && i == nl - 1) {
-            if (int rc = last_layer_cls(h, st, h->layers[i], S, n, nullptr, Pack())) return rc;
+            if (int rc = last_block_cls(h, st, h->layers[i].att, h->layers[i].ffn, ACT_GELU_TANH, h->x, h->y, S, n, nullptr, Pack())) return rc;
             break;
         }
         if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, n, nullptr)) return rc;
@@ -669,8 +671,28 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
         if (int rc = att_block(h, st, h->r_layers[i].att, h->x, h->y, ML, V, n, visn_add, pv)) return rc;
         if (int rc = ffn_block(h, st, h->r_layers[i].ffn, h->y, h->x, ML, MV, ACT_GELU_ERF, pv)) return rc;
     }
+    const bool trim_last = c.stop_after < 0 && c.x_layers > 0;   // debug runs keep the full hidden state
     for (int i = 0; i < c.x_layers && budget > 0; ++i, --budget) {
         const XLayerW& w = h->x_layers[i];
+        if (trim_last && i == c.x_layers - 1) {
+            // Last cross layer: only the language CLS row is read afterwards (pooler).  The vision stream's outputs
+            // (visn<-lang attention, vision self-attention, vision FFN) are dead; the language stream needs the
+            // lang<-visn cross attention on all its rows (they are the keys of its self-attention), then a CLS-only block.
+            if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, ML, H, H, ACT_NONE, to_f32(h->qkv, 3 * H), nullptr, pl.rows)) return rc;
+            if (int rc = gemm(h, st, h->x.at(ML * H), H, ID, w.cross.wqkv + (long long)H * H, w.cross.bqkv + H, MV, 2 * H, H, ACT_NONE,
+                              to_f32(h->qkv + ML * 3 * H + H, 3 * H), nullptr, pv.rows)) return rc;
+            AttnParams a{};
+            a.ldq = a.ldkv = 3 * H; a.ldo = H; a.B = (int)n; a.q_base = a.kv_base = 0;
+            a.q = h->qkv; a.Sq = T;
+            a.k = h->qkv + ML * 3 * H + H; a.v = h->qkv + ML * 3 * H + 2 * H; a.Sk = V; a.key_add = visn_add;
+            a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo;
+            a.q_off = pl.off; a.q_cnt = pl.cnt; a.kv_off = pv.off; a.kv_cnt = pv.cnt;
+            launch_attention(a, st);
+            if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
+            launch_ln_to_planes(h->t, H, w.cross.g, w.cross.b, h->y.hi, h->y.lo, H, (int)ML, st, pl.rows);
+            if (int rc = last_block_cls(h, st, w.lang_self, w.lang_ffn, ACT_GELU_ERF, h->y, h->x, T, n, lang_add, pl)) return rc;
+            break;
+        }
         // cross attention, both directions with the SAME weights (modeling.py:460-464): the QKV projection and
         // the output dense + LN run over both streams (one launch when dense, one per stream when packed)
         if (c.pack_tokens) {
@@ -709,7 +731,9 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
         if (int rc = ffn_block(h, st, w.visn_ffn, h->x, h->x, ML, MV, ACT_GELU_ERF, pv)) return rc;
     }
     // pooler (modeling.py:596-608) -> logit_fc (kdd_model.py:167-172)
-    if (int rc = gemm(h, st, h->x, H, RowMap{1, T, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_planes(h->ctx, H), nullptr, nullptr, pl.off)) return rc;
+    if (trim_last && budget > 0) {   // compact CLS rows were left in y by last_block_cls
+        if (int rc = gemm(h, st, h->y, H, ID, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_planes(h->ctx, H))) return rc;
+    } else if (int rc = gemm(h, st, h->x, H, RowMap{1, T, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_planes(h->ctx, H), nullptr, nullptr, pl.off)) return rc;
     if (int rc = gemm(h, st, h->ctx, H, ID, h->w_fc0, h->b_fc0, n, 2 * H, H, ACT_GELU_ERF, to_f32(h->hbuf, 2 * H))) return rc;
     launch_lx_head(h->hbuf, h->g_fc2, h->be_fc2, h->w_fc3, h->b_fc3, logits + p0 * 2, probs ? probs + p0 * 2 : nullptr, (int)n, st);
     return MMS_OK;
