@@ -1,6 +1,7 @@
 // libmmscore C ABI: handle, weight container, workspace and the launch plans of the three forwards.
 // See include/mmscore.h for the contract and the reference call sites each entry point replaces.
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -48,6 +49,7 @@ struct mms_handle {
     std::vector<void*> w_allocs, ws_allocs, lab_allocs;
     bool finalized = false;
     int nsplit = 2;
+    int x1_mask = 0;   // experiment (env MMS_X1_MASK): GEMM classes forced to one pass: 1 qkv, 2 att-out, 4 ffn-up, 8 ffn-down
     struct WPlane { const bf16* base; long long elems; };
     std::vector<WPlane> w_planes;   // precision 3: hi plane [base, base+elems), lo plane right behind it
 
@@ -416,8 +418,9 @@ struct GemmOut {
 
 int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf16* w, const float* bias, int64_t M,
          int N, int K, int act, const GemmOut& out, const Planes* resid = nullptr, const int* m_dev = nullptr,
-         const int* a_index = nullptr, RowMap rmap = RowMap{0, 0, 0}, const int* r_index = nullptr) {
+         const int* a_index = nullptr, RowMap rmap = RowMap{0, 0, 0}, const int* r_index = nullptr, int cls_bit = 0) {
     if (M <= 0) return MMS_OK;
+    const int nsplit = (h->nsplit == 2 && (h->x1_mask & cls_bit)) ? 1 : h->nsplit;
     if (N % 128 || K % 64) return h->fail(MMS_ERR_ARG, "gemm: N % 128 or K % 64 != 0");
     GemmParams p{};
     p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.amap = amap;
@@ -441,12 +444,12 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
         }
         p.flop_counter = h->flop_counter;   // executed algorithmic FLOPs (2*M_live*N*K), counted on the device
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
-        launch_gemm(p, h->nsplit, st);
+        launch_gemm(p, nsplit, st);
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
         h->ev_used += 2;
         h->gemm_launches += 1;
     } else {
-        launch_gemm(p, h->nsplit, st);
+        launch_gemm(p, nsplit, st);
     }
     return MMS_OK;
 }
@@ -465,7 +468,7 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
               const float* key_add, const Pack& pk = Pack()) {
     const int64_t M = B * S;
     if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wqkv, w.bqkv, M, 3 * H, H, ACT_NONE,
-                      to_f32(h->qkv + row0 * 3 * H, 3 * H), nullptr, pk.rows)) return rc;
+                      to_f32(h->qkv + row0 * 3 * H, 3 * H), nullptr, pk.rows, nullptr, ID, nullptr, 1)) return rc;
     AttnParams a{};
     a.q = h->qkv + row0 * 3 * H; a.ldq = 3 * H;
     a.k = a.q + H; a.v = a.q + 2 * H; a.ldkv = 3 * H;
@@ -477,7 +480,7 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     launch_attention(a, st);
     const Planes resid = in.at(row0 * H);
     if (int rc = gemm(h, st, h->ctx.at(row0 * H), H, ID, w.wo, w.bo, M, H, H, ACT_NONE,
-                      to_f32(h->t + row0 * H, H), &resid, pk.rows)) return rc;
+                      to_f32(h->t + row0 * H, H), &resid, pk.rows, nullptr, ID, nullptr, 2)) return rc;
     launch_ln_to_planes(h->t + row0 * H, H, w.g, w.b, out.hi + row0 * H, out.lo + row0 * H, H, (int)M, st, pk.rows);
     return MMS_OK;
 }
@@ -486,9 +489,9 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
 int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes out, int64_t row0, int64_t M, int act,
               const Pack& pk = Pack()) {
     const int I = h->cfg.inter;
-    if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I), nullptr, pk.rows)) return rc;
+    if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I), nullptr, pk.rows, nullptr, ID, nullptr, 4)) return rc;
     const Planes resid = in.at(row0 * H);
-    if (int rc = gemm(h, st, h->mid, I, ID, w.wd, w.bd, M, H, I, ACT_NONE, to_f32(h->t + row0 * H, H), &resid, pk.rows)) return rc;
+    if (int rc = gemm(h, st, h->mid, I, ID, w.wd, w.bd, M, H, I, ACT_NONE, to_f32(h->t + row0 * H, H), &resid, pk.rows, nullptr, ID, nullptr, 8)) return rc;
     launch_ln_to_planes(h->t + row0 * H, H, w.g, w.b, out.hi + row0 * H, out.lo + row0 * H, H, (int)M, st, pk.rows);
     return MMS_OK;
 }
@@ -773,6 +776,7 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
     mms_handle* h = new mms_handle();
     h->cfg = *cfg;
     h->nsplit = cfg->precision;
+    if (const char* e = getenv("MMS_X1_MASK")) h->x1_mask = atoi(e);
     *out = h;
     return MMS_OK;
 }

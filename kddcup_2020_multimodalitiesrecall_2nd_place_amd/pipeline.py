@@ -36,3 +36,32 @@ def predict_tsv(scorer, tsv_lines, label_table, tokenizer, out_path, sen2forest:
     else:
         scorefile.write_score_tsv(out_path, qid, pid, score)
     return qid, pid, score
+
+
+class EnsembleScorer:
+    """BASELINE.json config 5 host side: the three models score the same pair shard on the same GPU and are merged
+    pre-gather with main.py:59's weights, so the exchange step stays one fp32 per pair.
+
+    ``zk`` is used twice -- once on the query as given, once on the ``sen2forest`` rewrite (evaluate_normal_sen2fs.py,
+    load_data_v4.py:153-154) -- exactly the four tables main.py merges.  The product-uniqueness filter is global over
+    queries and therefore runs on rank 0 after the gather (``ensemble.uniqueness_filter``).
+    """
+
+    WEIGHTS = (0.2, 0.2, 0.3, 0.3)
+
+    def __init__(self, zk, lds, lxmert):
+        self.zk, self.lds, self.lxmert = zk, lds, lxmert
+
+    def score_lines(self, tsv_lines, label_table, tok_tf, tok_hf, batch_pairs: int = 8192):
+        """tok_tf: WordPieceTokenizer as the TF sub-projects build it; tok_hf: the lxmert (HF) flavour."""
+        lines = [l for l in tsv_lines if l.strip() and "product_id" not in l]
+        rec = [F.read_line(l, label_table, tok_tf) for l in lines]
+        rec_s2f = [F.read_line(l, label_table, tok_tf, sen2forest=True) for l in lines]
+        rec_hf = [F.read_line(l, label_table, tok_hf) for l in lines]
+        qid, pid, s1 = score_records(self.zk, rec, batch_pairs)
+        _, _, s2 = score_records(self.zk, rec_s2f, batch_pairs)
+        _, _, s3 = score_records(self.lds, rec, batch_pairs)
+        _, _, s4 = score_records(self.lxmert, rec_hf, batch_pairs)
+        w = self.WEIGHTS
+        merged = w[0] * s1.astype(np.float64) + w[1] * s2 + w[2] * s3 + w[3] * s4
+        return qid, pid, merged, (s1, s2, s3, s4)
