@@ -528,7 +528,8 @@ int check_ready(mms_handle* h, int model, const void* batch, const float* logits
     if (!h) return MMS_ERR_ARG;
     if (!h->finalized) return h->fail(MMS_ERR_STATE, "mms_finalize has not been called");
     if (h->cfg.model != model) return h->fail(MMS_ERR_ARG, "handle was created for a different model");
-    if (!batch || !logits) return h->fail(MMS_ERR_ARG, "null batch or logits pointer");
+    if (!batch) return h->fail(MMS_ERR_ARG, "null batch pointer");
+    if (!logits && *(const int64_t*)batch != 0) return h->fail(MMS_ERR_ARG, "null logits pointer");  // n_pairs is the first field
     return MMS_OK;
 }
 

@@ -57,7 +57,8 @@ class _Base:
         logits = torch.empty((n, 2), device=self.device, dtype=torch.float32)
         probs = torch.empty((n, 2), device=self.device, dtype=torch.float32)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        self.handle.score(struct, logits.data_ptr(), probs.data_ptr(), st)
+        if n > 0:
+            self.handle.score(struct, logits.data_ptr(), probs.data_ptr(), st)
         self._keep = keep  # keep inputs alive until the stream has consumed them
         self.logits = logits
         return logits, probs
