@@ -960,8 +960,11 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     DBG_TRY(hipMalloc((void**)&ap, (size_t)M * K * 4)); DBG_TRY(hipMalloc((void**)&wp, (size_t)N * K * 4));
     DBG_TRY(hipMalloc((void**)&rp, (size_t)M * N * 4)); DBG_TRY(hipMalloc((void**)&cp, (size_t)M * N * 4));
     DBG_TRY(hipMalloc((void**)&cf, (size_t)M * N * 4));
+    const bool zero_fill = getenv("MMS_GB_ZERO") != nullptr;   // DVFS probe: zero operands draw less power (never a bench number)
+    if (zero_fill) { DBG_TRY(hipMemset(af, 0, (size_t)M * K * 4)); DBG_TRY(hipMemset(wf, 0, (size_t)N * K * 4)); }
+    else
     hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, af, M * K, 1u);
-    hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, wf, N * K, 2u);
+    if (!zero_fill) hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, wf, N * K, 2u);
     hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, rf, M * N, 3u);
     hipLaunchKernelGGL(k_fill_random, dim3(64), dim3(256), 0, 0, bias, N, 4u);
     launch_split_f32(af, ap, ap + M * K, M * K, 0);

@@ -165,7 +165,7 @@ void set_gemm_variant(int v) { g_variant = v; }
 int get_gemm_variant() {
     if (g_variant < 0) {
         const char* e = getenv("MMS_GEMM_VARIANT");
-        g_variant = e ? atoi(e) : 4;   // 128x256 tile, 8 waves, register-staged: best measured (profiles/r01c_gemm_variants.txt)
+        g_variant = e ? atoi(e) : 99;  // 99 = auto: per-shape choice between the two best measured tiles (profiles/r01c_gemm_variants.txt)
     }
     return g_variant;
 }
@@ -175,9 +175,12 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     if (nblk <= 0) return;
     int variant = get_gemm_variant();
     if (nsplit == 3) { launch_gemm_tile(p, 3, 1, st); return; }
+    if (variant == 99)   // wide outputs (QKV, FFN-up): 256x256 / 16 waves (+3-4 %); N = 768 and small M: 128x256 / 8 waves
+        variant = (p.N >= 1536 && p.N % 256 == 0 && p.M >= 8192) ? 16 : 4;
     if (variant == 0 && (p.m_dev || p.flop_counter)) variant = 1;   // the v0 kernel has no device-side row count
     if (variant == 11 && launch_gemm_ring(p, nsplit, 4, st)) return;
     if (variant == 12 && launch_gemm_ring(p, nsplit, 2, st)) return;
+    if (variant >= 101 && variant <= 103 && launch_gemm_ring(p, nsplit, variant, st)) return;   // timing diagnostics
     if (variant > 0 && launch_gemm_tile(p, nsplit, variant, st)) return;
     if (variant > 0 && launch_gemm_tile(p, nsplit, 1, st)) return;   // N % 256 != 0: 128x128 tile
     if (nsplit == 2) launch_ns<2>(p, nblk, st);

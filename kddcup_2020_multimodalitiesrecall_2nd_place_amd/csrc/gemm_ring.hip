@@ -29,7 +29,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "unsupported count");
 }
 
-template <int NSPLIT, int ACT, int NSLOT>
+// DIAG (timing diagnostics only, results are WRONG): bit 0 drops the per-half-tile wait+barrier, bit 1 drops the LDS-DMA issue
+template <int NSPLIT, int ACT, int NSLOT, int DIAG>
 __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 256, WAVES_N = 4, NW = 8, TM = 64, TN = 64, FM = 4, FN = 4;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, SLOT = NSPLIT * A_BYTES + B_BYTES;
@@ -96,12 +97,14 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmParams p) {
     if (NSLOT == 4) { issue(1); if (nh > 2) issue(2); }
     for (int h = 0; h < nh; ++h) {
         const int ahead = (nh - 1 - h) < D ? (nh - 1 - h) : D;
-        if (ahead == 2) wait_vmcnt<2 * P>();
-        else if (ahead == 1) wait_vmcnt<P>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
+        if (!(DIAG & 1)) {
+            if (ahead == 2) wait_vmcnt<2 * P>();
+            else if (ahead == 1) wait_vmcnt<P>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
         asm volatile("" ::: "memory");
-        if (h + NSLOT - 1 < nh) issue(h + NSLOT - 1);
+        if (!(DIAG & 2) && h + NSLOT - 1 < nh) issue(h + NSLOT - 1);
         const unsigned char* sb = smem + (h & (NSLOT - 1)) * SLOT;
         bf16x8 a0[FM], a1[FM], b[FN];
 #pragma unroll
@@ -124,23 +127,27 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmParams p) {
     gemm_epilogue<ACT, BM, BN, TM, TN, FM, FN>(p, acc, smem, bm, bn, wm, wn, wave, lane, Meff);
 }
 
-template <int NSPLIT, int NSLOT>
+template <int NSPLIT, int NSLOT, int DIAG>
 static void launch_ring_ns(const GemmParams& p, hipStream_t st) {
     const int nblk = ((p.M + 127) / 128) * (p.N / 256);
     const dim3 grid(nblk), block(512);
     switch (p.act) {
-        case ACT_RELU: hipLaunchKernelGGL((gemm_ring_kernel<NSPLIT, ACT_RELU, NSLOT>), grid, block, 0, st, p); break;
-        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_ring_kernel<NSPLIT, ACT_GELU_TANH, NSLOT>), grid, block, 0, st, p); break;
-        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_ring_kernel<NSPLIT, ACT_GELU_ERF, NSLOT>), grid, block, 0, st, p); break;
-        case ACT_TANH: hipLaunchKernelGGL((gemm_ring_kernel<NSPLIT, ACT_TANH, NSLOT>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_ring_kernel<NSPLIT, ACT_NONE, NSLOT>), grid, block, 0, st, p); break;
+        case ACT_RELU: hipLaunchKernelGGL((gemm_ring_kernel<NSPLIT, ACT_RELU, NSLOT, DIAG>), grid, block, 0, st, p); break;
+        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_ring_kernel<NSPLIT, ACT_GELU_TANH, NSLOT, DIAG>), grid, block, 0, st, p); break;
+        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_ring_kernel<NSPLIT, ACT_GELU_ERF, NSLOT, DIAG>), grid, block, 0, st, p); break;
+        case ACT_TANH: hipLaunchKernelGGL((gemm_ring_kernel<NSPLIT, ACT_TANH, NSLOT, DIAG>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_ring_kernel<NSPLIT, ACT_NONE, NSLOT, DIAG>), grid, block, 0, st, p); break;
     }
 }
 
 bool launch_gemm_ring(const GemmParams& p, int nsplit, int nslot, hipStream_t st) {
     if (p.M <= 0) return true;
     if (p.N % 256 || nsplit > 2) return false;
-    if (nslot == 2) { if (nsplit == 2) launch_ring_ns<2, 2>(p, st); else launch_ring_ns<1, 2>(p, st); }
-    else { if (nsplit == 2) launch_ring_ns<2, 4>(p, st); else launch_ring_ns<1, 4>(p, st); }
+    if (nslot == 2) { if (nsplit == 2) launch_ring_ns<2, 2, 0>(p, st); else launch_ring_ns<1, 2, 0>(p, st); }
+    else if (nslot >= 100) {   // diagnostics: 101 no barrier, 102 no DMA, 103 neither (2-slot geometry, nsplit 2 only)
+        if (nsplit != 2) return false;
+        if (nslot == 101) launch_ring_ns<2, 2, 1>(p, st); else if (nslot == 102) launch_ring_ns<2, 2, 2>(p, st); else launch_ring_ns<2, 2, 3>(p, st);
+    }
+    else { if (nsplit == 2) launch_ring_ns<2, 4, 0>(p, st); else launch_ring_ns<1, 4, 0>(p, st); }
     return true;
 }

@@ -42,7 +42,7 @@ GEMM_CASES = [
 ]
 
 
-GEMM_VARIANTS = [0, 1, 3, 4, 11, 12]
+GEMM_VARIANTS = [0, 1, 3, 4, 11, 12, 16, 99]
 
 
 @pytest.fixture
@@ -50,7 +50,7 @@ def gemm_variant(request):
     l = lib.load()
     l.mms_set_gemm_variant(request.param)
     yield request.param
-    l.mms_set_gemm_variant(0)
+    l.mms_set_gemm_variant(99)   # back to the per-shape default
 
 
 @pytest.mark.parametrize("gemm_variant", GEMM_VARIANTS, indirect=True)
