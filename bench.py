@@ -88,14 +88,14 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("MMS_BENCH_SHARE_GPU"):
+        local = 0
+    torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # backend "nccl" == RCCL over xGMI; MMS_BENCH_BACKEND=gloo + MMS_BENCH_SHARE_GPU=1 only exist to exercise the
         # N > 1 code path on a single-GPU test box
         dist.init_process_group(os.environ.get("MMS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-    if os.environ.get("MMS_BENCH_SHARE_GPU"):
-        local = 0
-    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     cfg = {"zk": ZkConfig(), "lds": LdsConfig(), "lxmert": LxmertConfig()}[a.model]
