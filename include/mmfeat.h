@@ -1,0 +1,75 @@
+/*
+ * libmmfeat -- native (C++17, multi-threaded) TSV record featurizer feeding the pair scorers.
+ *
+ * Replaces the per-line Python work of the reference's data loaders on the callers' side of the hot path
+ * (paths relative to the reference root):
+ *   read_line              code/imagebert_zk/load_data_v4.py:133-163, code/imagebert_lds/src/load_data_pred.py:94-121,
+ *                          code/lxmert/src/utils.py:23-59   (tab split, base64 -> f32/i64 arrays, box normalisation + area,
+ *                          label-text ids per box, "[CLS] query [SEP]" WordPiece ids, sen2forest rewrite)
+ *   seq_padding(_2)        code/imagebert_zk/load_data_v4.py:78-102  (zero pad / truncate to 10 boxes, text_len tokens, 8 label ids)
+ * and writes straight into caller-owned (ideally pinned) padded batch buffers, so one H2D copy per array follows.
+ *
+ * Tokenisation: ASCII queries are tokenised natively (lower-case, whitespace / ASCII-punctuation split, greedy
+ * longest-match WordPiece) -- bit-identical to the BERT tokenizer on ASCII input.  A query containing any non-ASCII byte
+ * is NOT tokenised here: its row in `needs_host_tokenizer` is set to 1 and the caller fills query ids with the full
+ * Unicode tokenizer (featurizer.WordPieceTokenizer).  Label texts come pre-tokenised (there are only ~30 classes).
+ *
+ * Plain C ABI, no exceptions cross it; every function returns 0 on success or a negative error code, and
+ * mmf_last_error() returns a thread-local message.
+ */
+#ifndef MMFEAT_H
+#define MMFEAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mmf_context mmf_context;
+
+/* vocab: one token per line (id = line number).  max_chars: 200 (zk/lds tokenization.py:299) or 100 (lxmert).
+ * never_split_specials: 1 = keep "[CLS]" "[SEP]" "[PAD]" "[UNK]" "[MASK]" whole (lxmert's HF tokenizer), 0 = stock BERT. */
+int mmf_create(const char* vocab_path, int32_t max_chars, int32_t never_split_specials, mmf_context** out);
+void mmf_destroy(mmf_context* c);
+const char* mmf_last_error(void);
+
+/* class id -> pre-tokenised label text (<= 8 ids used, `len` = untruncated length, for the lxmert label mask) */
+int mmf_set_label(mmf_context* c, int64_t class_id, const int32_t* ids, int32_t len);
+
+/* ASCII tokeniser: returns the number of ids written (<= max_ids), or -2 if the text has non-ASCII bytes */
+int mmf_tokenize_ascii(const mmf_context* c, const char* text, int64_t text_len, int32_t* ids, int32_t max_ids);
+
+typedef struct mmf_batch_out {
+    int64_t* product_id;        /* [B] */
+    int64_t* query_id;          /* [B] */
+    int32_t* num_boxes;         /* [B]  raw count (may exceed 10) */
+    float* boxes;               /* [B,10,box_dim]  box_dim 5: 4 normalised corners + area (zk/lds); 4: corners (lxmert) */
+    float* feats;               /* [B,10,2048] */
+    int32_t* label_ids;         /* [B,10,8] */
+    int32_t* label_len;         /* [B,10]  untruncated label-text length */
+    int32_t* query_ids;         /* [B,text_len] zero padded / truncated */
+    int32_t* query_len;         /* [B]  untruncated length incl. [CLS] [SEP] */
+    uint8_t* needs_host_tokenizer; /* [B] 1 = query has non-ASCII bytes, query_ids/query_len not filled */
+    int64_t* query_span;        /* [B,2] byte range of the query field inside `data` (for the host tokenizer) */
+} mmf_batch_out;
+
+/* lines: `n` records in one buffer, record i = data[offsets[i] .. offsets[i+1]) (no trailing newline needed).
+ * Work is split over `threads` std::threads (<= 0: hardware concurrency).  Every output row is fully written
+ * (padding zeroed).  Returns 0, or -1000 - index of the first malformed record (message in mmf_last_error). */
+int mmf_featurize(const mmf_context* c, const char* data, const int64_t* offsets, int64_t n, int32_t text_len,
+                  int32_t box_dim, int32_t sen2forest, int32_t threads, const mmf_batch_out* out);
+
+/* Same, with record i = data[starts[i] .. ends[i]) -- records need not be contiguous (skipped header / blank lines). */
+int mmf_featurize_spans(const mmf_context* c, const char* data, const int64_t* starts, const int64_t* ends, int64_t n,
+                        int32_t text_len, int32_t box_dim, int32_t sen2forest, int32_t threads, const mmf_batch_out* out);
+
+/* Line splitter for a raw TSV buffer: fills starts/ends (newline excluded) for up to max_lines records, skipping blank
+ * lines and lines containing "product_id" (the header test of code/lxmert/src/tasks/kdd_data.py:70-71).  *consumed = bytes of
+ * `data` covered (resume the next call there).  Returns the number of records found, or -1. */
+int64_t mmf_split_lines(const char* data, int64_t len, int64_t* starts, int64_t* ends, int64_t max_lines, int64_t* consumed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -939,6 +939,10 @@ int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const fl
     return MMS_OK;
 }
 
+__global__ void k_mask_u16(unsigned short* p, long long n, unsigned short mask) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] &= mask;
+}
+
 __global__ void k_fill_random(float* p, long long n, unsigned seed) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         unsigned x = (unsigned)(i * 2654435761u) ^ seed;
@@ -970,6 +974,8 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     launch_split_f32(af, ap, ap + M * K, M * K, 0);
     launch_split_f32(wf, wp, wp + N * K, N * K, 0);
     launch_split_f32(rf, rp, rp + M * N, M * N, 0);
+    if (const char* e = getenv("MMS_GB_LOMASK"))   // power probe: zero the low mantissa bits of the A lo plane
+        hipLaunchKernelGGL(k_mask_u16, dim3(4096), dim3(256), 0, 0, (unsigned short*)(ap + M * K), M * K, (unsigned short)strtol(e, nullptr, 16));
     GemmParams p{};
     p.a_hi = ap; p.a_lo = ap + M * K; p.lda = (int)K; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
     p.w = wp; p.w_lo = wp + N * K; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;

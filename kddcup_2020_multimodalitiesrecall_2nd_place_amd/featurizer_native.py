@@ -1,0 +1,204 @@
+"""ctypes binding of libmmfeat (include/mmfeat.h): the multi-threaded native TSV featurizer.
+
+Same outputs as ``featurizer.read_line`` + ``featurizer.{zk,lds,lxmert}_batch`` (tests/test_featurizer_native.py),
+written straight into pinned host buffers when torch is available so each array needs one H2D copy.
+Queries with non-ASCII bytes are tokenised by the Python ``WordPieceTokenizer`` (full Unicode rules).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import featurizer as F
+from .config import FEAT_DIM, LABEL_LEN, N_BOX
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmmfeat.so")
+EXPORTS = ("mmf_create", "mmf_destroy", "mmf_last_error", "mmf_set_label", "mmf_tokenize_ascii", "mmf_featurize",
+           "mmf_featurize_spans", "mmf_split_lines")
+
+
+class BatchOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("product_id", "query_id", "num_boxes", "boxes", "feats", "label_ids", "label_len",
+                                          "query_ids", "query_len", "needs_host_tokenizer", "query_span")]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("native featurizer missing: %s (run __graft_entry__.build())" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        l.mmf_last_error.restype = C.c_char_p
+        l.mmf_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        l.mmf_destroy.argtypes = [C.c_void_p]
+        l.mmf_destroy.restype = None
+        l.mmf_set_label.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+        l.mmf_tokenize_ascii.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int32]
+        l.mmf_featurize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.POINTER(BatchOut)]
+        l.mmf_featurize_spans.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_int32, C.POINTER(BatchOut)]
+        l.mmf_split_lines.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        l.mmf_split_lines.restype = C.c_int64
+        _lib = l
+    return _lib
+
+
+def _host(shape, dtype, pinned):
+    if pinned:
+        import torch
+        t = torch.empty(shape, dtype=getattr(torch, np.dtype(dtype).name), pin_memory=True)
+        return t.numpy(), t
+    a = np.empty(shape, dtype)
+    return a, a
+
+
+class NativeFeaturizer:
+    """model: 'zk' | 'lds' | 'lxmert' (box_dim, text_len, tokenizer flavour follow the sub-project)."""
+
+    def __init__(self, vocab_path: str, label_table: dict, model: str = "zk", threads: int = 0, pinned: bool = False,
+                 reuse_buffers: bool = False):
+        """reuse_buffers: keep one (pinned) set of output buffers, grown on demand -- the returned arrays are then views
+        that the NEXT call overwrites (streaming use: featurize -> H2D copy -> featurize ...).  Page-faulting fresh
+        336 KB/row buffers costs more than the decode itself, so the streaming drivers turn this on."""
+        self.lib = load()
+        self.reuse, self._cap, self._pool = reuse_buffers, 0, None
+        self.model = model
+        self.text_len = 23 if model == "lxmert" else 20
+        self.box_dim = 4 if model == "lxmert" else 5
+        hf = model == "lxmert"
+        self.py_tok = F.WordPieceTokenizer(vocab_path, max_input_chars_per_word=100 if hf else 200,
+                                           never_split=F.SPECIALS if hf else ())
+        self.threads, self.pinned = threads, pinned
+        self._h = C.c_void_p()
+        if self.lib.mmf_create(vocab_path.encode(), 100 if hf else 200, int(hf), C.byref(self._h)) != 0:
+            raise RuntimeError("mmf_create: " + self.lib.mmf_last_error().decode())
+        for cls, text in label_table.items():             # ~30 classes: tokenised once with the full Unicode tokenizer
+            ids = np.asarray(self.py_tok.convert_tokens_to_ids(self.py_tok.tokenize(text)), np.int32)
+            if self.lib.mmf_set_label(self._h, int(cls), ids.ctypes.data if ids.size else None, int(ids.size)) != 0:
+                raise RuntimeError("mmf_set_label: " + self.lib.mmf_last_error().decode())
+
+    def tokenize_ascii(self, text: str):
+        b = text.encode("utf-8")
+        ids = np.empty(max(4 * len(b) + 4, 8), np.int32)
+        n = self.lib.mmf_tokenize_ascii(self._h, b, len(b), ids.ctypes.data, ids.size)
+        return None if n == -2 else ids[:n].tolist()
+
+    def _spec(self, n):
+        T = self.text_len
+        return dict(product_id=((n,), np.int64), query_id=((n,), np.int64), num_boxes=((n,), np.int32),
+                    boxes=((n, N_BOX, self.box_dim), np.float32), feats=((n, N_BOX, FEAT_DIM), np.float32),
+                    label_ids=((n, N_BOX, LABEL_LEN), np.int32), label_len=((n, N_BOX), np.int32),
+                    query_ids=((n, T), np.int32), query_len=((n,), np.int32), needs_host_tokenizer=((n,), np.uint8),
+                    query_span=((n, 2), np.int64))
+
+    def _buffers(self, n):
+        if not self.reuse:
+            pairs = {k: _host(shape, dt, self.pinned and n > 0) for k, (shape, dt) in self._spec(n).items()}
+            return {k: v[0] for k, v in pairs.items()}, {k: v[1] for k, v in pairs.items()}
+        if n > self._cap:
+            self._cap = max(n, 2 * self._cap)
+            self._pool = {k: _host(shape, dt, self.pinned) for k, (shape, dt) in self._spec(self._cap).items()}
+        return {k: v[0][:n] for k, v in self._pool.items()}, {k: v[1] for k, v in self._pool.items()}
+
+    def featurize(self, lines, sen2forest: bool = False) -> dict:
+        """lines: iterable of TSV records (str or bytes).  Returns the raw padded arrays (+ ``keep`` = pinned owners)."""
+        enc = [(l if isinstance(l, bytes) else l.encode("utf-8")) for l in lines]
+        offsets = np.zeros(len(enc) + 1, np.int64)
+        np.cumsum([len(e) for e in enc], out=offsets[1:])
+        return self.featurize_bytes(b"".join(enc), offsets, sen2forest)
+
+    def featurize_bytes(self, data, offsets: np.ndarray, sen2forest: bool = False) -> dict:
+        """record i = data[offsets[i]:offsets[i+1]] (``data``: bytes)."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        keep = np.frombuffer(data, np.uint8)
+        return self._run(keep.ctypes.data if keep.size else None, keep, offsets[:-1], offsets[1:], sen2forest)
+
+    def _run(self, base, view, starts, ends, sen2forest):
+        """base: address of the byte buffer; view: uint8 array over it (for the host-tokenizer fallback)."""
+        starts, ends = np.ascontiguousarray(starts, np.int64), np.ascontiguousarray(ends, np.int64)
+        n, T = len(starts), self.text_len
+        arr, keep = self._buffers(n)
+        out = BatchOut(*[arr[k].ctypes.data for k in ("product_id", "query_id", "num_boxes", "boxes", "feats", "label_ids",
+                                                      "label_len", "query_ids", "query_len", "needs_host_tokenizer", "query_span")])
+        if n:
+            rc = self.lib.mmf_featurize_spans(self._h, base, starts.ctypes.data, ends.ctypes.data, n, T, self.box_dim, int(sen2forest),
+                                              self.threads, C.byref(out))
+            if rc != 0:
+                raise ValueError("mmf_featurize failed (%d): %s" % (rc, self.lib.mmf_last_error().decode()))
+        for i in np.nonzero(arr["needs_host_tokenizer"])[0]:      # non-ASCII queries: full Unicode tokenizer
+            q = view[arr["query_span"][i, 0]:arr["query_span"][i, 1]].tobytes().decode("utf-8")
+            if sen2forest:
+                q = q.replace("sen department of", "forest style")
+            ids = self.py_tok.encode_query(q)
+            arr["query_len"][i] = len(ids)
+            arr["query_ids"][i] = 0
+            arr["query_ids"][i, :min(T, len(ids))] = ids[:T]
+        arr["keep"] = keep
+        return arr
+
+    def iter_file(self, path: str, batch_lines: int = 8192, sen2forest: bool = False, layout: bool = True):
+        """Stream a TSV file: yields one batch dict per ``batch_lines`` records (blank lines and header lines containing
+        'product_id' skipped, kdd_data.py:70-71).  The file is mmapped; line splitting and decoding are native."""
+        import mmap
+        with open(path, "rb") as f:
+            size = os.fstat(f.fileno()).st_size
+            if size == 0:
+                return
+            with mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+                view = np.frombuffer(mm, np.uint8)
+                try:
+                    base, pos = view.ctypes.data, 0
+                    starts, ends = np.empty(batch_lines, np.int64), np.empty(batch_lines, np.int64)
+                    used = C.c_int64()
+                    while pos < size:
+                        n = self.lib.mmf_split_lines(base + pos, size - pos, starts.ctypes.data, ends.ctypes.data, batch_lines, C.byref(used))
+                        if n < 0:
+                            raise ValueError(self.lib.mmf_last_error().decode())
+                        if n:
+                            a = self._run(base + pos, view[pos:], starts[:n], ends[:n], sen2forest)
+                            yield self._layout(a) if layout else a
+                        pos += used.value
+                finally:
+                    del view                                     # release the exported buffer before the mmap closes
+
+    # ---- the three reference batch layouts (same keys / dtypes as featurizer.*_batch) ----
+    def batch(self, lines, sen2forest: bool = False) -> dict:
+        return self._layout(self.featurize(lines, sen2forest))
+
+    def _layout(self, a: dict) -> dict:
+        n, T = a["product_id"].shape[0], self.text_len
+        if self.model == "zk":
+            return {"num_boxes": a["num_boxes"], "np_boxes_5": a["boxes"], "np_images_features": a["feats"],
+                    "np_idx_class_labels": a["label_ids"], "np_idx_query_": a["query_ids"], "len_query_": a["query_len"],
+                    "labels": np.ones(n, np.int64), "segment_ids": np.tile(np.array([0] * T + [1] * N_BOX, np.int32), (n, 1)),
+                    "query_id": a["query_id"], "product_id": a["product_id"]}
+        if self.model == "lds":
+            return {"input_ids": a["query_ids"].astype(np.int64), "segment_ids": np.zeros((n, T), np.int64), "boxes": a["boxes"],
+                    "features": a["feats"], "labelfeat": a["label_ids"].astype(np.int64), "next_sentence_labels": np.zeros(n, np.int64),
+                    "query_id": a["query_id"], "product_id": a["product_id"]}
+        nb = np.minimum(a["num_boxes"], N_BOX)
+        lens = np.minimum(a["query_len"], T)
+        return {"input_ids": a["query_ids"].astype(np.int64), "boxes_label_input_ids": a["label_ids"].astype(np.int64),
+                "input_mask": (np.arange(T)[None, :] < lens[:, None]).astype(np.int64),
+                "boxes_label_input_mask": (np.arange(LABEL_LEN)[None, None, :] < np.minimum(a["label_len"], LABEL_LEN)[:, :, None]).astype(np.int64),
+                "feats": a["feats"], "boxes": a["boxes"],
+                "visual_attention_mask": (np.arange(N_BOX)[None, :] < nb[:, None]).astype(np.float32),
+                "query_id": a["query_id"], "product_id": a["product_id"]}
+
+    def close(self):
+        if self._h:
+            self.lib.mmf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

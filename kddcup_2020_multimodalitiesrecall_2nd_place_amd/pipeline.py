@@ -38,6 +38,24 @@ def predict_tsv(scorer, tsv_lines, label_table, tokenizer, out_path, sen2forest:
     return qid, pid, score
 
 
+def predict_tsv_native(scorer, tsv_path, vocab_path, label_table, out_path, sen2forest: bool = False, batch_pairs: int = 8192,
+                       threads: int = 0):
+    """``predict_tsv`` with the native featurizer (libmmfeat): the TSV file is streamed, decoded by a thread pool into
+    reused pinned buffers and scored batch by batch -- same scores, same written file."""
+    from .featurizer_native import NativeFeaturizer
+    nf = NativeFeaturizer(vocab_path, label_table, scorer.cfg.name, threads=threads, pinned=True, reuse_buffers=True)
+    qids, pids, scores = [], [], []
+    for b in nf.iter_file(tsv_path, batch_pairs, sen2forest):
+        qids.append(b["query_id"].copy())
+        pids.append(b["product_id"].copy())
+        _, probs = score_batch(scorer, b)                    # H2D copies finish inside (host arrays are reused next turn)
+        scores.append(probs[:, 1].float().cpu().numpy())
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+    qid, pid, score = cat(qids, np.int64), cat(pids, np.int64), cat(scores, np.float32)
+    (scorefile.write_score_csv if scorer.cfg.name == "lxmert" else scorefile.write_score_tsv)(out_path, qid, pid, score)
+    return qid, pid, score
+
+
 class EnsembleScorer:
     """BASELINE.json config 5 host side: the three models score the same pair shard on the same GPU and are merged
     pre-gather with main.py:59's weights, so the exchange step stays one fp32 per pair.
