@@ -49,6 +49,7 @@ struct mms_handle {
     std::vector<void*> w_allocs, ws_allocs, lab_allocs;
     bool finalized = false;
     int nsplit = 2;
+    int resid_in_ln = 1;   // residual add in the LayerNorm that follows (1, default) or in the GEMM epilogue (0; env MMS_RESID_IN_LN, A/B only)
     int x1_mask = 0;   // experiment (env MMS_X1_MASK): GEMM classes forced to one pass: 1 qkv, 2 att-out, 4 ffn-up, 8 ffn-down
     struct WPlane { const bf16* base; long long elems; };
     std::vector<WPlane> w_planes;   // precision 3: hi plane [base, base+elems), lo plane right behind it
@@ -434,7 +435,7 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     p.out_kind = out.f32 ? OUT_F32 : OUT_PLANES;
     p.c_f32 = out.f32; p.ldc = out.ldc;
     p.c_hi = out.pl.hi; p.c_lo = out.pl.lo; p.ldp = out.ldp; p.cmap = out.cmap;
-    if (resid) { p.r_hi = resid->hi; p.r_lo = resid->lo; p.ldr = H; }
+    if (resid && !h->resid_in_ln) { p.r_hi = resid->hi; p.r_lo = resid->lo; p.ldr = H; }
     p.m_dev = m_dev; p.a_index = a_index; p.rmap = rmap; p.r_index = r_index;
     if (h->timing) {
         if (h->ev_used + 2 > h->ev.size()) {
@@ -457,6 +458,15 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
 GemmOut to_f32(float* p, int ldc) { GemmOut o; o.f32 = p; o.ldc = ldc; return o; }
 GemmOut to_planes(Planes p, int ldp, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.pl = p; o.ldp = ldp; o.cmap = m; return o; }
 const RowMap ID{0, 0, 0};
+
+// LayerNorm closing a residual sub-layer: out = LN(t + resid).  The residual rides here (default) or was already added
+// by the producing GEMM's epilogue (h->resid_in_ln == 0); the arithmetic is the same fp32 (acc + bias) + resid either way.
+void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, const float* b, Planes out, int64_t M, const int* m_dev,
+              const Planes& resid, RowMap rmap = RowMap{0, 0, 0}, const int* r_index = nullptr) {
+    LnResid r;
+    if (h->resid_in_ln) { r.hi = resid.hi; r.lo = resid.lo; r.ld = H; r.rmap = rmap; r.r_index = r_index; }
+    launch_ln_to_planes(t, H, g, b, out.hi, out.lo, H, (int)M, st, m_dev, r);
+}
 
 // Packed-stream descriptor: per-pair first row / live count (relative to the stream's first row) and the
 // device-side number of live rows.  off == nullptr: dense layout (row of (b, s) = b * S + s).
@@ -481,7 +491,7 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     const Planes resid = in.at(row0 * H);
     if (int rc = gemm(h, st, h->ctx.at(row0 * H), H, ID, w.wo, w.bo, M, H, H, ACT_NONE,
                       to_f32(h->t + row0 * H, H), &resid, pk.rows, nullptr, ID, nullptr, 2)) return rc;
-    launch_ln_to_planes(h->t + row0 * H, H, w.g, w.b, out.hi + row0 * H, out.lo + row0 * H, H, (int)M, st, pk.rows);
+    ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
     return MMS_OK;
 }
 
@@ -492,7 +502,7 @@ int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes ou
     if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I), nullptr, pk.rows, nullptr, ID, nullptr, 4)) return rc;
     const Planes resid = in.at(row0 * H);
     if (int rc = gemm(h, st, h->mid, I, ID, w.wd, w.bd, M, H, I, ACT_NONE, to_f32(h->t + row0 * H, H), &resid, pk.rows, nullptr, ID, nullptr, 8)) return rc;
-    launch_ln_to_planes(h->t + row0 * H, H, w.g, w.b, out.hi + row0 * H, out.lo + row0 * H, H, (int)M, st, pk.rows);
+    ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
     return MMS_OK;
 }
 
@@ -516,11 +526,11 @@ int last_block_cls(mms_handle* h, hipStream_t st, const AttW& att, const FfnW& f
     a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo; a.ldo = H; a.B = (int)n;
     launch_attention(a, st);
     if (int rc = gemm(h, st, h->ctx, H, ID, att.wo, att.bo, n, H, H, ACT_NONE, to_f32(h->t, H), &in, nullptr, nullptr, cls, pk.off)) return rc;
-    launch_ln_to_planes(h->t, H, att.g, att.b, tmp.hi, tmp.lo, H, (int)n, st);
+    ln_resid(h, st, h->t, att.g, att.b, tmp, n, nullptr, in, cls, pk.off);
     const int I = h->cfg.inter;
     if (int rc = gemm(h, st, tmp, H, ID, ffn.wi, ffn.bi, n, I, H, act, to_planes(h->mid, I))) return rc;
     if (int rc = gemm(h, st, h->mid, I, ID, ffn.wd, ffn.bd, n, H, I, ACT_NONE, to_f32(h->t, H), &tmp)) return rc;
-    launch_ln_to_planes(h->t, H, ffn.g, ffn.b, in.hi, in.lo, H, (int)n, st);
+    ln_resid(h, st, h->t, ffn.g, ffn.b, in, n, nullptr, tmp);
     return MMS_OK;
 }
 
@@ -693,7 +703,7 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
             a.q_off = pl.off; a.q_cnt = pl.cnt; a.kv_off = pv.off; a.kv_cnt = pv.cnt;
             launch_attention(a, st);
             if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
-            launch_ln_to_planes(h->t, H, w.cross.g, w.cross.b, h->y.hi, h->y.lo, H, (int)ML, st, pl.rows);
+            ln_resid(h, st, h->t, w.cross.g, w.cross.b, h->y, ML, pl.rows, h->x);
             if (int rc = last_block_cls(h, st, w.lang_self, w.lang_ffn, ACT_GELU_ERF, h->y, h->x, T, n, lang_add, pl)) return rc;
             break;
         }
@@ -722,11 +732,11 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
             if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
             const Planes rv = h->x.at(ML * H);
             if (int rc = gemm(h, st, h->ctx.at(ML * H), H, ID, w.cross.wo, w.cross.bo, MV, H, H, ACT_NONE, to_f32(h->t + ML * H, H), &rv, pv.rows)) return rc;
-            launch_ln_to_planes(h->t, H, w.cross.g, w.cross.b, h->y.hi, h->y.lo, H, (int)ML, st, pl.rows);
-            launch_ln_to_planes(h->t + ML * H, H, w.cross.g, w.cross.b, h->y.hi + ML * H, h->y.lo + ML * H, H, (int)MV, st, pv.rows);
+            ln_resid(h, st, h->t, w.cross.g, w.cross.b, h->y, ML, pl.rows, h->x);
+            ln_resid(h, st, h->t + ML * H, w.cross.g, w.cross.b, h->y.at(ML * H), MV, pv.rows, rv);
         } else {
             if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, R, H, H, ACT_NONE, to_f32(h->t, H), &h->x)) return rc;
-            launch_ln_to_planes(h->t, H, w.cross.g, w.cross.b, h->y.hi, h->y.lo, H, (int)R, st);
+            ln_resid(h, st, h->t, w.cross.g, w.cross.b, h->y, R, nullptr, h->x);
         }
         // per-stream self attention (y -> x), then per-stream FFN (x -> x)
         if (int rc = att_block(h, st, w.lang_self, h->y, h->x, 0, T, n, lang_add, pl)) return rc;
@@ -778,6 +788,7 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
     h->cfg = *cfg;
     h->nsplit = cfg->precision;
     if (const char* e = getenv("MMS_X1_MASK")) h->x1_mask = atoi(e);
+    if (const char* e = getenv("MMS_RESID_IN_LN")) h->resid_in_ln = atoi(e);
     *out = h;
     return MMS_OK;
 }

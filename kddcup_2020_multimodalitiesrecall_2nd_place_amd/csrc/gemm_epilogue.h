@@ -4,6 +4,15 @@
 #pragma once
 #include "kernels.h"
 
+// Orders this wave's strip writes against its strip reads (and the reverse).  LDS operations of one wavefront execute in
+// order, so only the compiler has to be held back; NOT a wavefront-scope release fence: hipcc lowers that to
+// `s_waitcnt vmcnt(0) lgkmcnt(0)`, which made every 16-row strip wait for its global stores to be acknowledged (a
+// ~1 us round trip, 8-16 times per tile: measured 10-12 us of a 50 us tile, profiles/r01c_gemm_variants.txt).
+__device__ __forceinline__ void strip_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int ACT, int BM, int BN, int TM, int TN, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], unsigned char* smem, int bm, int bn,
                                               int wm, int wn, int wave, int lane, int Meff) {
@@ -16,20 +25,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     const int col = bn * BN + wn * TN + ec;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+    static_assert(ITERS == FN, "one float4 per lane per 16x16 fragment: the transposed tile reuses the accumulator registers");
+    // Pass 1: transpose every 16-row strip through LDS back INTO the accumulator registers (acc[i][t] then holds row
+    // t*ROWS_PER_IT + er, columns ec..ec+3 of strip i).  No global memory operation in this pass, so nothing makes the
+    // compiler wait on stores; every strip lands in registers of its own (a register reused for the next strip's
+    // ds_read made hipcc wait `vmcnt(0)` for the previous strip's stores: a store round trip per strip).
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) strip[(fk * 4 + r) * ES + j * 16 + fr] = acc[i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        strip_sync();
+#pragma unroll
+        for (int t = 0; t < ITERS; ++t) acc[i][t] = *reinterpret_cast<const f32x4*>(strip + (t * ROWS_PER_IT + er) * ES + ec);
+        strip_sync();
+    }
+    // Pass 2: bias / residual / activation / split and the global stores, back to back
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
 #pragma unroll
         for (int t = 0; t < ITERS; ++t) {
             const int lrow = t * ROWS_PER_IT + er;
             const int row = bm * BM + wm * TM + i * 16 + lrow;
-            f32x4 v = *reinterpret_cast<const f32x4*>(strip + lrow * ES + ec);
+            f32x4 v = acc[i][t];
             if (row < Meff) {
                 v += bias4;
                 if (p.r_hi) {
@@ -53,8 +72,5 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }

@@ -1,0 +1,254 @@
+// Ping-pong phase GEMM (gfx950): 256x256 workgroup tile, 8 wavefronts as 2(M) x 4(N), 128x64 outputs per wave
+// (half the LDS fragment bytes per MFMA of the 64x64-per-wave kernels), one workgroup per CU, 2 waves per SIMD.
+//
+// Same contract / epilogue as gemm_tile.hip (GemmParams: C = act(A W^T + bias (+ residual)), A in split planes).
+//
+// K is consumed in 32-wide STAGES.  A stage = A_hi [256][64 B] (+ A_lo) + W [256][64 B] (48 KiB at two passes), kept
+// in a 3-slot LDS ring filled by `global_load_lds_dwordx4` (LDS-DMA; the bank swizzle f(r) = {0,3,2,1}[(r>>2)&3] is
+// applied on the per-lane SOURCE address, fragment reads use the same involution: conflict-free ds_read_b128).
+// Each stage runs as 4 PHASES, one 64x32 quadrant of the wave's outputs per phase (16 MFMAs at two passes):
+//
+//     phase:   L: ds_read the fragments this phase needs (+ issue 2 LDS-DMA pieces of stage s+2)
+//              s_barrier ; s_waitcnt lgkmcnt(0)
+//              M: s_setprio 1 ; 16 x v_mfma_f32_16x16x32_bf16 ; s_setprio 0
+//              s_barrier
+//
+// The two wave rows (wm = 0 / 1; one wave of each per SIMD) run STAGGERED by one barrier, so on every SIMD one wave is
+// in its M section while the other is in its L section: the matrix pipe sees back-to-back MFMAs while LDS reads,
+// DMA issue and address math ride in the other wave's slots.  Quadrant order (A0,B0) (A0,B1) (A1,B1) (A1,B0) reuses
+// one register set per operand half: 10 / 2 / 8 / 0 ds_read_b128 per phase at two passes.
+//
+// DMA waits are COUNTED: stage s+2 is issued during phases 1-3 of stage s; phase 4 waits `vmcnt(pieces per stage)`
+// (= everything but the stage just issued), so one full stage stays in flight across every barrier.
+// RAW: the wait sits before phase 4's first barrier and the first read of that data is in the next phase (one
+// barrier later for the staggered wave row).  WAR: a slot is refilled >= 2 phases after its last ds_read.
+#include <type_traits>
+
+#include "kernels.h"
+#include "gemm_epilogue.h"
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+namespace {
+
+__device__ __forceinline__ int pp_swz(int r) { return (4 - ((r >> 2) & 3)) & 3; }
+
+template <int N> __device__ __forceinline__ void pp_wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else static_assert(N == 0, "unsupported count");
+}
+
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+}  // namespace
+
+// DIAG (timing diagnostics only, results WRONG): bit 0 drops the phase barriers, bit 1 the in-loop LDS-DMA issue, bit 2 the in-loop ds_reads,
+// bit 3 re-reads the first two K-stages (always cache hits)
+template <int NSPLIT, int ACT, int DIAG, int DIST>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 256, WAVES_N = 4, NW = 8, TM = 128, TN = 64, FM = 8, FN = 4;
+    constexpr int PLANE = 256 * 64;                 // one operand plane of a stage: 256 rows x 32 bf16
+    constexpr int SLOT = (NSPLIT + 1) * PLANE;
+    constexpr int NSLOT = 3;
+    constexpr int P = 2 * (NSPLIT + 1);             // LDS-DMA pieces per wave per stage (8 KiB = 128 rows per piece)
+    constexpr int EPI_BYTES = NW * 16 * (TN + 4) * 4;
+    static_assert(NSLOT * SLOT >= EPI_BYTES, "epilogue strip must fit in the ring");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * SLOT];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    int Meff = p.M;
+    if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
+    if (p.flop_counter && blockIdx.x == 0 && tid == 0)
+        atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
+    const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM, nblk = nbm * nbn;
+    int bid = blockIdx.x;
+    if (bid >= nblk) return;
+    {   // bijective XCD remap over the live workgroups
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int bm = bid / nbn, bn = bid % nbn;
+    const long long lo_delta = p.a_lo - p.a_hi;
+    // LDS-DMA sources: piece h (0/1) of an operand = rows h*128 + wave*16 + lane/4, 16-B chunk lane%4 (swizzled)
+    const int gr_l = lane >> 2, gc = lane & 3;
+    const bf16* a_src[2];
+    const bf16* w_src[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = h * 128 + wave * 16 + gr_l;
+        int gr = bm * BM + r;
+        gr = gr < Meff ? gr : Meff - 1;
+        a_src[h] = p.a_hi + (p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda + (gc ^ pp_swz(r)) * 8;
+        w_src[h] = p.w + (long long)(bn * BN + r) * p.K + (gc ^ pp_swz(r)) * 8;
+    }
+    // piece q of stage `st` into ring slot `slot`: q>>1 = operand (A planes first, then W), q&1 = row half
+    auto issue = [&](int q, int st, int slot) {
+        const int o = q >> 1, h = q & 1;
+        unsigned char* d = smem + slot * SLOT + o * PLANE + h * 8192 + wave * 1024;
+        const bf16* s = (o < NSPLIT ? a_src[h] + (o ? lo_delta : 0) : w_src[h]) + ((DIAG & 8) ? (st & 1) : st) * 32;   // DIAG 8: L2-resident source
+        __builtin_amdgcn_global_load_lds((glb_void*)s, (lds_void*)d, 16, 0, 0);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets inside a slot (lane part; the rest are immediates)
+    const int fr = lane & 15, fk = lane >> 4;
+    const int laneA = (wm * TM + fr) * 64 + ((fk ^ pp_swz(fr)) << 4);
+    const int laneB = NSPLIT * PLANE + (wn * TN + fr) * 64 + ((fk ^ pp_swz(fr)) << 4);
+
+    bf16x8 a[NSPLIT][4], b0[2], b1[2];
+    auto read_a = [&](const unsigned char* sb, int mh) {
+#pragma unroll
+        for (int pl = 0; pl < NSPLIT; ++pl)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(sb + laneA + pl * PLANE + (mh * 64 + i * 16) * 64);
+    };
+    auto read_b = [&](const unsigned char* sb, int nh, bf16x8 (&b)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + laneB + (nh * 32 + j * 16) * 64);
+    };
+    // M section: quadrant (mh, nh); hi-plane MFMAs first, then lo (dependent pairs 8 MFMAs apart)
+    auto mma = [&](int mh, int nh, const bf16x8 (&b)[2]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int pl = 0; pl < NSPLIT; ++pl)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pl][i], b[j], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int ns = p.K / 32;   // >= 2 (K % 64 == 0)
+    // PRE: stage s+2 exists and is issued during this stage; WAITN: outstanding pieces allowed at the phase-4 wait
+    auto stage = [&](auto pre_tag, auto wait_tag, int s, int slot) {
+        constexpr bool PRE = decltype(pre_tag)::value;
+        constexpr int WAITN = decltype(wait_tag)::value;
+        const unsigned char* sb = smem + slot * SLOT;
+        const int nslot = slot == 0 ? 2 : slot - 1;     // (slot + 2) % 3
+        constexpr bool DMA = PRE && !(DIAG & 2), RD = !(DIAG & 4);
+        auto bar = [&]() { if (DIAG & 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } else pp_barrier(); };
+        // LDS-DMA pieces of stage s+2 per phase (DIST selects the placement; a piece costs the issuing wave 60-180 cycles,
+        // least in phases that carry few ds_reads)
+        constexpr int D0[4] = {2, 2, 2, 0}, D1[4] = {0, 3, 0, 3}, D2[4] = {0, 0, 0, 6}, D3[4] = {0, 4, 0, 2}, DS[4] = {2, 2, 0, 0};
+        auto dma = [&](int ph) {
+            if (!DMA) return;
+            int q0 = 0, cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = P == 4 ? DS[k] : DIST == 0 ? D0[k] : DIST == 1 ? D1[k] : DIST == 2 ? D2[k] : D3[k];
+                if (k < ph) q0 += c;
+                if (k == ph) cnt = c;
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (q >= q0 && q < q0 + cnt) issue(q, s + 2, nslot);
+        };
+        // phase 1: (A0, B0)
+        if (RD) { read_b(sb, 0, b0); read_a(sb, 0); }
+        dma(0);
+        bar();
+        mma(0, 0, b0);
+        bar();
+        // phase 2: (A0, B1)
+        if (RD) read_b(sb, 1, b1);
+        dma(1);
+        bar();
+        mma(0, 1, b1);
+        bar();
+        // phase 3: (A1, B1)
+        if (RD) read_a(sb, 1);
+        dma(2);
+        bar();
+        mma(1, 1, b1);
+        bar();
+        // phase 4: (A1, B0); my pieces of stage s+1 have landed before the first barrier -> readable next phase
+        dma(3);
+        if (WAITN >= 0) pp_wait_vmcnt<(WAITN >= 0 && !(DIAG & 2) ? WAITN : 0)>();
+        bar();
+        mma(1, 0, b0);
+        bar();
+    };
+
+    // prologue: stages 0 and 1 in flight, stage 0 landed
+#pragma unroll
+    for (int q = 0; q < P; ++q) issue(q, 0, 0);
+#pragma unroll
+    for (int q = 0; q < P; ++q) issue(q, 1, 1);
+    pp_wait_vmcnt<P>();
+    pp_barrier();
+    if (wm == 1) pp_barrier();     // stagger the second wave row by one barrier
+
+    if (DIAG & 4) { read_b(smem, 0, b0); read_b(smem, 1, b1); read_a(smem, 0); }
+    int slot = 0, s = 0;
+    for (; s + 2 < ns; ++s) {
+        stage(std::true_type{}, std::integral_constant<int, P>{}, s, slot);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    stage(std::false_type{}, std::integral_constant<int, 0>{}, s, slot);          // stage ns-2: wait for everything
+    slot = slot == 2 ? 0 : slot + 1;
+    stage(std::false_type{}, std::integral_constant<int, -1>{}, s + 1, slot);     // stage ns-1: nothing in flight
+    if (wm == 0) pp_barrier();     // re-align the wave rows
+
+    if (DIAG & 16) {   // no epilogue (keep the accumulators live)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 12345.678f) p.c_f32[tid] = t;
+        return;
+    }
+    gemm_epilogue<ACT, BM, BN, TM, TN, FM, FN>(p, acc, smem, bm, bn, wm, wn, wave, lane, Meff);
+}
+
+template <int NSPLIT, int DIAG, int DIST = 0>
+static void launch_pp_ns(const GemmParams& p, hipStream_t st) {
+    const int nblk = ((p.M + 255) / 256) * (p.N / 256);
+    const dim3 grid(nblk), block(512);
+    switch (p.act) {
+        case ACT_RELU: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_RELU, DIAG, DIST>), grid, block, 0, st, p); break;
+        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_TANH, DIAG, DIST>), grid, block, 0, st, p); break;
+        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_ERF, DIAG, DIST>), grid, block, 0, st, p); break;
+        case ACT_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_TANH, DIAG, DIST>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_NONE, DIAG, DIST>), grid, block, 0, st, p); break;
+    }
+}
+
+bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, int dist) {
+    if (p.M <= 0) return true;
+    if (p.N % 256 || p.K % 64 || nsplit > 2) return false;
+    if (diag) {   // timing diagnostics (two-pass only)
+        if (nsplit != 2) return false;
+        switch (diag) {
+            case 1: launch_pp_ns<2, 1>(p, st); break; case 2: launch_pp_ns<2, 2>(p, st); break; case 3: launch_pp_ns<2, 3>(p, st); break;
+            case 4: launch_pp_ns<2, 4>(p, st); break; case 6: launch_pp_ns<2, 6>(p, st); break; case 7: launch_pp_ns<2, 7>(p, st); break;
+            case 8: launch_pp_ns<2, 8>(p, st); break; case 16: launch_pp_ns<2, 16>(p, st); break; case 23: launch_pp_ns<2, 23>(p, st); break;
+            default: return false;
+        }
+        return true;
+    }
+    if (nsplit == 2) {
+        switch (dist) { case 1: launch_pp_ns<2, 0, 1>(p, st); break; case 2: launch_pp_ns<2, 0, 2>(p, st); break;
+                        case 3: launch_pp_ns<2, 0, 3>(p, st); break; default: launch_pp_ns<2, 0, 0>(p, st); }
+    } else launch_pp_ns<1, 0>(p, st);
+    return true;
+}

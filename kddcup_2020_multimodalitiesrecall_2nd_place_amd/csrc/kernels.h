@@ -28,6 +28,7 @@ struct GemmParams {
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
 bool launch_gemm_ring(const GemmParams& p, int nsplit, int nslot, hipStream_t st);      // gemm_ring.hip (variants 11: 4 slots, 12: 2 slots)
+bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, int dist = 0);                     // gemm_pp.hip (variant 20: 256x256 ping-pong phases)
 void set_gemm_variant(int v);   // 0 = gemm.hip kernel, >0 = gemm_tile.hip configurations
 int get_gemm_variant();
 
@@ -53,8 +54,10 @@ void launch_attention(const AttnParams& p, hipStream_t st);
 // ---------------------------------------------------------------------------------------------
 // Row-wise kernels (one wavefront per 768-wide row)                   (rowops.hip)
 // ---------------------------------------------------------------------------------------------
+// optional residual of the LayerNorm input: row r adds planes row (r_index ? r_index[r] : rmap(r)) before normalising
+struct LnResid { const bf16* hi = nullptr; const bf16* lo = nullptr; int ld = 0; RowMap rmap{0, 0, 0}; const int* r_index = nullptr; };
 void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta,
-                         bf16* o_hi, bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev = nullptr);
+                         bf16* o_hi, bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev = nullptr, LnResid res = LnResid());
 void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipStream_t st);
 void launch_planes_to_f32(const bf16* hi, const bf16* lo, float* out, long long n, hipStream_t st);
 void launch_mean8(const float* in, float* out, int U, hipStream_t st);

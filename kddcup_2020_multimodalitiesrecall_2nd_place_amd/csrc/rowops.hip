@@ -87,19 +87,35 @@ static inline dim3 row_grid(long long rows) { return dim3((unsigned)((rows + ROW
 // ------------------------------------------------------------------------------------------------
 // generic
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void row_add_planes(Row& x, const bf16* hi, const bf16* lo) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(hi + t * 256 + lane_id() * 4);
+        const bf16x4 l = *reinterpret_cast<const bf16x4*>(lo + t * 256 + lane_id() * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x.v[t * 4 + e] += join_bf16(h[e], l[e]);
+    }
+}
+// out = LN(in (+ residual row)).  The residual add sits here rather than in the GEMM epilogue: this kernel streams whole
+// rows at full HBM rate, the epilogue's per-strip residual reads were a latency chain (profiles/r01c_gemm_variants.txt).
+// All of a row's reads precede its writes, so out may alias the residual planes row for row (ffn_block: x -> x).
 __global__ __launch_bounds__(256) void k_ln_to_planes(const float* in, int ld, const float* gamma,
                                                       const float* beta, bf16* o_hi, bf16* o_lo, int ldo, int M,
-                                                      const int* m_dev) {
+                                                      const int* m_dev, LnResid res) {
     const int row = wave_row();
     if (row >= M || (m_dev && row >= *m_dev)) return;
     Row x;
     row_load(x, in + (long long)row * ld);
+    if (res.hi) {
+        const long long ro = (res.r_index ? (long long)res.r_index[row] : res.rmap(row)) * (long long)res.ld;
+        row_add_planes(x, res.hi + ro, res.lo + ro);
+    }
     row_ln(x, gamma, beta);
     row_store_planes(x, o_hi + (long long)row * ldo, o_lo + (long long)row * ldo);
 }
 void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta, bf16* o_hi,
-                         bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev) {
-    if (M > 0) hipLaunchKernelGGL(k_ln_to_planes, row_grid(M), dim3(256), 0, st, in, ld, gamma, beta, o_hi, o_lo, ldo, M, m_dev);
+                         bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev, LnResid res) {
+    if (M > 0) hipLaunchKernelGGL(k_ln_to_planes, row_grid(M), dim3(256), 0, st, in, ld, gamma, beta, o_hi, o_lo, ldo, M, m_dev, res);
 }
 
 __global__ __launch_bounds__(256) void k_ln_f32(const float* in, const float* gamma, const float* beta,

@@ -10,13 +10,16 @@ from kddcup_2020_multimodalitiesrecall_2nd_place_amd import lib  # noqa: E402
 M = int(os.environ.get("GB_M", 122880))
 SHAPES = [  # name, N, K, act, planes, resid
     ("qkv", 2304, 768, 0, 0, 0),
-    ("attout", 768, 768, 0, 0, 1),
+    ("attout", 768, 768, 0, 0, int(os.environ.get("GB_RESID", 0))),   # residual add now lives in the LayerNorm
     ("ffn_up", 3072, 768, 2, 1, 0),
-    ("ffn_down", 768, 3072, 0, 0, 1),
+    ("ffn_down", 768, 3072, 0, 0, int(os.environ.get("GB_RESID", 0))),
 ]
+if os.environ.get("GB_SHAPES"):   # "name,N,K,act,planes,resid;..."
+    SHAPES = [(f[0],) + tuple(int(x) for x in f[1:]) for f in (t.split(",") for t in os.environ["GB_SHAPES"].split(";"))]
+NSPLITS = [int(x) for x in os.environ.get("GB_NSPLIT", "2,1").split(",")]
 l = lib.load()
 variants = [int(v) for v in sys.argv[1:]] or [0, 1, 3, 4, 11, 12]
-for nsplit in (2, 1):
+for nsplit in NSPLITS:
     for name, N, K, act, planes, resid in SHAPES:
         row = []
         for v in variants:
