@@ -168,7 +168,7 @@ def main():
             # kernels EXECUTE fewer FLOPs than that (padded tokens are skipped), so this is an equivalent rate, not
             # a utilisation; roofline.achieved below counts executed FLOPs only.
             "reference_graph_tflops_per_gpu": round(value / world * fpp / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_tile_kernel<%d,*,128,256,2,4,0> (all dense contractions)" % a.precision,
+            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<%d,*> 256x256 ping-pong phases (all dense contractions; small GEMMs: gemm_tile_kernel)" % min(a.precision, 2),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches": int(gemm_n), "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
