@@ -13,11 +13,12 @@ __device__ __forceinline__ void strip_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int ACT, int BM, int BN, int TM, int TN, int FM, int FN>
+// SYNC = false: the caller guarantees that no wave still reads the bytes behind `smem` (persistent kernel: a free ring slot)
+template <int ACT, int BM, int BN, int TM, int TN, int FM, int FN, bool SYNC = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], unsigned char* smem, int bm, int bn,
                                               int wm, int wn, int wave, int lane, int Meff) {
     const int fr = lane & 15, fk = lane >> 4;
-    __syncthreads();  // all waves are done reading operand tiles
+    if (SYNC) __syncthreads();  // all waves are done reading operand tiles
     constexpr int ES = TN + 4;                      // strip row stride in floats
     float* strip = reinterpret_cast<float*>(smem) + wave * 16 * ES;
     constexpr int V4_PER_ROW = TN / 4, ROWS_PER_IT = 64 / V4_PER_ROW, ITERS = 16 / ROWS_PER_IT;

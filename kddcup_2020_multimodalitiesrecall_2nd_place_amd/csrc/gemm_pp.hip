@@ -53,7 +53,7 @@ __device__ __forceinline__ void pp_barrier() {
 
 // DIAG (timing diagnostics only, results WRONG): bit 0 drops the phase barriers, bit 1 the in-loop LDS-DMA issue, bit 2 the in-loop ds_reads,
 // bit 3 re-reads the first two K-stages (always cache hits)
-template <int NSPLIT, int ACT, int DIAG, int DIST>
+template <int NSPLIT, int ACT, int DIAG>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 256, WAVES_N = 4, NW = 8, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int PLANE = 256 * 64;                 // one operand plane of a stage: 256 rows x 32 bf16
@@ -146,21 +146,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         const int nslot = slot == 0 ? 2 : slot - 1;     // (slot + 2) % 3
         constexpr bool DMA = PRE && !(DIAG & 2), RD = !(DIAG & 4);
         auto bar = [&]() { if (DIAG & 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } else pp_barrier(); };
-        // LDS-DMA pieces of stage s+2 per phase (DIST selects the placement; a piece costs the issuing wave 60-180 cycles,
-        // least in phases that carry few ds_reads)
-        constexpr int D0[4] = {2, 2, 2, 0}, D1[4] = {0, 3, 0, 3}, D2[4] = {0, 0, 0, 6}, D3[4] = {0, 4, 0, 2}, DS[4] = {2, 2, 0, 0};
+        // LDS-DMA pieces of stage s+2: two per phase in phases 1-3 (other placements measured no better, profiles/r01c_gemm_variants.txt)
         auto dma = [&](int ph) {
             if (!DMA) return;
-            int q0 = 0, cnt = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = P == 4 ? DS[k] : DIST == 0 ? D0[k] : DIST == 1 ? D1[k] : DIST == 2 ? D2[k] : D3[k];
-                if (k < ph) q0 += c;
-                if (k == ph) cnt = c;
-            }
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-                if (q >= q0 && q < q0 + cnt) issue(q, s + 2, nslot);
+            for (int q = 0; q < P; ++q)
+                if (q / 2 == ph) issue(q, s + 2, nslot);
         };
         // phase 1: (A0, B0)
         if (RD) { read_b(sb, 0, b0); read_a(sb, 0); }
@@ -220,20 +211,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     gemm_epilogue<ACT, BM, BN, TM, TN, FM, FN>(p, acc, smem, bm, bn, wm, wn, wave, lane, Meff);
 }
 
-template <int NSPLIT, int DIAG, int DIST = 0>
+template <int NSPLIT, int DIAG>
 static void launch_pp_ns(const GemmParams& p, hipStream_t st) {
     const int nblk = ((p.M + 255) / 256) * (p.N / 256);
     const dim3 grid(nblk), block(512);
     switch (p.act) {
-        case ACT_RELU: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_RELU, DIAG, DIST>), grid, block, 0, st, p); break;
-        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_TANH, DIAG, DIST>), grid, block, 0, st, p); break;
-        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_ERF, DIAG, DIST>), grid, block, 0, st, p); break;
-        case ACT_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_TANH, DIAG, DIST>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_NONE, DIAG, DIST>), grid, block, 0, st, p); break;
+        case ACT_RELU: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_RELU, DIAG>), grid, block, 0, st, p); break;
+        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_TANH, DIAG>), grid, block, 0, st, p); break;
+        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_ERF, DIAG>), grid, block, 0, st, p); break;
+        case ACT_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_TANH, DIAG>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_NONE, DIAG>), grid, block, 0, st, p); break;
     }
 }
 
-bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, int dist) {
+bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st) {
     if (p.M <= 0) return true;
     if (p.N % 256 || p.K % 64 || nsplit > 2) return false;
     if (diag) {   // timing diagnostics (two-pass only)
@@ -246,9 +237,6 @@ bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, i
         }
         return true;
     }
-    if (nsplit == 2) {
-        switch (dist) { case 1: launch_pp_ns<2, 0, 1>(p, st); break; case 2: launch_pp_ns<2, 0, 2>(p, st); break;
-                        case 3: launch_pp_ns<2, 0, 3>(p, st); break; default: launch_pp_ns<2, 0, 0>(p, st); }
-    } else launch_pp_ns<1, 0>(p, st);
+    if (nsplit == 2) launch_pp_ns<2, 0>(p, st); else launch_pp_ns<1, 0>(p, st);
     return true;
 }

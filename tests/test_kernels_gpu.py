@@ -42,7 +42,7 @@ GEMM_CASES = [
 ]
 
 
-GEMM_VARIANTS = [0, 1, 3, 4, 11, 12, 16, 20, 21, 22, 23, 99]
+GEMM_VARIANTS = [0, 1, 3, 4, 11, 12, 16, 20, 99]
 
 
 @pytest.fixture
