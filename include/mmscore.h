@@ -58,7 +58,7 @@ typedef struct mms_config {
     int32_t precision;        /* 1: bf16 activations, one MFMA pass; 2: split-bf16 activations (hi+lo), two passes, GEMM
                                  weights stored as bf16; 3: activations AND weights split (three passes): follows an
                                  arbitrary fp32 checkpoint to ~2e-5 */
-    int32_t chunk_pairs;      /* pairs per internal launch wave (0 = default 8192) */
+    int32_t chunk_pairs;      /* max pairs per internal launch wave (0 = default 32768); a batch is cut into equal chunks */
     int32_t stop_after;       /* debug: run only the first n encoder layers (-1 = all) and skip nothing else */
     int32_t device;           /* HIP device ordinal */
     int32_t pack_tokens;      /* zk/lxmert: 1 = drop padded tokens whose keys are masked (identical logits: a masked

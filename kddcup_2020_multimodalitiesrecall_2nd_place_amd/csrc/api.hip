@@ -753,9 +753,13 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
     return MMS_OK;
 }
 
+// Pairs per launch wave: at most chunk_pairs (default 32768: the 256-row GEMM tiles then run >= 25 full rounds over the
+// 256 CUs per launch, +2.4 % zk / +4.8 % lxmert over 8192, profiles/r01c_gemm_variants.txt), and equal-sized chunks so that
+// no launch wave is a short tail (B = 40000 -> 2 x 20000, not 32768 + 7232).  The workspace is sized for one chunk.
 int chunk_size(const mms_handle* h, int64_t B) {
-    int64_t c = h->cfg.chunk_pairs > 0 ? h->cfg.chunk_pairs : 8192;
-    return (int)(B < c ? B : c);
+    const int64_t c = h->cfg.chunk_pairs > 0 ? h->cfg.chunk_pairs : 32768;
+    const int64_t n = (B + c - 1) / c;
+    return (int)(n <= 1 ? B : (B + n - 1) / n);
 }
 
 }  // namespace
