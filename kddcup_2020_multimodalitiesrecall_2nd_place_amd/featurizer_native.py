@@ -63,12 +63,13 @@ class NativeFeaturizer:
     """model: 'zk' | 'lds' | 'lxmert' (box_dim, text_len, tokenizer flavour follow the sub-project)."""
 
     def __init__(self, vocab_path: str, label_table: dict, model: str = "zk", threads: int = 0, pinned: bool = False,
-                 reuse_buffers: bool = False):
-        """reuse_buffers: keep one (pinned) set of output buffers, grown on demand -- the returned arrays are then views
-        that the NEXT call overwrites (streaming use: featurize -> H2D copy -> featurize ...).  Page-faulting fresh
-        336 KB/row buffers costs more than the decode itself, so the streaming drivers turn this on."""
+                 reuse_buffers: bool = False, pools: int = 1):
+        """reuse_buffers: keep ``pools`` (pinned) sets of output buffers, grown on demand and used round-robin -- the
+        returned arrays are then views that the ``pools``-th following call overwrites (streaming use: featurize ->
+        H2D copy -> featurize ...).  Page-faulting fresh 336 KB/row buffers costs more than the decode itself, so the
+        streaming drivers turn this on."""
         self.lib = load()
-        self.reuse, self._cap, self._pool = reuse_buffers, 0, None
+        self.reuse, self._caps, self._pools, self._turn = reuse_buffers, [0] * pools, [None] * pools, 0
         self.model = model
         self.text_len = 23 if model == "lxmert" else 20
         self.box_dim = 4 if model == "lxmert" else 5
@@ -102,10 +103,12 @@ class NativeFeaturizer:
         if not self.reuse:
             pairs = {k: _host(shape, dt, self.pinned and n > 0) for k, (shape, dt) in self._spec(n).items()}
             return {k: v[0] for k, v in pairs.items()}, {k: v[1] for k, v in pairs.items()}
-        if n > self._cap:
-            self._cap = max(n, 2 * self._cap)
-            self._pool = {k: _host(shape, dt, self.pinned) for k, (shape, dt) in self._spec(self._cap).items()}
-        return {k: v[0][:n] for k, v in self._pool.items()}, {k: v[1] for k, v in self._pool.items()}
+        t = self._turn
+        self._turn = (t + 1) % len(self._pools)
+        if n > self._caps[t]:
+            self._caps[t] = max(n, 2 * self._caps[t])
+            self._pools[t] = {k: _host(shape, dt, self.pinned) for k, (shape, dt) in self._spec(self._caps[t]).items()}
+        return {k: v[0][:n] for k, v in self._pools[t].items()}, {k: v[1] for k, v in self._pools[t].items()}
 
     def featurize(self, lines, sen2forest: bool = False) -> dict:
         """lines: iterable of TSV records (str or bytes).  Returns the raw padded arrays (+ ``keep`` = pinned owners)."""

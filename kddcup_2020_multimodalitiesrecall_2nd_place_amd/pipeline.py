@@ -38,20 +38,62 @@ def predict_tsv(scorer, tsv_lines, label_table, tokenizer, out_path, sen2forest:
     return qid, pid, score
 
 
-def predict_tsv_native(scorer, tsv_path, vocab_path, label_table, out_path, sen2forest: bool = False, batch_pairs: int = 8192,
-                       threads: int = 0):
-    """``predict_tsv`` with the native featurizer (libmmfeat): the TSV file is streamed, decoded by a thread pool into
-    reused pinned buffers and scored batch by batch -- same scores, same written file."""
+def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: bool = False, batch_pairs: int = 32768, threads: int = 0):
+    """TSV file -> (query_id, product_id, score) with the three stages overlapped:
+
+      producer thread   libmmfeat decodes batch i+2 into one of three pinned buffer sets (ctypes releases the GIL)
+      copy stream       H2D of batch i+1 (pinned -> device, waited for on the host, which then frees that buffer set)
+      main stream       the scorer's kernels for batch i (asynchronous; nothing on the host waits for them until the end)
+    """
+    import queue
+    import threading
+
+    import torch
+
     from .featurizer_native import NativeFeaturizer
-    nf = NativeFeaturizer(vocab_path, label_table, scorer.cfg.name, threads=threads, pinned=True, reuse_buffers=True)
+    nf = NativeFeaturizer(vocab_path, label_table, scorer.cfg.name, threads=threads, pinned=True, reuse_buffers=True, pools=3)
+    dev = scorer.device
+    q = queue.Queue(maxsize=1)           # one decoded batch waiting + one being decoded + one being copied = 3 pools
+
+    def produce():
+        try:
+            for b in nf.iter_file(tsv_path, batch_pairs, sen2forest):
+                q.put(b)
+            q.put(None)
+        except BaseException as e:       # surfaced in the consumer
+            q.put(e)
+
+    th = threading.Thread(target=produce, daemon=True)
+    th.start()
+    copy_stream = torch.cuda.Stream(dev)
     qids, pids, scores = [], [], []
-    for b in nf.iter_file(tsv_path, batch_pairs, sen2forest):
+    while True:
+        b = q.get()
+        if b is None:
+            break
+        if isinstance(b, BaseException):
+            raise b
         qids.append(b["query_id"].copy())
         pids.append(b["product_id"].copy())
-        _, probs = score_batch(scorer, b)                    # H2D copies finish inside (host arrays are reused next turn)
-        scores.append(probs[:, 1].float().cpu().numpy())
+        with torch.cuda.stream(copy_stream):
+            d = {k: (torch.from_numpy(v).to(dev, non_blocking=True) if isinstance(v, np.ndarray) and v.dtype.kind in "fiu" else v)
+                 for k, v in b.items() if k not in ("query_id", "product_id", "keep")}
+        copy_stream.synchronize()        # the pinned set may be refilled from here on; the main stream is still busy with batch i
+        _, probs = score_batch(scorer, d)
+        for t in d.values():             # allocated on the copy stream, consumed on the main one: defer reuse of the memory
+            if torch.is_tensor(t):
+                t.record_stream(torch.cuda.current_stream(dev))
+        scores.append(probs[:, 1])
+    th.join()
     cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
-    qid, pid, score = cat(qids, np.int64), cat(pids, np.int64), cat(scores, np.float32)
+    score = torch.cat(scores).float().cpu().numpy() if scores else np.zeros(0, np.float32)
+    return cat(qids, np.int64), cat(pids, np.int64), score
+
+
+def predict_tsv_native(scorer, tsv_path, vocab_path, label_table, out_path, sen2forest: bool = False, batch_pairs: int = 32768,
+                       threads: int = 0):
+    """``predict_tsv`` with the native featurizer (libmmfeat), decode / H2D / scoring overlapped -- same scores, same file."""
+    qid, pid, score = stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest, batch_pairs, threads)
     (scorefile.write_score_csv if scorer.cfg.name == "lxmert" else scorefile.write_score_tsv)(out_path, qid, pid, score)
     return qid, pid, score
 
