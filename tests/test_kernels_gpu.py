@@ -39,6 +39,8 @@ GEMM_CASES = [
     (33, 768, 1536, lib.ACT_GELU_ERF, False, False),   # logit_fc.0
     (5, 768, 768, lib.ACT_TANH, False, True),          # pooler, tiny M
     (1000, 6144, 768, lib.ACT_RELU, False, False),     # kdd_conv1 im2col
+    (520, 64, 256, lib.ACT_NONE, False, False),        # shortest K (two 32-wide stages), three row tiles
+    (700, 128, 512, lib.ACT_GELU_ERF, False, True),    # four stages: one full ring turn + tail
 ]
 
 
