@@ -27,10 +27,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
     static_assert(ITERS == FN, "one float4 per lane per 16x16 fragment: the transposed tile reuses the accumulator registers");
-    // Pass 1: transpose every 16-row strip through LDS back INTO the accumulator registers (acc[i][t] then holds row
-    // t*ROWS_PER_IT + er, columns ec..ec+3 of strip i).  No global memory operation in this pass, so nothing makes the
-    // compiler wait on stores; every strip lands in registers of its own (a register reused for the next strip's
-    // ds_read made hipcc wait `vmcnt(0)` for the previous strip's stores: a store round trip per strip).
+    // Per 16-row strip: transpose it through the wave's LDS strip back INTO its own accumulator registers (acc[i][t] then
+    // holds row t*ROWS_PER_IT + er, columns ec..ec+3), then bias / residual / activation / split and the global stores.
+    // Every strip lives in registers of its own, so the next strip's ds_reads never target a register a pending store
+    // still has to read (that hazard made hipcc wait `vmcnt(0)` -- a store round trip -- per strip), and the stores of
+    // strip i drain while strip i+1 is being transposed.
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -41,10 +42,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
         for (int t = 0; t < ITERS; ++t) acc[i][t] = *reinterpret_cast<const f32x4*>(strip + (t * ROWS_PER_IT + er) * ES + ec);
         strip_sync();
-    }
-    // Pass 2: bias / residual / activation / split and the global stores, back to back
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
 #pragma unroll
         for (int t = 0; t < ITERS; ++t) {
             const int lrow = t * ROWS_PER_IT + er;
