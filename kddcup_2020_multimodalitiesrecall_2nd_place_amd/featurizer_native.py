@@ -121,10 +121,10 @@ class NativeFeaturizer:
         """record i = data[offsets[i]:offsets[i+1]] (``data``: bytes)."""
         offsets = np.ascontiguousarray(offsets, np.int64)
         keep = np.frombuffer(data, np.uint8)
-        return self._run(keep.ctypes.data if keep.size else None, keep, offsets[:-1], offsets[1:], sen2forest)
+        return self._run(keep.ctypes.data if keep.size else None, lambda a, b: bytes(data[a:b]), offsets[:-1], offsets[1:], sen2forest)
 
-    def _run(self, base, view, starts, ends, sen2forest):
-        """base: address of the byte buffer; view: uint8 array over it (for the host-tokenizer fallback)."""
+    def _run(self, base, getbytes, starts, ends, sen2forest):
+        """base: address of the byte buffer; getbytes(a, b): bytes [a, b) of it (for the host-tokenizer fallback)."""
         starts, ends = np.ascontiguousarray(starts, np.int64), np.ascontiguousarray(ends, np.int64)
         n, T = len(starts), self.text_len
         arr, keep = self._buffers(n)
@@ -136,7 +136,7 @@ class NativeFeaturizer:
             if rc != 0:
                 raise ValueError("mmf_featurize failed (%d): %s" % (rc, self.lib.mmf_last_error().decode()))
         for i in np.nonzero(arr["needs_host_tokenizer"])[0]:      # non-ASCII queries: full Unicode tokenizer
-            q = view[arr["query_span"][i, 0]:arr["query_span"][i, 1]].tobytes().decode("utf-8")
+            q = getbytes(int(arr["query_span"][i, 0]), int(arr["query_span"][i, 1])).decode("utf-8")
             if sen2forest:
                 q = q.replace("sen department of", "forest style")
             ids = self.py_tok.encode_query(q)
@@ -146,9 +146,10 @@ class NativeFeaturizer:
         arr["keep"] = keep
         return arr
 
-    def iter_file(self, path: str, batch_lines: int = 8192, sen2forest: bool = False, layout: bool = True):
-        """Stream a TSV file: yields one batch dict per ``batch_lines`` records (blank lines and header lines containing
-        'product_id' skipped, kdd_data.py:70-71).  The file is mmapped; line splitting and decoding are native."""
+    def iter_spans(self, path: str, batch_lines: int = 8192):
+        """Stream a TSV file as record spans: yields (base address, getbytes, starts, ends) per ``batch_lines`` records
+        (blank lines and header lines containing 'product_id' skipped, kdd_data.py:70-71).  The file is mmapped and the line
+        splitting is native; the spans stay valid until the generator is advanced."""
         import mmap
         with open(path, "rb") as f:
             size = os.fstat(f.fileno()).st_size
@@ -165,11 +166,16 @@ class NativeFeaturizer:
                         if n < 0:
                             raise ValueError(self.lib.mmf_last_error().decode())
                         if n:
-                            a = self._run(base + pos, view[pos:], starts[:n], ends[:n], sen2forest)
-                            yield self._layout(a) if layout else a
+                            yield base + pos, (lambda a, b, p0=pos: mm[p0 + a:p0 + b]), starts[:n], ends[:n]
                         pos += used.value
                 finally:
                     del view                                     # release the exported buffer before the mmap closes
+
+    def iter_file(self, path: str, batch_lines: int = 8192, sen2forest: bool = False, layout: bool = True):
+        """Stream a TSV file: yields one batch dict per ``batch_lines`` records (see ``iter_spans``)."""
+        for base, getbytes, starts, ends in self.iter_spans(path, batch_lines):
+            a = self._run(base, getbytes, starts, ends, sen2forest)
+            yield self._layout(a) if layout else a
 
     # ---- the three reference batch layouts (same keys / dtypes as featurizer.*_batch) ----
     def batch(self, lines, sen2forest: bool = False) -> dict:

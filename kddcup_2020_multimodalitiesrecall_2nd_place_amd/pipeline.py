@@ -125,3 +125,25 @@ class EnsembleScorer:
         w = self.WEIGHTS
         merged = w[0] * s1.astype(np.float64) + w[1] * s2 + w[2] * s3 + w[3] * s4
         return qid, pid, merged, (s1, s2, s3, s4)
+
+    def score_tsv_native(self, tsv_path, vocab_path, label_table, batch_pairs: int = 16384, threads: int = 0):
+        """``score_lines`` on a TSV file through libmmfeat: every span batch is decoded three times (zk flavour, zk with the
+        sen2forest rewrite, lxmert flavour -- the lds feed is the zk one with int64 ids) and scored by the four passes."""
+        from .featurizer_native import NativeFeaturizer
+        mk = lambda m: NativeFeaturizer(vocab_path, label_table, m, threads=threads, pinned=True, reuse_buffers=True)
+        nf_zk, nf_s2f, nf_lx = mk("zk"), mk("zk"), mk("lxmert")
+        nf_lds = mk("lds")                                    # layout only: re-labels the zk arrays
+        qids, pids, parts = [], [], [[], [], [], []]
+        for base, getbytes, starts, ends in nf_zk.iter_spans(tsv_path, batch_pairs):
+            a = nf_zk._run(base, getbytes, starts, ends, False)
+            qids.append(a["query_id"].copy())
+            pids.append(a["product_id"].copy())
+            feeds = (nf_zk._layout(a), nf_s2f._layout(nf_s2f._run(base, getbytes, starts, ends, True)), nf_lds._layout(a),
+                     nf_lx._layout(nf_lx._run(base, getbytes, starts, ends, False)))
+            for k, (sc, feed) in enumerate(zip((self.zk, self.zk, self.lds, self.lxmert), feeds)):
+                parts[k].append(score_batch(sc, feed)[1][:, 1].float().cpu().numpy())
+        cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+        s1, s2, s3, s4 = (cat(x, np.float32) for x in parts)
+        w = self.WEIGHTS
+        merged = w[0] * s1.astype(np.float64) + w[1] * s2 + w[2] * s3 + w[3] * s4
+        return cat(qids, np.int64), cat(pids, np.int64), merged, (s1, s2, s3, s4)

@@ -364,6 +364,14 @@ def test_three_model_ensemble_on_one_gpu():
     sc = {n: scorers.make_scorer(cfgs[n], ws[n]) for n in cfgs}
     ens = pipeline.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
     qid, pid, merged, parts = ens.score_lines(lines, table, tok_tf, tok_hf, batch_pairs=4)
+    # the native-featurizer route over the same records as a TSV file (header + blank line): same merged scores
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False, encoding="utf-8") as f:
+        f.write("product_id\tx\n" + "\n\n".join(lines) + "\n")
+    q2, p2, merged2, parts2 = ens.score_tsv_native(f.name, os.path.join(d, "vocab_small.txt"), table, batch_pairs=2)
+    os.remove(f.name)
+    assert np.array_equal(q2, qid) and np.array_equal(p2, pid)
+    assert np.abs(merged2 - merged).max() < 1e-5 and all(np.abs(x - y).max() < 1e-5 for x, y in zip(parts, parts2))
     for s_ in sc.values():
         s_.close()
     rec = [F.read_line(l, table, tok_tf) for l in lines]

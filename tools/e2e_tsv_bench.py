@@ -33,6 +33,25 @@ with open(path, "w") as f:
         f.write(F.encode_record(i, h, w, boxes, feats_pool[i % 64, :nb], rng.choice(classes, nb), " ".join(rng.choice(words, int(rng.integers(2, 9)))), i // 30) + "\n")
 print("wrote %s: %.2f GB in %.0f s" % (path, os.path.getsize(path) / 1e9, time.time() - t0), flush=True)
 
+if name == "ensemble":      # BASELINE.json config 5: TSV -> four score tables -> merge -> uniqueness filter -> top-5 submission
+    from collections import OrderedDict
+    from kddcup_2020_multimodalitiesrecall_2nd_place_amd import ensemble as E
+    sc = {m: scorers.make_scorer(c, weights.make_weights(c), device=0) for m, c in (("zk", ZkConfig()), ("lds", LdsConfig()), ("lxmert", LxmertConfig()))}
+    ens = pipeline.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.time()
+        qid, pid, merged, parts = ens.score_tsv_native(path, VOCAB, TABLE, batch_pairs=16384)
+        t1 = time.time()
+        tab = OrderedDict()
+        for q, p_, m_ in zip(qid, pid, merged):
+            tab.setdefault(str(int(q)), OrderedDict())[str(int(p_))] = float(m_)
+        rows = E.top5(tab, E.uniqueness_filter(tab))
+        E.write_submission("/tmp/e2e_submission.csv", rows)
+        dt = time.time() - t0
+    print("TSV -> 4 score tables -> submission.csv: %.0f pairs/s end to end (%d pairs, %d queries; scoring %.2f s, post-process %.2f s)"
+          % (len(merged) / dt, len(merged), len(rows), t1 - t0, dt - (t1 - t0)), flush=True)
+    os.remove(path)
+    sys.exit(0)
 cfg = {"zk": ZkConfig(), "lds": LdsConfig(), "lxmert": LxmertConfig()}[name]
 sc = scorers.make_scorer(cfg, weights.make_weights(cfg), device=0)
 nf = NativeFeaturizer(VOCAB, TABLE, name, pinned=True, reuse_buffers=True)
