@@ -182,7 +182,7 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     }
     if (variant == 0 && (p.m_dev || p.flop_counter)) variant = 1;   // the v0 kernel has no device-side row count
     if (variant == 20) { if (launch_gemm_pp(p, nsplit, 0, st)) return; variant = 4; }
-    if (variant > 200 && variant < 232 && launch_gemm_pp(p, nsplit, variant - 200, st)) return;   // timing diagnostics
+    if (variant > 200 && variant < 233 && launch_gemm_pp(p, nsplit, variant - 200, st)) return;   // timing diagnostics
     if (variant == 11 && launch_gemm_ring(p, nsplit, 4, st)) return;
     if (variant == 12 && launch_gemm_ring(p, nsplit, 2, st)) return;
     if (variant >= 101 && variant <= 103 && launch_gemm_ring(p, nsplit, variant, st)) return;   // timing diagnostics

@@ -22,10 +22,12 @@
 // (= everything but the stage just issued), so one full stage stays in flight across every barrier.
 // RAW: the wait sits before phase 4's first barrier and the first read of that data is in the next phase (one
 // barrier later for the staggered wave row).  WAR: a slot is refilled >= 2 phases after its last ds_read.
+#include <cstdio>
 #include <type_traits>
+#include <vector>
 
 #include "kernels.h"
-#include "gemm_epilogue.h"
+#include "gemm_pp_epilogue.h"
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -68,9 +70,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+    const unsigned long long tr0 = (DIAG & 32) ? wall_clock64() : 0;      // DIAG 32: per-workgroup timeline (100 MHz ticks) into p.flop_counter
     int Meff = p.M;
     if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
-    if (p.flop_counter && blockIdx.x == 0 && tid == 0)
+    if (!(DIAG & 32) && p.flop_counter && blockIdx.x == 0 && tid == 0)
         atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
     const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM, nblk = nbm * nbn;
     int bid = blockIdx.x;
@@ -123,7 +126,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + laneB + (nh * 32 + j * 16) * 64);
     };
-    // M section: quadrant (mh, nh); hi-plane MFMAs first, then lo (dependent pairs 8 MFMAs apart)
+    // M section: quadrant (mh, nh); hi-plane MFMAs first, then lo (dependent pairs 8 MFMAs apart).  The operands are SWAPPED
+    // (W fragment first): each 16x16 result then sits transposed in the lane -- lane l holds row l&15, columns 4*(l>>4)..+3 --
+    // so the epilogue stores float4s straight from the accumulators, no LDS transposition (pp_epilogue below).
     auto mma = [&](int mh, int nh, const bf16x8 (&b)[2]) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pl][i], b[j], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[pl][i], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);   // swapped: C^T fragment
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     pp_wait_vmcnt<P>();
     pp_barrier();
     if (wm == 1) pp_barrier();     // stagger the second wave row by one barrier
+    const unsigned long long tr1 = (DIAG & 32) ? wall_clock64() : 0;
 
     if (DIAG & 4) { read_b(smem, 0, b0); read_b(smem, 1, b1); read_a(smem, 0); }
     int slot = 0, s = 0;
@@ -198,6 +204,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     slot = slot == 2 ? 0 : slot + 1;
     stage(std::false_type{}, std::integral_constant<int, -1>{}, s + 1, slot);     // stage ns-1: nothing in flight
     if (wm == 0) pp_barrier();     // re-align the wave rows
+    const unsigned long long tr2 = (DIAG & 32) ? wall_clock64() : 0;
 
     if (DIAG & 16) {   // no epilogue (keep the accumulators live)
         float t = 0.f;
@@ -208,7 +215,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         if (t == 12345.678f) p.c_f32[tid] = t;
         return;
     }
-    gemm_epilogue<ACT, BM, BN, TM, TN, FM, FN>(p, acc, smem, bm, bn, wm, wn, wave, lane, Meff);
+    pp_epilogue<ACT, FM, FN>(p, acc, bm * BM + wm * TM, bn * BN + wn * TN, lane, Meff);
+    if ((DIAG & 32) && tid == 0 && p.flop_counter) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // epilogue stores acknowledged
+        unsigned long long* t = p.flop_counter + 5ull * blockIdx.x;
+        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = wall_clock64(); t[4] = ((unsigned long long)bm << 32) | (unsigned)bn;
+    }
 }
 
 template <int NSPLIT, int DIAG>
@@ -232,6 +244,20 @@ bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st) {
         switch (diag) {
             case 1: launch_pp_ns<2, 1>(p, st); break; case 2: launch_pp_ns<2, 2>(p, st); break; case 3: launch_pp_ns<2, 3>(p, st); break;
             case 4: launch_pp_ns<2, 4>(p, st); break; case 6: launch_pp_ns<2, 6>(p, st); break; case 7: launch_pp_ns<2, 7>(p, st); break;
+            case 32: {   // timeline dump: /tmp/pp_trace.bin = 5 x u64 per workgroup (entry, main loop start, main loop end, stores acknowledged, tile)
+                const int nblk = ((p.M + 255) / 256) * (p.N / 256);
+                unsigned long long* buf = nullptr;
+                if (hipMalloc(&buf, (size_t)nblk * 40) != hipSuccess) return false;
+                (void)hipMemsetAsync(buf, 0, (size_t)nblk * 40, st);
+                GemmParams q = p; q.flop_counter = buf;
+                launch_pp_ns<2, 32>(q, st);
+                std::vector<unsigned long long> h((size_t)nblk * 5);
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(h.data(), buf, (size_t)nblk * 40, hipMemcpyDeviceToHost);
+                (void)hipFree(buf);
+                if (FILE* f = fopen("/tmp/pp_trace.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+                break;
+            }
             case 8: launch_pp_ns<2, 8>(p, st); break; case 16: launch_pp_ns<2, 16>(p, st); break; case 23: launch_pp_ns<2, 23>(p, st); break;
             default: return false;
         }
