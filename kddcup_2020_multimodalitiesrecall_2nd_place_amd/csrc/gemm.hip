@@ -177,10 +177,11 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     if (nsplit == 3) { launch_gemm_tile(p, 3, 1, st); return; }
     if (variant == 99) {  // auto (profiles/r01c_gemm_variants.txt): 256x256 ping-pong phases for large M; for the small GEMMs
                           // (CLS-only last block, poolers) 256x256 / 16 waves on wide outputs, 128x256 / 8 waves otherwise
-        if (p.N % 256 == 0 && p.M >= 16384) variant = 20;
+        if (p.N % 256 == 0 && p.M >= 16384) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)
         else variant = (p.N >= 1536 && p.N % 256 == 0 && p.M >= 8192) ? 16 : 4;
     }
     if (variant == 0 && (p.m_dev || p.flop_counter)) variant = 1;   // the v0 kernel has no device-side row count
+    if (variant == 26) { if (launch_gemm_pp(p, nsplit, 0, st, true)) return; variant = 4; }
     if (variant == 20) { if (launch_gemm_pp(p, nsplit, 0, st)) return; variant = 4; }
     if (variant > 200 && variant < 233 && launch_gemm_pp(p, nsplit, variant - 200, st)) return;   // timing diagnostics
     if (variant == 11 && launch_gemm_ring(p, nsplit, 4, st)) return;

@@ -55,7 +55,7 @@ __device__ __forceinline__ void pp_barrier() {
 
 // DIAG (timing diagnostics only, results WRONG): bit 0 drops the phase barriers, bit 1 the in-loop LDS-DMA issue, bit 2 the in-loop ds_reads,
 // bit 3 re-reads the first two K-stages (always cache hits)
-template <int NSPLIT, int ACT, int DIAG>
+template <int NSPLIT, int ACT, int DIAG, bool PERSIST>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 256, WAVES_N = 4, NW = 8, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int PLANE = 256 * 64;                 // one operand plane of a stage: 256 rows x 32 bf16
@@ -76,26 +76,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     if (!(DIAG & 32) && p.flop_counter && blockIdx.x == 0 && tid == 0)
         atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
     const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM, nblk = nbm * nbn;
-    int bid = blockIdx.x;
-    if (bid >= nblk) return;
-    {   // bijective XCD remap over the live workgroups
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int bm = bid / nbn, bn = bid % nbn;
+    int vb = blockIdx.x;                 // virtual block id; PERSIST: the workgroup walks vb, vb + gridDim.x, ... (gridDim.x % 8 == 0)
+    if (vb >= nblk) return;
     const long long lo_delta = p.a_lo - p.a_hi;
     // LDS-DMA sources: piece h (0/1) of an operand = rows h*128 + wave*16 + lane/4, 16-B chunk lane%4 (swizzled)
     const int gr_l = lane >> 2, gc = lane & 3;
     const bf16* a_src[2];
     const bf16* w_src[2];
+    int bm, bn;
+    auto setup = [&](int v) {
+        // bijective XCD remap over the live tiles (virtual block v runs on XCD v % 8)
+        const int q = nblk >> 3, r8 = nblk & 7, xcd = v & 7, loc = v >> 3;
+        const int bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+        bm = bid / nbn; bn = bid % nbn;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int r = h * 128 + wave * 16 + gr_l;
-        int gr = bm * BM + r;
-        gr = gr < Meff ? gr : Meff - 1;
-        a_src[h] = p.a_hi + (p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda + (gc ^ pp_swz(r)) * 8;
-        w_src[h] = p.w + (long long)(bn * BN + r) * p.K + (gc ^ pp_swz(r)) * 8;
-    }
+        for (int h = 0; h < 2; ++h) {
+            const int r = h * 128 + wave * 16 + gr_l;
+            int gr = bm * BM + r;
+            gr = gr < Meff ? gr : Meff - 1;
+            a_src[h] = p.a_hi + (p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda + (gc ^ pp_swz(r)) * 8;
+            w_src[h] = p.w + (long long)(bn * BN + r) * p.K + (gc ^ pp_swz(r)) * 8;
+        }
+    };
+    setup(vb);
     // piece q of stage `st` into ring slot `slot`: q>>1 = operand (A planes first, then W), q&1 = row half
     auto issue = [&](int q, int st, int slot) {
         const int o = q >> 1, h = q & 1;
@@ -105,10 +108,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     };
 
     f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets inside a slot (lane part; the rest are immediates)
     const int fr = lane & 15, fk = lane >> 4;
@@ -195,48 +194,82 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     const unsigned long long tr1 = (DIAG & 32) ? wall_clock64() : 0;
 
     if (DIAG & 4) { read_b(smem, 0, b0); read_b(smem, 1, b1); read_a(smem, 0); }
-    int slot = 0, s = 0;
-    for (; s + 2 < ns; ++s) {
-        stage(std::true_type{}, std::integral_constant<int, P>{}, s, slot);
-        slot = slot == 2 ? 0 : slot + 1;
-    }
-    stage(std::false_type{}, std::integral_constant<int, 0>{}, s, slot);          // stage ns-2: wait for everything
-    slot = slot == 2 ? 0 : slot + 1;
-    stage(std::false_type{}, std::integral_constant<int, -1>{}, s + 1, slot);     // stage ns-1: nothing in flight
-    if (wm == 0) pp_barrier();     // re-align the wave rows
-    const unsigned long long tr2 = (DIAG & 32) ? wall_clock64() : 0;
-
-    if (DIAG & 16) {   // no epilogue (keep the accumulators live)
-        float t = 0.f;
+    for (;;) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (t == 12345.678f) p.c_f32[tid] = t;
-        return;
-    }
-    pp_epilogue<ACT, FM, FN>(p, acc, bm * BM + wm * TM, bn * BN + wn * TN, lane, Meff);
-    if ((DIAG & 32) && tid == 0 && p.flop_counter) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // epilogue stores acknowledged
-        unsigned long long* t = p.flop_counter + 5ull * blockIdx.x;
-        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = wall_clock64(); t[4] = ((unsigned long long)bm << 32) | (unsigned)bn;
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int slot = 0, s = 0;
+        for (; s + 2 < ns; ++s) {
+            stage(std::true_type{}, std::integral_constant<int, P>{}, s, slot);
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        stage(std::false_type{}, std::integral_constant<int, 0>{}, s, slot);          // stage ns-2: wait for everything
+        slot = slot == 2 ? 0 : slot + 1;
+        stage(std::false_type{}, std::integral_constant<int, -1>{}, s + 1, slot);     // stage ns-1: nothing in flight
+        if (wm == 0) pp_barrier();     // re-align the wave rows: nobody reads the ring any more
+        const unsigned long long tr2 = (DIAG & 32) ? wall_clock64() : 0;
+
+        if (DIAG & 16) {   // no epilogue (keep the accumulators live)
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (t == 12345.678f) p.c_f32[tid] = t;
+            return;
+        }
+        // PERSIST: the workgroup's next tile.  Its first two stages go out BEFORE this tile's stores (the epilogue needs no LDS), so
+        // their round trip -- the whole prologue of a fresh workgroup -- runs under the store drain; one full `vmcnt(0)` then covers
+        // both, and neither a workgroup retirement nor a dispatch (~4.6 us) sits between two tiles.
+        const int row0 = bm * BM + wm * TM, col0 = bn * BN + wn * TN;
+        const bool more = PERSIST && vb + (int)gridDim.x < nblk;
+        if (more) {
+            vb += gridDim.x;
+            setup(vb);
+#pragma unroll
+            for (int q = 0; q < P; ++q) issue(q, 0, 0);
+#pragma unroll
+            for (int q = 0; q < P; ++q) issue(q, 1, 1);
+        }
+        pp_epilogue<ACT, FM, FN>(p, acc, row0, col0, lane, Meff);
+        if ((DIAG & 32) && tid == 0 && p.flop_counter) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // epilogue stores acknowledged
+            unsigned long long* t = p.flop_counter + 5ull * blockIdx.x;
+            t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = wall_clock64(); t[4] = ((unsigned long long)bm << 32) | (unsigned)bn;
+        }
+        if (!more) break;
+        pp_wait_vmcnt<0>();
+        pp_barrier();
+        if (wm == 1) pp_barrier();     // stagger again
     }
 }
 
-template <int NSPLIT, int DIAG>
+static int pp_cu_count() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+                   ? prop.multiProcessorCount / 8 * 8 : 8;
+    }
+    return n_cu;
+}
+
+template <int NSPLIT, int DIAG, bool PERSIST = false>
 static void launch_pp_ns(const GemmParams& p, hipStream_t st) {
     const int nblk = ((p.M + 255) / 256) * (p.N / 256);
-    const dim3 grid(nblk), block(512);
+    const dim3 grid(PERSIST && nblk > pp_cu_count() ? pp_cu_count() : nblk), block(512);
     switch (p.act) {
-        case ACT_RELU: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_RELU, DIAG>), grid, block, 0, st, p); break;
-        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_TANH, DIAG>), grid, block, 0, st, p); break;
-        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_ERF, DIAG>), grid, block, 0, st, p); break;
-        case ACT_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_TANH, DIAG>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_NONE, DIAG>), grid, block, 0, st, p); break;
+        case ACT_RELU: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_RELU, DIAG, PERSIST>), grid, block, 0, st, p); break;
+        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_TANH, DIAG, PERSIST>), grid, block, 0, st, p); break;
+        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_ERF, DIAG, PERSIST>), grid, block, 0, st, p); break;
+        case ACT_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_TANH, DIAG, PERSIST>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_NONE, DIAG, PERSIST>), grid, block, 0, st, p); break;
     }
 }
 
-bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st) {
+bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist) {
     if (p.M <= 0) return true;
     if (p.N % 256 || p.K % 64 || nsplit > 2) return false;
     if (diag) {   // timing diagnostics (two-pass only)
@@ -263,6 +296,7 @@ bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st) {
         }
         return true;
     }
-    if (nsplit == 2) launch_pp_ns<2, 0>(p, st); else launch_pp_ns<1, 0>(p, st);
+    if (persist) { if (nsplit == 2) launch_pp_ns<2, 0, true>(p, st); else launch_pp_ns<1, 0, true>(p, st); }
+    else if (nsplit == 2) launch_pp_ns<2, 0>(p, st); else launch_pp_ns<1, 0>(p, st);
     return true;
 }

@@ -44,7 +44,7 @@ GEMM_CASES = [
 ]
 
 
-GEMM_VARIANTS = [0, 1, 3, 4, 11, 12, 16, 20, 99]
+GEMM_VARIANTS = [0, 1, 3, 4, 11, 12, 16, 20, 26, 99]
 
 
 @pytest.fixture
