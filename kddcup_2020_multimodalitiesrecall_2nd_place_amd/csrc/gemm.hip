@@ -174,7 +174,11 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
     if (nblk <= 0) return;
     int variant = get_gemm_variant();
-    if (nsplit == 3) { launch_gemm_tile(p, 3, 1, st); return; }
+    if (nsplit == 3) {   // three passes: 256x128 ping-pong phases for large M (variant 27 forces it), 128x128 tile otherwise
+        if ((variant == 27 || (variant == 99 && p.M >= 16384)) && launch_gemm_ppw(p, st)) return;
+        launch_gemm_tile(p, 3, 1, st);
+        return;
+    }
     if (variant == 99) {  // auto (profiles/r01c_gemm_variants.txt): 256x256 ping-pong phases for large M; for the small GEMMs
                           // (CLS-only last block, poolers) 256x256 / 16 waves on wide outputs, 128x256 / 8 waves otherwise
         if (p.N % 256 == 0 && p.M >= 16384) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)

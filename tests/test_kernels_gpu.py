@@ -86,8 +86,9 @@ def test_gemm_matches_fp64(case, nsplit, gemm_variant):
     assert err < tol, (case, nsplit, gemm_variant, err)
 
 
-@pytest.mark.parametrize("case", GEMM_CASES[:5])
-def test_gemm_precision3_follows_fp32_weights(case):
+@pytest.mark.parametrize("gemm_variant", [99, 27], indirect=True)      # 99: 128x128 tile (small M), 27: 256x128 ping-pong phases
+@pytest.mark.parametrize("case", GEMM_CASES[:5] + GEMM_CASES[8:])
+def test_gemm_precision3_follows_fp32_weights(case, gemm_variant):
     """nsplit 3: weights split hi+lo as well -> an arbitrary fp32 W is followed to ~2^-16."""
     M, K, N, act, resid, planes = case
     l = lib.load()
