@@ -5,7 +5,7 @@ Workload (config.workload): imagebert_zk, full 12-layer / 768 / 3072 model, 1000
 region.  One "step" = one scoring pass over the rank's whole 30 000-pair set, plus the all-gather of
 scores when N > 1 (queries are sharded by rank: weak scaling).  Prints ONE JSON line on rank 0.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--model zk|lds|lxmert] [--precision 1|2]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--model zk|lds|lxmert] [--precision 1|2|3]
 """
 import argparse
 import json
@@ -156,7 +156,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 MFMA operands (weights bf16; activations %s), fp32 accumulate/residual/LN/softmax"
-                     % ("split hi+lo bf16, 2 passes" if a.precision == 2 else "bf16, 1 pass"),
+                     % {1: "bf16, 1 pass", 2: "split hi+lo bf16, 2 passes", 3: "split hi+lo bf16 x split weights, 3 passes"}[a.precision],
             "data": "synthetic",
             "config": {"workload": "imagebert_%s 12-layer, %d queries x %d candidates per GPU (<=10 boxes x 2048-d), "
                                    "seeded weights, inputs HBM-resident" % (cfg.name, a.queries, a.cands)
@@ -168,7 +168,7 @@ def main():
             # kernels EXECUTE fewer FLOPs than that (padded tokens are skipped), so this is an equivalent rate, not
             # a utilisation; roofline.achieved below counts executed FLOPs only.
             "reference_graph_tflops_per_gpu": round(value / world * fpp / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<%d,*> 256x256 ping-pong phases (all dense contractions; small GEMMs: gemm_tile_kernel)" % min(a.precision, 2),
+            "roofline": {"bound": "mfma", "kernel": ("gemm_ppw_kernel<*> 256x128 ping-pong phases, 3 passes" if a.precision == 3 else "gemm_pp_kernel<%d,*,0,true> 256x256 ping-pong phases, persistent" % a.precision) + " (all dense contractions; small GEMMs: gemm_tile_kernel)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches": int(gemm_n), "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),

@@ -27,10 +27,15 @@ def _is_np(x):
 
 
 class _Base:
-    def __init__(self, cfg, weights: dict, precision: int = 2, device: int = 0, chunk_pairs: int = 0,
+    def __init__(self, cfg, weights: dict, precision="auto", device: int = 0, chunk_pairs: int = 0,
                  stop_after: int = -1, dedup_labels: bool = True, pack_tokens: bool = True):
+        """precision: 1 / 2 / 3 or "auto" = ``weights.auto_precision``: 2 for bf16-representable matrices,
+        3 for a real fp32 checkpoint."""
         if not torch.cuda.is_available():
             raise _lib.MmsError("no HIP device visible: the scorers have no CPU path")
+        if precision == "auto":
+            from .weights import auto_precision
+            precision = auto_precision(weights)
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         self.dedup_labels = dedup_labels

@@ -296,6 +296,21 @@ def validate(cfg, weights: dict):
             [(k, tuple(weights[k].shape), want[k]) for k in bad[:5]]))
 
 
+def auto_precision(weights: dict) -> int:
+    """Precision mode a checkpoint needs for 1e-3 logit parity with its fp32 reference: 2 (weights stored as bf16, two MFMA
+    passes) when every matrix is bf16-representable -- the synthetic weights of this repo --, else 3 (weights kept as hi + lo
+    planes, three passes: a real fp32 checkpoint loses ~5e-3 to the bf16 rounding alone)."""
+    for k, v in weights.items():
+        v = np.asarray(v)
+        dims = sorted(d for d in v.shape if d > 1)
+        # the GEMM operands: dense / conv kernels with both dimensions >= 256 (embedding tables, 5->768 box projections, 768->2
+        # heads stay fp32 in the HIP path whatever the mode)
+        if len(dims) >= 2 and dims[-2] >= 256 and "embedding" not in k and v.dtype == np.float32:
+            if np.any(np.ascontiguousarray(v).view(np.uint32) & np.uint32(0xFFFF)):
+                return 3
+    return 2
+
+
 def bf16_rounding_report(weights: dict) -> dict:
     """How far a real fp32 checkpoint is from this build's bf16 GEMM-weight storage format: max relative rounding
     step per matrix (2^-9 worst case).  DESIGN.md 'precision modes' explains what that means for logit parity."""

@@ -282,6 +282,8 @@ def test_precision3_follows_unrounded_fp32_checkpoint(name):
     e3, e2 = vecrel(got3, ref).max(), vecrel(got2, ref).max()
     print("\n[%s, fp32 weights] vec-rel logit error: precision3 %.2e  precision2 %.2e" % (name, e3, e2))
     assert e3 < TOL_P2, e3
+    got_auto, _ = _hip_logits(cfg, w, b)                       # default precision="auto" picks mode 3 for such a checkpoint
+    assert np.array_equal(got_auto, got3)
     assert e2 < TOL_P1
 
 
