@@ -52,6 +52,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[qt][s] = *reinterpret_cast<const float4*>(qr + s * 16);
     }
+    // V fragments are requested up front as well: all of the unit's HBM traffic is in flight before the first MFMA (the loads used
+    // to be issued one row group at a time inside the P V loop, each exposing its latency)
+    float4 vfr[KT][4];
+#pragma unroll
+    for (int jt = 0; jt < KT; ++jt) {
+        if (jt * 16 >= Sk) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int j = jt * 16 + fk * 4 + r;
+            j = j < Sk ? j : Sk - 1;  // P is exactly 0 there; keep the load in bounds and finite
+            vfr[jt][r] = *reinterpret_cast<const float4*>(p.v + (long long)(kv0 + j) * p.ldkv + h * MMS_HEAD_DIM + fr * 4);
+        }
+    }
     f32x4 sc[KT][QT];
 #pragma unroll
     for (int jt = 0; jt < KT; ++jt)
@@ -121,10 +134,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (jt * 16 >= Sk) continue;   // whole tile has P == 0
-            int j = jt * 16 + fk * 4 + r;
-            j = j < Sk ? j : Sk - 1;  // P is exactly 0 there; keep the load in bounds and finite
-            const float4 vf = *reinterpret_cast<const float4*>(
-                p.v + (long long)(kv0 + j) * p.ldkv + h * MMS_HEAD_DIM + fr * 4);
+            const float4 vf = vfr[jt][r];
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 if (qt * 16 >= Sq) continue;
