@@ -179,6 +179,13 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         launch_gemm_tile(p, 3, 1, st);
         return;
     }
+    if (variant > 100) {   // timing diagnostics (101-103 ring, 201-232 ping-pong): they compute WRONG results on purpose, so they are only
+                           // honoured when MMS_GEMM_DIAG is set as well; otherwise fall back to the per-shape default
+        static const bool diag_ok = getenv("MMS_GEMM_DIAG") != nullptr;
+        if (diag_ok && variant > 200 && variant < 233 && launch_gemm_pp(p, nsplit, variant - 200, st)) return;
+        if (diag_ok && variant >= 101 && variant <= 103 && launch_gemm_ring(p, nsplit, variant, st)) return;
+        variant = 99;
+    }
     if (variant == 99) {  // auto (profiles/r01c_gemm_variants.txt): 256x256 ping-pong phases for large M; for the small GEMMs
                           // (CLS-only last block, poolers) 256x256 / 16 waves on wide outputs, 128x256 / 8 waves otherwise
         if (p.N % 256 == 0 && p.M >= 16384) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)
@@ -187,10 +194,8 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     if (variant == 0 && (p.m_dev || p.flop_counter)) variant = 1;   // the v0 kernel has no device-side row count
     if (variant == 26) { if (launch_gemm_pp(p, nsplit, 0, st, true)) return; variant = 4; }
     if (variant == 20) { if (launch_gemm_pp(p, nsplit, 0, st)) return; variant = 4; }
-    if (variant > 200 && variant < 233 && launch_gemm_pp(p, nsplit, variant - 200, st)) return;   // timing diagnostics
     if (variant == 11 && launch_gemm_ring(p, nsplit, 4, st)) return;
     if (variant == 12 && launch_gemm_ring(p, nsplit, 2, st)) return;
-    if (variant >= 101 && variant <= 103 && launch_gemm_ring(p, nsplit, variant, st)) return;   // timing diagnostics
     if (variant > 0 && launch_gemm_tile(p, nsplit, variant, st)) return;
     if (variant > 0 && launch_gemm_tile(p, nsplit, 1, st)) return;   // N % 256 != 0: 128x128 tile
     if (nsplit == 2) launch_ns<2>(p, nblk, st);

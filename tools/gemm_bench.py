@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import sys
 
+os.environ.setdefault("MMS_GEMM_DIAG", "1")   # this tool may run the timing-only kernel variants
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd import lib  # noqa: E402
 
