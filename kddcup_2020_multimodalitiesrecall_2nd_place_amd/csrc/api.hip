@@ -49,6 +49,9 @@ struct mms_handle {
     std::vector<void*> w_allocs, ws_allocs, lab_allocs;
     bool finalized = false;
     int nsplit = 2;
+    int alternate = 1;     // successive big kernels walk their rows in opposite directions, so each starts on the rows its producer wrote last
+                           // (still in the 256 MB Infinity Cache / L2); env MMS_ALTERNATE=0 turns it off (A/B)
+    int flip = 0;
     int resid_in_ln = 1;   // residual add in the LayerNorm that follows (1, default) or in the GEMM epilogue (0; env MMS_RESID_IN_LN, A/B only)
     int x1_mask = 0;   // experiment (env MMS_X1_MASK): GEMM classes forced to one pass: 1 qkv, 2 att-out, 4 ffn-up, 8 ffn-down
     struct WPlane { const bf16* base; long long elems; };
@@ -437,6 +440,7 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     p.c_hi = out.pl.hi; p.c_lo = out.pl.lo; p.ldp = out.ldp; p.cmap = out.cmap;
     if (resid && !h->resid_in_ln) { p.r_hi = resid->hi; p.r_lo = resid->lo; p.ldr = H; }
     p.m_dev = m_dev; p.a_index = a_index; p.rmap = rmap; p.r_index = r_index;
+    if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
     if (h->timing) {
         if (h->ev_used + 2 > h->ev.size()) {
             h->ev.resize(h->ev_used + 2);
@@ -465,12 +469,18 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
               const Planes& resid, RowMap rmap = RowMap{0, 0, 0}, const int* r_index = nullptr) {
     LnResid r;
     if (h->resid_in_ln) { r.hi = resid.hi; r.lo = resid.lo; r.ld = H; r.rmap = rmap; r.r_index = r_index; }
+    if (h->alternate) { r.reverse = h->flip; h->flip ^= 1; }
     launch_ln_to_planes(t, H, g, b, out.hi, out.lo, H, (int)M, st, m_dev, r);
 }
 
 // Packed-stream descriptor: per-pair first row / live count (relative to the stream's first row) and the
 // device-side number of live rows.  off == nullptr: dense layout (row of (b, s) = b * S + s).
 struct Pack { const int* off = nullptr; const int* cnt = nullptr; const int* rows = nullptr; };
+
+void attend(mms_handle* h, AttnParams& a, hipStream_t st) {
+    if (h->alternate) { a.reverse = h->flip; h->flip ^= 1; }
+    launch_attention(a, st);
+}
 
 // attention sub-layer: out = LN(dense(attn(in_q, in_kv)) + in_q)    (pixelbert.py:932-966, modeling.py:355-392)
 // self-attention over one stream whose first row is row0; S = (maximum) tokens per pair.
@@ -487,7 +497,7 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     a.o_hi = h->ctx.hi + row0 * H; a.o_lo = h->ctx.lo + row0 * H; a.ldo = H;
     a.B = (int)B;
     a.q_off = a.kv_off = pk.off; a.q_cnt = a.kv_cnt = pk.cnt;
-    launch_attention(a, st);
+    attend(h, a, st);
     const Planes resid = in.at(row0 * H);
     if (int rc = gemm(h, st, h->ctx.at(row0 * H), H, ID, w.wo, w.bo, M, H, H, ACT_NONE,
                       to_f32(h->t + row0 * H, H), &resid, pk.rows, nullptr, ID, nullptr, 2)) return rc;
@@ -524,7 +534,7 @@ int last_block_cls(mms_handle* h, hipStream_t st, const AttW& att, const FfnW& f
     a.k = h->qkv + H; a.v = h->qkv + 2 * H; a.ldkv = 3 * H; a.Sk = S;
     a.key_add = key_add; a.kv_off = pk.off; a.kv_cnt = pk.cnt;
     a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo; a.ldo = H; a.B = (int)n;
-    launch_attention(a, st);
+    attend(h, a, st);
     if (int rc = gemm(h, st, h->ctx, H, ID, att.wo, att.bo, n, H, H, ACT_NONE, to_f32(h->t, H), &in, nullptr, nullptr, cls, pk.off)) return rc;
     ln_resid(h, st, h->t, att.g, att.b, tmp, n, nullptr, in, cls, pk.off);
     const int I = h->cfg.inter;
@@ -701,7 +711,7 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
             a.k = h->qkv + ML * 3 * H + H; a.v = h->qkv + ML * 3 * H + 2 * H; a.Sk = V; a.key_add = visn_add;
             a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo;
             a.q_off = pl.off; a.q_cnt = pl.cnt; a.kv_off = pv.off; a.kv_cnt = pv.cnt;
-            launch_attention(a, st);
+            attend(h, a, st);
             if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
             ln_resid(h, st, h->t, w.cross.g, w.cross.b, h->y, ML, pl.rows, h->x);
             if (int rc = last_block_cls(h, st, w.lang_self, w.lang_ffn, ACT_GELU_ERF, h->y, h->x, T, n, lang_add, pl)) return rc;
@@ -722,12 +732,12 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
         a.k = h->qkv + ML * 3 * H + H; a.v = h->qkv + ML * 3 * H + 2 * H; a.Sk = V; a.key_add = visn_add;
         a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo;
         a.q_off = pl.off; a.q_cnt = pl.cnt; a.kv_off = pv.off; a.kv_cnt = pv.cnt;
-        launch_attention(a, st);
+        attend(h, a, st);
         a.q = h->qkv + ML * 3 * H; a.Sq = V;                      // visn <- lang
         a.k = h->qkv + H; a.v = h->qkv + 2 * H; a.Sk = T; a.key_add = lang_add;
         a.o_hi = h->ctx.hi + ML * H; a.o_lo = h->ctx.lo + ML * H;
         a.q_off = pv.off; a.q_cnt = pv.cnt; a.kv_off = pl.off; a.kv_cnt = pl.cnt;
-        launch_attention(a, st);
+        attend(h, a, st);
         if (c.pack_tokens) {
             if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
             const Planes rv = h->x.at(ML * H);
@@ -793,6 +803,7 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
     h->nsplit = cfg->precision;
     if (const char* e = getenv("MMS_X1_MASK")) h->x1_mask = atoi(e);
     if (const char* e = getenv("MMS_RESID_IN_LN")) h->resid_in_ln = atoi(e);
+    if (const char* e = getenv("MMS_ALTERNATE")) h->alternate = atoi(e);
     *out = h;
     return MMS_OK;
 }

@@ -22,8 +22,9 @@
 template <int QT, int KT>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= p.B * MMS_HEADS) return;
+    if (p.reverse) unit = p.B * MMS_HEADS - 1 - unit;
     const int b = unit / MMS_HEADS, h = unit % MMS_HEADS;
     const int fr = lane & 15, fk = lane >> 4;
     // dense: rows b*S .. ; packed (ragged): per-pair row offset / live-token count

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     auto setup = [&](int v) {
         // bijective XCD remap over the live tiles (virtual block v runs on XCD v % 8)
         const int q = nblk >> 3, r8 = nblk & 7, xcd = v & 7, loc = v >> 3;
-        const int bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+        int bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+        if (p.reverse) bid = nblk - 1 - bid;
         bm = bid / nbn; bn = bid % nbn;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {

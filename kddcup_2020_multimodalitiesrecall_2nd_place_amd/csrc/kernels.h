@@ -24,6 +24,7 @@ struct GemmParams {
     const int* a_index;          // optional row gather: logical row r reads A row a_index[r]
     RowMap rmap; const int* r_index;  // residual row of logical row r: r_index ? r_index[r] : rmap(r)
     unsigned long long* flop_counter;  // optional: block 0 adds 2*M_eff*N*K (executed algorithmic FLOPs)
+    int reverse;                 // 1: walk the tiles from the last row panel to the first (cache-direction alternation, api.hip)
 };
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
@@ -49,6 +50,7 @@ struct AttnParams {
     const int* q_off; const int* q_cnt; const int* kv_off; const int* kv_cnt;
     int q_stride;                // dense q rows: q_base + b * q_stride (0 -> Sq)
     int o_compact;               // 1: Sq == 1 and the output row is b (CLS-only last layer)
+    int reverse;                 // 1: last pair first
 };
 void launch_attention(const AttnParams& p, hipStream_t st);
 
@@ -56,7 +58,7 @@ void launch_attention(const AttnParams& p, hipStream_t st);
 // Row-wise kernels (one wavefront per 768-wide row)                   (rowops.hip)
 // ---------------------------------------------------------------------------------------------
 // optional residual of the LayerNorm input: row r adds planes row (r_index ? r_index[r] : rmap(r)) before normalising
-struct LnResid { const bf16* hi = nullptr; const bf16* lo = nullptr; int ld = 0; RowMap rmap{0, 0, 0}; const int* r_index = nullptr; };
+struct LnResid { const bf16* hi = nullptr; const bf16* lo = nullptr; int ld = 0; RowMap rmap{0, 0, 0}; const int* r_index = nullptr; int reverse = 0; };
 void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta,
                          bf16* o_hi, bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev = nullptr, LnResid res = LnResid());
 void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipStream_t st);

@@ -102,8 +102,10 @@ __device__ __forceinline__ void row_add_planes(Row& x, const bf16* hi, const bf1
 __global__ __launch_bounds__(256) void k_ln_to_planes(const float* in, int ld, const float* gamma,
                                                       const float* beta, bf16* o_hi, bf16* o_lo, int ldo, int M,
                                                       const int* m_dev, LnResid res) {
-    const int row = wave_row();
-    if (row >= M || (m_dev && row >= *m_dev)) return;
+    int row = wave_row();
+    const int lim = m_dev ? min(M, *m_dev) : M;
+    if (row >= lim) return;
+    if (res.reverse) row = lim - 1 - row;
     Row x;
     row_load(x, in + (long long)row * ld);
     if (res.hi) {
