@@ -1,15 +1,26 @@
 """bench.py -- pairs scored per second on the headline workload of BASELINE.json.
 
-Workload (config.workload): imagebert_zk, full 12-layer / 768 / 3072 model, 1000 synthetic queries x
-30 candidates per GPU (<= 10 boxes x 2048-d fp32 features), inputs resident in HBM before the timed
-region.  One "step" = one scoring pass over the rank's whole 30 000-pair set, plus the all-gather of
-scores when N > 1 (queries are sharded by rank: weak scaling).  Prints ONE JSON line on rank 0.
+Default workload (config.workload; BASELINE.json config 2, the configuration the metric is quoted on): imagebert_zk, full
+12-layer / 768 / 3072 model, 1000 synthetic queries x 30 candidates PER GPU (<= 10 boxes x 2048-d fp32 features), inputs resident
+in HBM before the timed region.  One "step" = one scoring pass over the rank's whole pair set -- feed preparation (struct
+building, on-device label-tuple de-duplication), every kernel of the forward -- plus the all-gather of scores when N > 1
+(queries are sharded by rank).  Prints ONE JSON line on rank 0.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--model zk|lds|lxmert] [--precision 1|2|3]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--model zk|lds|lxmert|ensemble] [--precision 1|2|3|4]
+                  [--workload bench|testB] [--dense] [--all-boxes] [--no-cpu] [--no-secondary]
+
+--gpus N > 1 without WORLD_SIZE in the environment: this process spawns the N ranks itself (one process per GPU, RCCL);
+under torchrun / torch.distributed.run it uses the ranks it is given (and refuses a --gpus that contradicts WORLD_SIZE).
+--workload testB: the reference's testB shape -- 994 queries x 8..30 candidates = ONE job cut into contiguous query blocks
+(ragged shards, strong scaling; run_pretraining_predict_score.py:566, prediction_result/*.txt).
+--model ensemble: BASELINE.json config 5 -- zk, zk on the sen2forest rewrite, lds and lxmert on the same pairs through the
+fused entry point (mms_score_ensemble); a "pair scored" then means scored by all four members and merged.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,8 +35,13 @@ from kddcup_2020_multimodalitiesrecall_2nd_place_amd import scorers, sharding, s
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd.config import (FEAT_DIM, N_BOX, LdsConfig, LxmertConfig,  # noqa: E402
                                                                     ZkConfig, flops_per_pair)
 
-PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (non-scaled fp8 MFMA runs at the same rate)
 BASELINE_FLOPS = {"zk": 5.174e9, "lds": 6.886e9, "lxmert": 6.829e9}
+CFGS = {"zk": ZkConfig, "lds": LdsConfig, "lxmert": LxmertConfig}
+DTYPES = {1: "bf16 MFMA operands, 1 pass (weights bf16; activations bf16)",
+          2: "bf16 MFMA operands (weights bf16; activations split hi+lo bf16, 2 passes), fp32 accumulate/residual/LN/softmax",
+          3: "bf16 MFMA operands (weights and activations split hi+lo bf16, 3 passes), fp32 accumulate/residual/LN/softmax",
+          4: "fp8 e4m3 MFMA operands on the encoder GEMMs (weights: per-channel scale; activations fp8), rest as mode 2"}
 
 
 def device_feats(ps, device, seed):
@@ -36,152 +52,327 @@ def device_feats(ps, device, seed):
     return f * live[:, :, None]
 
 
-def prepare(scorer, cfg, ps, feats):
+def device_feed(cfg_name, cfgs, ps, feats, dev):
+    """The rank's feed, every array already on the device in the dtype the library reads (so a step's prepare() is struct
+    building only -- what a caller that keeps its candidate store in HBM pays per call)."""
     ps.feats = feats
-    b = synth.batch_for(cfg, ps)
-    key = {"zk": "np_images_features", "lds": "features", "lxmert": "feats"}[cfg.name]
+
+    def dv(b):
+        return {k: (torch.as_tensor(v).to(dev) if isinstance(v, np.ndarray) and v.dtype.kind in "fiu" else v) for k, v in b.items()}
+    if cfg_name == "ensemble":
+        zb = synth.zk_batch(ps, cfgs["zk"].text_len)
+        zb2 = synth.zk_batch(synth.sen2forest_variant(ps), cfgs["zk"].text_len)
+        xb = synth.lxmert_batch(ps, cfgs["lxmert"].text_len)
+        from kddcup_2020_multimodalitiesrecall_2nd_place_amd.pipeline import ensemble_feed
+        f = ensemble_feed(zb, zb2, xb)
+        f = {k: (v if torch.is_tensor(v) else torch.as_tensor(v).to(dev)) for k, v in f.items()}
+        for k in ("num_boxes", "label_ids", "query_ids", "len_query", "s2f_query_ids", "s2f_len_query", "lx_input_ids", "lx_input_mask"):
+            f[k] = f[k].to(torch.int32)
+        return f
+    b = dv(synth.batch_for(cfgs[cfg_name], ps))
+    key = {"zk": "np_images_features", "lds": "features", "lxmert": "feats"}[cfg_name]
     b[key] = feats
-    if cfg.name == "zk":
-        return scorer.prepare(b["num_boxes"], b["np_boxes_5"], b[key], b["np_idx_class_labels"], b["np_idx_query_"],
-                              b["len_query_"], b["labels"], b["segment_ids"])
-    if cfg.name == "lds":
+    return b
+
+
+def prepare(scorer, name, b):
+    if name == "ensemble":
         return scorer.prepare(b)
-    return scorer.prepare(b["input_ids"], b["boxes_label_input_ids"], b["input_mask"], b[key], b["boxes"],
+    if name == "zk":
+        return scorer.prepare(b["num_boxes"], b["np_boxes_5"], b["np_images_features"], b["np_idx_class_labels"], b["np_idx_query_"],
+                              b["len_query_"], b["labels"], b["segment_ids"])
+    if name == "lds":
+        return scorer.prepare(b)
+    return scorer.prepare(b["input_ids"], b["boxes_label_input_ids"], b["input_mask"], b["feats"], b["boxes"],
                           b["visual_attention_mask"])
 
 
-def cpu_baseline(cfg, w, budget_s=15.0):
-    """The oracle's torch-fp32 port of the same forward on this box's host cores (bounded sample)."""
+def cpu_baseline(cfg, w, hip_logits_fn=None, budget_s=20.0):
+    """the oracle's torch-fp32 port of the same forward on this box's host cores, on BASELINE.json config 1's
+    shape (100 queries x 30 candidates, batch 256), bounded to ~budget_s of CPU work: whole batches of 256 pairs are timed until the
+    budget is spent.  The same sample's logits also serve as a CHECK of the HIP path (hip_logits_fn), never as its output."""
     from oracle import np_models, torch_models  # checker / baseline only
     cores = torch.get_num_threads()
-    ps = synth.make_pairs(3, 30, tag="/cpu")  # 90 pairs of config 1's shape
+    ps = synth.make_pairs(100, 30, tag="/cpu")     # config 1: 3000 pairs
     b = synth.batch_for(cfg, ps)
     run = (lambda bb: torch_models.forward(cfg, w, bb)) if cfg.name != "lxmert" else \
         (lambda bb: np_models.forward(cfg, w, bb, np.float32))
-    t0 = time.time()
-    run({k: (v[:30] if hasattr(v, "__len__") and len(v) == ps.n else v) for k, v in b.items()})
-    t30 = time.time() - t0
-    reps = int(max(1, min(30, budget_s / max(t30 * 3, 1e-3))))
-    t0 = time.time()
-    for _ in range(reps):
-        run(b)
-    dt = time.time() - t0
-    return {"value": round(reps * ps.n / dt, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d x 90 pairs (3 queries x 30 candidates), torch fp32 restatement of %s, batch 90" % (reps, cfg.name)}
+    cut = lambda lo, hi: {k: (v[lo:hi] if hasattr(v, "__len__") and len(v) == ps.n else v) for k, v in b.items()}
+    run(cut(0, 16))                                 # thread-pool / allocator warm-up, untimed
+    done, dt, ref = 0, 0.0, []
+    while done < ps.n and dt < budget_s:
+        hi = min(done + 256, ps.n)
+        t0 = time.time()
+        out = run(cut(done, hi))
+        dt += time.time() - t0
+        ref.append(np.asarray(out[0], np.float64))
+        done = hi
+    res = {"value": round(done / dt, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
+           "sample": "%d of config 1's 3000 pairs (100 queries x 30 candidates) in batches of 256, torch fp32 restatement of %s on %d "
+                     "threads, %.1f s" % (done, cfg.name, cores, dt)}
+    if hip_logits_fn is not None:
+        got = hip_logits_fn(cut(0, done))
+        ref = np.concatenate(ref)
+        res["hip_vs_port_max_vecrel"] = float((np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)).max())
+    return res
+
+
+def make_members(name, a, local):
+    """-> (scorer, {member name: (cfg, weights, member scorer)})"""
+    kw = dict(device=local, chunk_pairs=a.chunk)
+    if name != "ensemble":
+        cfg = CFGS[name]()
+        w = weights.make_weights(cfg, bf16_matrices=not a.fp32_weights)
+        s = scorers.make_scorer(cfg, w, precision=a.precision, pack_tokens=not a.dense, **kw)
+        return s, {name: (cfg, w, s)}
+    mem = {}
+    for n in ("zk", "lds", "lxmert"):
+        cfg = CFGS[n]()
+        w = weights.make_weights(cfg, bf16_matrices=not a.fp32_weights)
+        mem[n] = (cfg, w, scorers.make_scorer(cfg, w, precision=a.precision, pack_tokens=not a.dense, **kw))
+    return scorers.EnsembleScorer(mem["zk"][2], mem["lds"][2], mem["lxmert"][2]), mem
+
+
+def run_timed(step, steps, warmup, world, dev, handles):
+    """W untimed + exactly K timed steps between barrier + synchronize, MAX over ranks; also one hipEvent pair per step on the
+    stream the kernels run on (torch's current stream is the one handed to the library)."""
+    for i in range(warmup):
+        step(first=(i == 0))
+    for h in handles:
+        h.gemm_timing(True, True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    per = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    med = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
+    gms = gn = gfl = 0.0
+    for h in handles:
+        ms, n, fl = h.gemm_timing(False, True, read=True)
+        gms += ms; gn += n; gfl += fl
+    if world > 1:
+        t = torch.tensor([dt, med], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, med = float(t[0].item()), float(t[1].item())
+    return dt, med, gms, gn, gfl
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: one child per GPU with the torchrun environment contract."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    sys.exit(rc)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="zk")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="zk", choices=["zk", "lds", "lxmert", "ensemble"])
     ap.add_argument("--precision", type=int, default=2)
+    ap.add_argument("--workload", default="bench", choices=["bench", "testB"])
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--cands", type=int, default=30)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (precision 3 on fp32 weights, lds, lxmert, H2D-inclusive)")
+    ap.add_argument("--fp32-weights", action="store_true", help="seeded weights NOT rounded to bf16 (what a real checkpoint looks like)")
     ap.add_argument("--dense", action="store_true", help="keep padded tokens (reference layout) instead of packing live tokens")
     ap.add_argument("--all-boxes", action="store_true", help="worst case: every pair has 10 boxes")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if os.environ.get("MMS_BENCH_SHARE_GPU"):
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d contradicts WORLD_SIZE=%d" % (a.gpus, world))
+    if os.environ.get("MMS_BENCH_SHARE_GPU"):      # N ranks on ONE device: exercises the N > 1 path on a single-GPU box (tests)
         local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # backend "nccl" == RCCL over xGMI; MMS_BENCH_BACKEND=gloo + MMS_BENCH_SHARE_GPU=1 only exist to exercise the
-        # N > 1 code path on a single-GPU test box
+        # backend "nccl" == RCCL over xGMI; MMS_BENCH_BACKEND=gloo (+ MMS_BENCH_SHARE_GPU=1) only exists for single-GPU test boxes
         dist.init_process_group(os.environ.get("MMS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local)
+    gather_dev = dev if os.environ.get("MMS_BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")
 
-    cfg = {"zk": ZkConfig(), "lds": LdsConfig(), "lxmert": LxmertConfig()}[a.model]
-    w = weights.make_weights(cfg)
-    scorer = scorers.make_scorer(cfg, w, precision=a.precision, device=local, chunk_pairs=a.chunk, pack_tokens=not a.dense)
-    # rank r owns queries [r*Q, (r+1)*Q) of the logical N*Q-query job (weak scaling)
-    ps = synth.make_pairs(a.queries, a.cands, tag="/bench%d" % rank, with_feats=False, query_offset=rank * a.queries,
-                          all_boxes=a.all_boxes)
+    scorer, members = make_members(a.model, a, local)
+    cfgs = {n: m[0] for n, m in members.items()}
+    handles = [m[2].handle for m in members.values()]
+    if a.workload == "testB":
+        # ONE 994-query job, candidate sets of 8..30, contiguous query blocks per rank (strong scaling, ragged shards)
+        whole = synth.make_pairs(994, (8, 30), tag="/testB", with_feats=False, all_boxes=a.all_boxes)
+        qop = whole.query_id - whole.query_id.min()
+        counts = sharding.shard_sizes(qop, 994, world)
+        lo, hi = sharding.query_block(994, world, rank)
+        s, e = sharding.pair_slice_for_queries(qop, lo, hi)
+        ps = whole.take(slice(s, e))
+        total_pairs = whole.n
+        scaling = "strong"
+        wl = "testB-like: 994 queries x 8..30 candidates (%d pairs) cut into %d contiguous query blocks" % (whole.n, world)
+    else:
+        # rank r owns queries [r*Q, (r+1)*Q) of the logical N*Q-query job (weak scaling)
+        ps = synth.make_pairs(a.queries, a.cands, tag="/bench%d" % rank, with_feats=False, query_offset=rank * a.queries,
+                              all_boxes=a.all_boxes)
+        counts = [ps.n] * world
+        total_pairs = ps.n * world
+        scaling = "weak"
+        wl = "%d queries x %d candidates per GPU" % (a.queries, a.cands)
     feats = device_feats(ps, dev, 20200823 + rank)
-    prep = prepare(scorer, cfg, ps, feats)
-    qid = torch.as_tensor(ps.query_id, device=dev)
-    pid = torch.as_tensor(ps.product_id, device=dev)
+    feed = device_feed(a.model, cfgs, ps, feats, dev)
+    qid = torch.as_tensor(ps.query_id, device=gather_dev)
+    pid = torch.as_tensor(ps.product_id, device=gather_dev)
 
-    def step(with_ids=False):
-        logits, probs = scorer.score_prepared(prep)
-        score = probs[:, 1].contiguous()
-        return sharding.gather_scores(score, qid if with_ids else None, pid if with_ids else None)
+    def score():
+        prep = prepare(scorer, a.model, feed)            # per-call feed preparation is part of the step
+        if a.model == "ensemble":
+            merged, _ = scorer.score_prepared(prep, members=False)
+            return merged
+        _, probs = scorer.score_prepared(prep)
+        return probs[:, 1].contiguous()
 
-    for i in range(a.warmup):
-        step(with_ids=(i == 0))
-    scorer.handle.gemm_timing(True, True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    gemm_ms, gemm_n, gemm_fl = scorer.handle.gemm_timing(False, True, read=True)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    pairs_total = ps.n * world * a.steps
-    value = pairs_total / dt
+    def step(first=False):
+        sc = score()
+        if world > 1:
+            sc = sc.to(gather_dev)
+            return sharding.gather_scores(sc, qid if first else None, pid if first else None, counts=counts)
+        return sc, None, None
+
+    dt, med, gemm_ms, gemm_n, gemm_fl = run_timed(step, a.steps, a.warmup, world, dev, handles)
+    value = total_pairs * a.steps / dt
 
     if rank == 0:
-        fpp = BASELINE_FLOPS[cfg.name]
-        b0 = synth.batch_for(cfg, ps)
-        if cfg.name == "zk":
-            live = (np.minimum(b0["len_query_"], cfg.text_len) + np.minimum(b0["num_boxes"], N_BOX)).sum()
-            live_frac = live / float(ps.n * cfg.seq)
-        elif cfg.name == "lxmert":
-            live_frac = (b0["input_mask"].sum() + b0["visual_attention_mask"].sum()) / float(ps.n * (cfg.text_len + N_BOX))
-        else:
-            live_frac = 1.0
-        assert abs(flops_per_pair(cfg) / fpp - 1) < 5e-3
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        fpp = sum(BASELINE_FLOPS[n] * (2 if n == "zk" and a.model == "ensemble" else 1) for n in members)
+        for n, (cfg, _, _) in members.items():
+            assert abs(flops_per_pair(cfg) / BASELINE_FLOPS[n] - 1) < 5e-3
+        live_frac = None
+        if a.model in ("zk", "lxmert"):
+            b0 = synth.batch_for(cfgs[a.model], ps)
+            if a.model == "zk":
+                live = (np.minimum(b0["len_query_"], cfgs["zk"].text_len) + np.minimum(b0["num_boxes"], N_BOX)).sum()
+                live_frac = round(float(live) / (ps.n * cfgs["zk"].seq), 4)
+            else:
+                live_frac = round(float(b0["input_mask"].sum() + b0["visual_attention_mask"].sum()) / (ps.n * (cfgs["lxmert"].text_len + N_BOX)), 4)
+        elif a.model == "lds":
+            live_frac = 1.0
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % cfg.name)
-        if os.path.exists(tp) and not a.dense and a.precision == 2:   # measured by tools/pmc_traffic.sh on this workload
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % a.model)
+        if os.path.exists(tp) and not a.dense and a.precision == 2 and a.workload == "bench":   # tools/pmc_traffic.sh on this workload
             traffic = round(json.load(open(tp))["hbm_bytes_per_launch"], 1)
+        kern = {1: "gemm_pp_kernel<1,*,0,true> 256x256 ping-pong phases, persistent", 2: "gemm_pp_kernel<2,*,0,true> 256x256 ping-pong phases, persistent",
+                3: "gemm_ppw_kernel<*> 256x128 ping-pong phases, 3 passes", 4: "gemm_pp_kernel<1,*,0,true,fp8> 256x256 ping-pong phases on e4m3 operands"}[a.precision]
         res = {
             "metric": "query-image pairs scored/sec (whole node)", "value": round(value, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 MFMA operands (weights bf16; activations %s), fp32 accumulate/residual/LN/softmax"
-                     % {1: "bf16, 1 pass", 2: "split hi+lo bf16, 2 passes", 3: "split hi+lo bf16 x split weights, 3 passes"}[a.precision],
-            "data": "synthetic",
-            "config": {"workload": "imagebert_%s 12-layer, %d queries x %d candidates per GPU (<=10 boxes x 2048-d), "
-                                   "seeded weights, inputs HBM-resident" % (cfg.name, a.queries, a.cands)
-                       if cfg.name != "lxmert" else "lxmert 9/5/5, %d queries x %d candidates per GPU" % (a.queries, a.cands),
-                       "pairs_per_gpu": ps.n, "precision_mode": a.precision, "parallelism": "query-sharded dp%d" % world,
-                       "token_packing": (not a.dense) and cfg.name != "lds",
-                       "live_token_fraction": round(live_frac, 4)},
+            "ms_per_step_median_hipevent": round(med, 3),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": DTYPES[a.precision], "data": "synthetic",
+            "config": {"workload": ("imagebert_%s 12-layer, " % a.model if a.model in ("zk", "lds") else
+                                    "lxmert 9/5/5, " if a.model == "lxmert" else
+                                    "3-model ensemble (imagebert_zk on the query and on its sen2forest rewrite + imagebert_lds + lxmert, fused entry point), ")
+                                   + wl + " (<=10 boxes x 2048-d), seeded weights%s, inputs HBM-resident" % (" (fp32, not bf16-rounded)" if a.fp32_weights else ""),
+                       "pairs_per_gpu": ps.n, "pairs_total": total_pairs, "precision_mode": a.precision,
+                       "parallelism": "query-sharded dp%d" % world,
+                       "token_packing": (not a.dense) and a.model != "lds", "live_token_fraction": live_frac},
             # pairs/s x the reference graph's padded-shape FLOPs/pair (BASELINE.md section 2).  With token packing the
             # kernels EXECUTE fewer FLOPs than that (padded tokens are skipped), so this is an equivalent rate, not
             # a utilisation; roofline.achieved below counts executed FLOPs only.
             "reference_graph_tflops_per_gpu": round(value / world * fpp / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": ("gemm_ppw_kernel<*> 256x128 ping-pong phases, 3 passes" if a.precision == 3 else "gemm_pp_kernel<%d,*,0,true> 256x256 ping-pong phases, persistent" % a.precision) + " (all dense contractions; small GEMMs: gemm_tile_kernel)",
+            "roofline": {"bound": "mfma", "kernel": kern + " (all dense contractions; small GEMMs: gemm_tile_kernel)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches": int(gemm_n), "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                          "algorithmic_flops_per_launch": round(gemm_fl / max(gemm_n, 1), 1),
                          "note": "achieved = sum over GEMM launches of executed 2*M_live*N*K (device-counted) / sum of hipEvent "
-                                 "launch durations in the timed region; traffic = PMC HBM bytes per launch from profiles/"},
+                                 "launch durations in the timed region (rank 0); traffic = PMC HBM bytes per launch from profiles/"},
         }
+        if world == 1 and not a.no_secondary and a.workload == "bench":
+            res["secondary"] = secondary(a, local, dev, ps, feats, members, scorer, feed, value)
         if world == 1 and not a.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(cfg, w)
-        print(json.dumps(res))
+            n0 = "zk" if a.model == "ensemble" else a.model
+            cfg0, w0, s0 = members[n0]
+
+            def hip_logits(bb):
+                lg, _ = scorers.score_batch(s0, bb)
+                return lg.double().cpu().numpy()
+            res["cpu_baseline"] = cpu_baseline(cfg0, w0, hip_logits)
+        print(json.dumps(res), flush=True)
     scorer.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def secondary(a, local, dev, ps, feats, members, scorer, feed, value):
+    """Numbers the driver would otherwise never see (N = 1 only, a few seconds each): the H2D-inclusive rate of the headline
+    workload, the fp32-checkpoint-faithful mode on UNROUNDED weights with its measured parity, and the other two models."""
+    out = {}
+    # ---- headline workload, features copied from pinned host memory inside the step (not overlapped) ----
+    key = {"zk": "np_images_features", "lds": "features", "lxmert": "feats", "ensemble": "feats"}[a.model]
+    host = torch.empty(feats.shape, dtype=torch.float32, pin_memory=True)
+    host.copy_(feats)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        f2 = dict(feed)
+        f2[key] = host.to(dev, non_blocking=True)
+        p = prepare(scorer, a.model, f2)
+        scorer.score_prepared(p, members=False) if a.model == "ensemble" else scorer.score_prepared(p)
+    torch.cuda.synchronize()
+    out["value_incl_h2d"] = {"value": round(ps.n * reps / (time.perf_counter() - t0), 1), "unit": "pairs/s",
+                             "note": "same step + H2D of the fp32 box features (%.2f GB per pass) from pinned memory, not overlapped" % (feats.numel() * 4 / 1e9)}
+    del host
+    if a.model != "zk" or a.precision != 2:
+        return out
+
+    def quick(name, precision, fp32_weights, parity):
+        cfg = CFGS[name]()
+        w = weights.make_weights(cfg, bf16_matrices=not fp32_weights)
+        s = scorers.make_scorer(cfg, w, precision=precision, device=local, chunk_pairs=a.chunk)
+        fd = device_feed(name, {name: cfg}, ps, feats, dev)
+        def st(first=False):
+            s.score_prepared(prepare(s, name, fd))
+        dt, med, gms, gn, gfl = run_timed(st, 3, 1, 1, dev, [s.handle])
+        r = {"value": round(ps.n * 3 / dt, 1), "unit": "pairs/s", "precision_mode": s.precision,
+             "gemm_tflops": round(gfl / (gms * 1e-3) / 1e12, 1), "frac": round(gfl / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        if parity:   # checker: the oracle's fp32 port on the same (unrounded) weights, 30 pairs
+            from oracle import torch_models
+            p30 = synth.make_pairs(1, 30, tag="/p3check")
+            b30 = synth.batch_for(cfg, p30)
+            ref = np.asarray(torch_models.forward(cfg, w, b30)[0], np.float64)
+            got = scorers.score_batch(s, b30)[0].double().cpu().numpy()
+            r["parity_max_vecrel_vs_fp32_port"] = float((np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)).max())
+            r["weights"] = "seeded fp32, NOT bf16-rounded (a real checkpoint's situation); precision auto -> mode 3"
+        s.close()
+        return r
+    out["precision3"] = quick("zk", "auto", True, True)
+    out["lds"] = quick("lds", 2, False, False)
+    out["lxmert"] = quick("lxmert", 2, False, False)
+    return out
 
 
 if __name__ == "__main__":

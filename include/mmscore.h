@@ -23,6 +23,8 @@
  *   - one handle per GPU/stream; calls on one handle must be serialised by the caller; kernels are
  *     enqueued asynchronously on the hipStream_t passed as `stream` (NULL = default stream).
  *   - integer dtypes are the reference feed dtypes (zk: int32 ids, int64 labels; lds/lxmert: int64).
+ *   - the library reads no environment variable (A/B knobs and timing-only diagnostics live in the separate lab build,
+ *     csrc/Makefile `make lab`, which the package never loads).
  */
 #ifndef MMSCORE_H
 #define MMSCORE_H
@@ -57,7 +59,10 @@ typedef struct mms_config {
     int32_t text_len;         /* zk/lds 20, lxmert 23 */
     int32_t precision;        /* 1: bf16 activations, one MFMA pass; 2: split-bf16 activations (hi+lo), two passes, GEMM
                                  weights stored as bf16; 3: activations AND weights split (three passes): follows an
-                                 arbitrary fp32 checkpoint to ~2e-5 */
+                                 arbitrary fp32 checkpoint to ~2e-5; 4: fp8 (OCP e4m3) weights with one fp32 scale per output
+                                 channel and fp8 activations on the four big encoder GEMM classes (QKV, attention output,
+                                 FFN up / down), fp8 MFMA -- BASELINE.json config 5; OUTSIDE the 1e-3 logit contract, its measured
+                                 deviation is reported by the tests and bench.py */
     int32_t chunk_pairs;      /* max pairs per internal launch wave (0 = default 32768); a batch is cut into equal chunks */
     int32_t stop_after;       /* debug: run only the first n encoder layers (-1 = all) and skip nothing else */
     int32_t device;           /* HIP device ordinal */
@@ -66,21 +71,24 @@ typedef struct mms_config {
                                  lds has no mask (pixelmodel.py:189-190) and must use 0 */
 } mms_config;
 
-/* zk feed, code/imagebert_zk/evaluate_normal.py:141-152.  np_idx_class_labels [B,10,8] is passed
- * de-duplicated: uniq_label_ids [U,8] + label_index [B,10] (U = B*10 and index = arange reproduces
- * the dense graph; the label-text encoder depends only on the 8-id tuple). */
+/* zk feed, code/imagebert_zk/evaluate_normal.py:141-152.  np_idx_class_labels [B,10,8] is either passed as the reference
+ * feeds it (`label_ids`, dense: the library finds the distinct 8-id tuples itself -- the label-text encoder depends on the
+ * tuple only -- which costs one 4-byte device->host read on `stream` per call), or already de-duplicated by the caller:
+ * uniq_label_ids [U,8] + label_index [B,10] (U = B*10 and index = arange reproduces the dense graph).  uniq_label_ids ==
+ * NULL selects the dense form. */
 typedef struct mms_zk_batch {
     int64_t n_pairs;
     const int32_t* num_boxes;      /* [B] */
     const float* boxes_5;          /* [B,10,5] */
     const float* feats;            /* [B,10,2048] */
-    const int32_t* uniq_label_ids; /* [U,8] */
+    const int32_t* uniq_label_ids; /* [U,8] or NULL */
     int64_t n_uniq_labels;
-    const int32_t* label_index;    /* [B,10] -> row of uniq_label_ids */
+    const int32_t* label_index;    /* [B,10] -> row of uniq_label_ids (values outside [0,U) are clamped) */
     const int32_t* query_ids;      /* [B,text_len] */
     const int32_t* len_query;      /* [B] */
     const int64_t* labels;         /* [B] (AM-softmax head is label dependent, model_triple.py:68-81) */
-    const int32_t* segment_ids;    /* [B,text_len+10] */
+    const int32_t* segment_ids;    /* [B,text_len+10]; ids are clamped to [0, type_vocab) */
+    const int32_t* label_ids;      /* [B,10,8] dense np_idx_class_labels, read when uniq_label_ids == NULL */
 } mms_zk_batch;
 
 /* lds feed, code/imagebert_lds/src/run_pretraining_predict_score.py:526-548 (boxes is unused there) */
@@ -92,18 +100,42 @@ typedef struct mms_lds_batch {
     const int64_t* labelfeat;      /* [B,10,8] */
 } mms_lds_batch;
 
-/* lxmert feed, code/lxmert/src/tasks/kdd_model.py:183-186 (label text de-duplicated as for zk) */
+/* lxmert feed, code/lxmert/src/tasks/kdd_model.py:183-186 (label text dense or de-duplicated, as for zk) */
 typedef struct mms_lxmert_batch {
     int64_t n_pairs;
     const int64_t* input_ids;      /* [B,text_len] */
     const int64_t* input_mask;     /* [B,text_len] */
-    const int64_t* uniq_label_ids; /* [U,8] */
+    const int64_t* uniq_label_ids; /* [U,8] or NULL */
     int64_t n_uniq_labels;
     const int32_t* label_index;    /* [B,10] */
     const float* feats;            /* [B,10,2048] */
     const float* boxes;            /* [B,10,4] */
     const float* visual_attention_mask; /* [B,10] */
+    const int64_t* label_ids;      /* [B,10,8] dense boxes_label_input_ids, read when uniq_label_ids == NULL */
+    float* x_norm;                 /* optional OUTPUT, device fp32 [B,768]: pooled / max(||pooled||, 1e-12), the first element
+                                      of KDDModel.forward's return tuple (kdd_model.py:204-205,214); NULL = not wanted */
 } mms_lxmert_batch;
+
+/* The three models on the SAME pairs in one call -- BASELINE.json config 5, what code/main.py:41-59 merges from four score files:
+ * imagebert_zk on the query, imagebert_zk on its sen2forest rewrite (evaluate_normal_sen2fs.py, load_data_v4.py:153-154),
+ * imagebert_lds and lxmert.  One TSV record feeds all of them (load_data_v4.py:133-163, load_data_pred.py:94-121,
+ * lxmert/src/utils.py:23-59), so the image side is passed ONCE: the 2048-d box features are split into operand planes once per
+ * launch wave, the class-name tuples are de-duplicated once, zk's image-token stage (label conv, kdd_conv2, kdd_dense1,
+ * kdd_featureemb: model_triple.py:189-195, pixelbert.py:449-452) runs once for both query variants.  All ids are int32 here. */
+typedef struct mms_ensemble_batch {
+    int64_t n_pairs;
+    const float* feats;            /* [B,10,2048] */
+    const float* boxes_5;          /* [B,10,5] = corners/[h,w,h,w] + area (load_data_v4.py:141-147); lxmert reads the 4 corners */
+    const int32_t* num_boxes;      /* [B]; lxmert's visual mask = box index < min(num_boxes, 10) */
+    const int32_t* label_ids;      /* [B,10,8] */
+    const int32_t* query_ids;      /* [B,zk.text_len]  zk + lds query ([CLS] .. [SEP], zero padded) */
+    const int32_t* len_query;      /* [B] */
+    const int32_t* s2f_query_ids;  /* [B,zk.text_len]  the sen2forest rewrite of the same query */
+    const int32_t* s2f_len_query;  /* [B] */
+    const int64_t* labels;         /* [B] zk AM-softmax label (1 on testB, ground truth on valid: load_data_v4.py:259-265) */
+    const int32_t* lx_input_ids;   /* [B,lxmert.text_len]  lxmert tokenizer flavour */
+    const int32_t* lx_input_mask;  /* [B,lxmert.text_len] */
+} mms_ensemble_batch;
 
 int mms_version(void);
 const char* mms_global_error(void);              /* message of the last failing mms_create */
@@ -121,6 +153,11 @@ int mms_finalize(mms_handle* h);
 int mms_score_zk(mms_handle* h, const mms_zk_batch* b, float* logits, float* probs, void* stream);
 int mms_score_lds(mms_handle* h, const mms_lds_batch* b, float* logits, float* probs, void* stream);
 int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, float* probs, void* stream);
+/* merged[i] = w[0]*zk(query) + w[1]*zk(sen2forest query) + w[2]*lds + w[3]*lxmert, each member = softmax(logit)[1]
+ * (main.py:59: w = 0.2, 0.2, 0.3, 0.3).  merged: device fp32 [B]; member_scores: optional device fp32 [4,B] (the four columns
+ * main.py reads from the score files).  The three handles must live on the same device; zk and lds share text_len. */
+int mms_score_ensemble(mms_handle* zk, mms_handle* lds, mms_handle* lxmert, const mms_ensemble_batch* b, const float* weights4,
+                       float* merged, float* member_scores, void* stream);
 
 /* accumulated hipEvent time (ms) and launch count of the GEMM kernels since the last reset;
  * enable = 1 brackets every GEMM launch with events on its stream (bench / roofline only) */
@@ -131,7 +168,12 @@ int mms_debug_read_x(mms_handle* h, float* dst_dev, int64_t rows, void* stream);
 int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const float* w_f32_nk, int64_t N,
                  const float* bias, const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes,
                  float* c_f32, void* stream);
-/* experiments: select the GEMM kernel configuration (0 = default) / time one GEMM shape on random data */
+/* fp8 GEMM (precision 4) on fp32 operands: A and W are quantised exactly as the forward does it (A: e4m3 RNE of the value;
+ * W: per-output-channel scale max|w|/448, e4m3 RNE of w/scale) */
+int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, int64_t N, const float* bias, int32_t act,
+                    int32_t out_f8, float* c_f32, void* stream);
+/* test hook: force one of the PRODUCT tile engines for every GEMM (1, 4, 16: register-staged tiles; 26: persistent ping-pong;
+ * 27: three-pass ping-pong; anything else = per-shape default) / time one GEMM shape on random data */
 int mms_set_gemm_variant(int32_t variant);
 int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t act, int32_t out_planes, int32_t resid,
                        int32_t variant, int32_t iters, float* ms_out);

@@ -25,11 +25,15 @@ struct HostTensor {
 struct Planes {
     bf16* hi = nullptr;
     bf16* lo = nullptr;
-    Planes at(long long elem_off) const { Planes p; p.hi = hi + elem_off; p.lo = lo + elem_off; return p; }
+    unsigned char* f8 = nullptr;   // precision mode 4: the same activation as e4m3 bytes (the fp8 GEMMs' A operand)
+    Planes at(long long elem_off) const { Planes p; p.hi = hi + elem_off; p.lo = lo + elem_off; p.f8 = f8 ? f8 + elem_off : nullptr; return p; }
 };
 
-struct AttW { bf16* wqkv; float* bqkv; bf16* wo; float* bo; float* g; float* b; };
-struct FfnW { bf16* wi; float* bi; bf16* wd; float* bd; float* g; float* b; };
+// *8 / *s: e4m3 copy of the matrix and its per-output-channel scales (precision mode 4 only)
+struct AttW { bf16* wqkv; float* bqkv; bf16* wo; float* bo; float* g; float* b; unsigned char* wqkv8 = nullptr; float* wqkvs = nullptr;
+              unsigned char* wo8 = nullptr; float* wos = nullptr; };
+struct FfnW { bf16* wi; float* bi; bf16* wd; float* bd; float* g; float* b; unsigned char* wi8 = nullptr; float* wis = nullptr;
+              unsigned char* wd8 = nullptr; float* wds = nullptr; };
 struct LayerW { AttW att; FfnW ffn; };
 struct XLayerW { AttW cross, lang_self, visn_self; FfnW lang_ffn, visn_ffn; };
 
@@ -49,11 +53,12 @@ struct mms_handle {
     std::vector<void*> w_allocs, ws_allocs, lab_allocs;
     bool finalized = false;
     int nsplit = 2;
+    bool f8 = false;       // precision mode 4: the big encoder GEMMs run on e4m3 operands; everything else as mode 2
     int alternate = 1;     // successive big kernels walk their rows in opposite directions, so each starts on the rows its producer wrote last
                            // (still in the 256 MB Infinity Cache / L2); env MMS_ALTERNATE=0 turns it off (A/B)
     int flip = 0;
     int resid_in_ln = 1;   // residual add in the LayerNorm that follows (1, default) or in the GEMM epilogue (0; env MMS_RESID_IN_LN, A/B only)
-    int x1_mask = 0;   // experiment (env MMS_X1_MASK): GEMM classes forced to one pass: 1 qkv, 2 att-out, 4 ffn-up, 8 ffn-down
+    int x1_mask = 0;   // lab build only (env MMS_X1_MASK): GEMM classes forced to one pass: 1 qkv, 2 att-out, 4 ffn-up, 8 ffn-down
     struct WPlane { const bf16* base; long long elems; };
     std::vector<WPlane> w_planes;   // precision 3: hi plane [base, base+elems), lo plane right behind it
 
@@ -85,6 +90,17 @@ struct mms_handle {
     // label-text workspace, sized for lab_cap unique labels
     int64_t lab_cap = 0;
     Planes lab_planes; float *lab_f32 = nullptr, *lab_feat = nullptr; int64_t lab_feat_cap = 0;
+    int64_t n_labels = 0;  // rows of lab_feat that are valid for the current call
+    // label-tuple de-duplication workspace (dense label ids), sized for dd_rows = B*10 tuples
+    std::vector<void*> dd_allocs;
+    int64_t dd_rows = 0; int dd_cap = 0;
+    int *dd_slots = nullptr, *dd_rep = nullptr, *dd_uid = nullptr, *dd_counter = nullptr, *dd_index = nullptr;
+    int32_t* dd_uniq32 = nullptr; int64_t* dd_uniq64 = nullptr;
+    // fused three-model entry point: feed conversions and member outputs, sized for ens_pairs
+    std::vector<void*> ens_allocs;
+    int64_t ens_pairs = 0;
+    int32_t* ens_seg = nullptr; int64_t *ens_ids64 = nullptr, *ens_seg64 = nullptr, *ens_lab64 = nullptr, *ens_mask64 = nullptr;
+    float *ens_vmask = nullptr, *ens_boxes4 = nullptr, *ens_logits = nullptr, *ens_probs = nullptr, *ens_tok = nullptr;
 
     // ---- gemm timing ----
     bool timing = false;
@@ -183,6 +199,39 @@ int upload_mat(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, bf16**
     if (with_lo) h->w_planes.push_back({(const bf16*)p, N * K});
     return MMS_OK;
 }
+// precision mode 4: e4m3 copy [N][K] of the same sources + one power-of-two scale per output channel (quantised on the device:
+// launch_quant_rows_f8, the routine mms_dbg_gemm_f8 exposes to the kernel tests)
+int upload_mat_f8(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, unsigned char** out, float** scale) {
+    int64_t N = 0;
+    for (auto& s : srcs) N += s.n;
+    std::vector<float> buf((size_t)(N * K));
+    int64_t r0 = 0;
+    for (auto& s : srcs) {
+        for (int64_t n = 0; n < s.n; ++n)
+            for (int64_t k = 0; k < K; ++k) buf[(size_t)((r0 + n) * K + k)] = s.in_out ? s.p[k * s.n + n] : s.p[n * K + k];
+        r0 += s.n;
+    }
+    float* tmp = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&tmp, buf.size() * 4));
+    hipError_t e = hipMemcpy(tmp, buf.data(), buf.size() * 4, hipMemcpyHostToDevice);
+    void *q = nullptr, *sc = nullptr;
+    int rc = e == hipSuccess ? MMS_OK : h->fail(MMS_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    if (!rc) rc = dev_alloc(h, h->w_allocs, &q, (size_t)(N * K));
+    if (!rc) rc = dev_alloc(h, h->w_allocs, &sc, (size_t)N * 4);
+    if (!rc) {
+        launch_quant_rows_f8(tmp, (unsigned char*)q, (float*)sc, (int)N, (int)K, 0);
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) rc = h->fail(MMS_ERR_HIP, std::string("quantise weights: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(tmp);
+    *out = (unsigned char*)q; *scale = (float*)sc;
+    return rc;
+}
+int mat_f8(mms_handle* h, const std::string& name, int64_t N, int64_t K, bool in_out, unsigned char** out, float** scale) {
+    const HostTensor* t = find(h, name);
+    if (!t) return h->fail(MMS_ERR_WEIGHT, "missing weight: " + name);
+    return upload_mat_f8(h, {{t->data.data(), N, in_out}}, K, out, scale);
+}
 int mat(mms_handle* h, const std::string& name, int64_t N, int64_t K, bool in_out, bf16** out,
         std::vector<int64_t> shape_override = {}) {
     const HostTensor* t;
@@ -214,6 +263,10 @@ int load_att(mms_handle* h, bool tf, const std::string& self_scope, const std::s
         bnames.push_back(self_scope + (tf ? "/" : ".") + qkv[i] + (tf ? "/bias" : ".bias"));
     }
     if (int rc = upload_mat(h, srcs, H, &w->wqkv)) return rc;
+    if (h->f8) {
+        if (int rc = upload_mat_f8(h, srcs, H, &w->wqkv8, &w->wqkvs)) return rc;
+        if (int rc = mat_f8(h, out_scope + (tf ? "/dense/kernel" : ".dense.weight"), H, H, tf, &w->wo8, &w->wos)) return rc;
+    }
     if (int rc = cat_vec(h, bnames, H, &w->bqkv)) return rc;
     if (int rc = mat(h, out_scope + (tf ? "/dense/kernel" : ".dense.weight"), H, H, tf, &w->wo)) return rc;
     if (int rc = vec(h, out_scope + (tf ? "/dense/bias" : ".dense.bias"), H, &w->bo)) return rc;
@@ -223,6 +276,10 @@ int load_att(mms_handle* h, bool tf, const std::string& self_scope, const std::s
 }
 int load_ffn(mms_handle* h, bool tf, const std::string& inter, const std::string& out, FfnW* w) {
     const int64_t I = h->cfg.inter;
+    if (h->f8) {
+        if (int rc = mat_f8(h, inter + (tf ? "/dense/kernel" : ".dense.weight"), I, H, tf, &w->wi8, &w->wis)) return rc;
+        if (int rc = mat_f8(h, out + (tf ? "/dense/kernel" : ".dense.weight"), H, I, tf, &w->wd8, &w->wds)) return rc;
+    }
     if (int rc = mat(h, inter + (tf ? "/dense/kernel" : ".dense.weight"), I, H, tf, &w->wi)) return rc;
     if (int rc = vec(h, inter + (tf ? "/dense/bias" : ".dense.bias"), I, &w->bi)) return rc;
     if (int rc = mat(h, out + (tf ? "/dense/kernel" : ".dense.weight"), H, I, tf, &w->wd)) return rc;
@@ -348,6 +405,8 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     if (pairs <= h->ws_pairs) return MMS_OK;
     free_pool(h->ws_allocs);
     h->ws_pairs = 0;
+    h->ens_tok = nullptr;
+    h->x.f8 = h->y.f8 = h->ctx.f8 = h->mid.f8 = nullptr;
     const mms_config& c = h->cfg;
     const int64_t T = c.text_len;
     int64_t rows, mid_rows;
@@ -364,6 +423,16 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     if (int rc = alloc_planes(h, h->ws_allocs, &h->ctx, rows * H)) return rc;
     if (int rc = alloc_planes(h, h->ws_allocs, &h->y, rows * H)) return rc;
     if (int rc = alloc_planes(h, h->ws_allocs, &h->mid, mid_elems)) return rc;
+    if (h->f8) {   // e4m3 copies of the GEMM A operands (x / y: LayerNorm outputs, ctx: attention output, mid: FFN intermediate)
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * H)) return rc;
+        h->x.f8 = (unsigned char*)p;
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * H)) return rc;
+        h->y.f8 = (unsigned char*)p;
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * H)) return rc;
+        h->ctx.f8 = (unsigned char*)p;
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)mid_rows * c.inter)) return rc;
+        h->mid.f8 = (unsigned char*)p;
+    }
     if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * 3 * H * 4)) return rc;
     h->qkv = (float*)p;
     if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * H * 4)) return rc;
@@ -459,6 +528,37 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     return MMS_OK;
 }
 
+// precision mode 4: C = act((A8 W8^T) * scale[n] + bias) on e4m3 operands; out: fp32 (out.f32) or e4m3 bytes (out.pl.f8)
+int gemm_f8(mms_handle* h, hipStream_t st, const unsigned char* a8, int lda, const unsigned char* w8, const float* wscale,
+            const float* bias, int64_t M, int N, int K, int act, const GemmOut& out, const int* m_dev) {
+    if (M <= 0) return MMS_OK;
+    if (N % 256 || K % 128 || lda % 2) return h->fail(MMS_ERR_ARG, "gemm_f8: N % 256, K % 128 or odd lda");
+    GemmParams p{};
+    p.f8 = 1;
+    p.a_hi = (const bf16*)a8; p.a_lo = p.a_hi; p.lda = lda / 2; p.amap = RowMap{0, 0, 0};
+    p.w = (const bf16*)w8; p.bias = bias; p.col_scale = wscale; p.M = (int)M; p.N = N; p.K = K / 2;
+    p.act = act;
+    if (out.f32) { p.out_kind = OUT_F32; p.c_f32 = out.f32; p.ldc = out.ldc; }
+    else { p.out_kind = OUT_F8; p.c_f8 = out.pl.f8; p.ldf8 = out.ldp; }
+    p.cmap = out.cmap; p.rmap = RowMap{0, 0, 0};
+    p.m_dev = m_dev;
+    if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
+    if (h->timing) {
+        if (h->ev_used + 2 > h->ev.size()) {
+            h->ev.resize(h->ev_used + 2);
+            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used]));
+            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used + 1]));
+        }
+        p.flop_counter = h->flop_counter;
+        HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
+        if (!launch_gemm_pp_f8(p, st)) return h->fail(MMS_ERR_ARG, "gemm_f8: shape not supported");
+        HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
+        h->ev_used += 2;
+        h->gemm_launches += 1;
+    } else if (!launch_gemm_pp_f8(p, st)) return h->fail(MMS_ERR_ARG, "gemm_f8: shape not supported");
+    return MMS_OK;
+}
+
 GemmOut to_f32(float* p, int ldc) { GemmOut o; o.f32 = p; o.ldc = ldc; return o; }
 GemmOut to_planes(Planes p, int ldp, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.pl = p; o.ldp = ldp; o.cmap = m; return o; }
 const RowMap ID{0, 0, 0};
@@ -470,6 +570,7 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
     LnResid r;
     if (h->resid_in_ln) { r.hi = resid.hi; r.lo = resid.lo; r.ld = H; r.rmap = rmap; r.r_index = r_index; }
     if (h->alternate) { r.reverse = h->flip; h->flip ^= 1; }
+    r.o_f8 = out.f8;
     launch_ln_to_planes(t, H, g, b, out.hi, out.lo, H, (int)M, st, m_dev, r);
 }
 
@@ -477,9 +578,11 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
 // device-side number of live rows.  off == nullptr: dense layout (row of (b, s) = b * S + s).
 struct Pack { const int* off = nullptr; const int* cnt = nullptr; const int* rows = nullptr; };
 
-void attend(mms_handle* h, AttnParams& a, hipStream_t st) {
+int attend(mms_handle* h, AttnParams& a, hipStream_t st) {
     if (h->alternate) { a.reverse = h->flip; h->flip ^= 1; }
-    launch_attention(a, st);
+    if (!launch_attention(a, st))
+        return h->fail(MMS_ERR_ARG, "attention: sequence of " + std::to_string(a.Sq) + " x " + std::to_string(a.Sk) + " tokens exceeds the 48-token kernels");
+    return MMS_OK;
 }
 
 // attention sub-layer: out = LN(dense(attn(in_q, in_kv)) + in_q)    (pixelbert.py:932-966, modeling.py:355-392)
@@ -487,8 +590,11 @@ void attend(mms_handle* h, AttnParams& a, hipStream_t st) {
 int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes out, int64_t row0, int S, int64_t B,
               const float* key_add, const Pack& pk = Pack()) {
     const int64_t M = B * S;
-    if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wqkv, w.bqkv, M, 3 * H, H, ACT_NONE,
-                      to_f32(h->qkv + row0 * 3 * H, 3 * H), nullptr, pk.rows, nullptr, ID, nullptr, 1)) return rc;
+    const bool f8 = h->f8 && in.f8;
+    if (f8) {
+        if (int rc = gemm_f8(h, st, in.f8 + row0 * H, H, w.wqkv8, w.wqkvs, w.bqkv, M, 3 * H, H, ACT_NONE, to_f32(h->qkv + row0 * 3 * H, 3 * H), pk.rows)) return rc;
+    } else if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wqkv, w.bqkv, M, 3 * H, H, ACT_NONE,
+                             to_f32(h->qkv + row0 * 3 * H, 3 * H), nullptr, pk.rows, nullptr, ID, nullptr, 1)) return rc;
     AttnParams a{};
     a.q = h->qkv + row0 * 3 * H; a.ldq = 3 * H;
     a.k = a.q + H; a.v = a.q + 2 * H; a.ldkv = 3 * H;
@@ -497,10 +603,13 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     a.o_hi = h->ctx.hi + row0 * H; a.o_lo = h->ctx.lo + row0 * H; a.ldo = H;
     a.B = (int)B;
     a.q_off = a.kv_off = pk.off; a.q_cnt = a.kv_cnt = pk.cnt;
-    attend(h, a, st);
+    if (f8) a.o_f8 = h->ctx.f8 + row0 * H;
+    if (int rc = attend(h, a, st)) return rc;
     const Planes resid = in.at(row0 * H);
-    if (int rc = gemm(h, st, h->ctx.at(row0 * H), H, ID, w.wo, w.bo, M, H, H, ACT_NONE,
-                      to_f32(h->t + row0 * H, H), &resid, pk.rows, nullptr, ID, nullptr, 2)) return rc;
+    if (f8) {
+        if (int rc = gemm_f8(h, st, h->ctx.f8 + row0 * H, H, w.wo8, w.wos, w.bo, M, H, H, ACT_NONE, to_f32(h->t + row0 * H, H), pk.rows)) return rc;
+    } else if (int rc = gemm(h, st, h->ctx.at(row0 * H), H, ID, w.wo, w.bo, M, H, H, ACT_NONE,
+                             to_f32(h->t + row0 * H, H), &resid, pk.rows, nullptr, ID, nullptr, 2)) return rc;
     ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
     return MMS_OK;
 }
@@ -509,8 +618,14 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
 int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes out, int64_t row0, int64_t M, int act,
               const Pack& pk = Pack()) {
     const int I = h->cfg.inter;
-    if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I), nullptr, pk.rows, nullptr, ID, nullptr, 4)) return rc;
     const Planes resid = in.at(row0 * H);
+    if (h->f8 && in.f8) {
+        if (int rc = gemm_f8(h, st, in.f8 + row0 * H, H, w.wi8, w.wis, w.bi, M, I, H, act, to_planes(h->mid, I), pk.rows)) return rc;
+        if (int rc = gemm_f8(h, st, h->mid.f8, I, w.wd8, w.wds, w.bd, M, H, I, ACT_NONE, to_f32(h->t + row0 * H, H), pk.rows)) return rc;
+        ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
+        return MMS_OK;
+    }
+    if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I), nullptr, pk.rows, nullptr, ID, nullptr, 4)) return rc;
     if (int rc = gemm(h, st, h->mid, I, ID, w.wd, w.bd, M, H, I, ACT_NONE, to_f32(h->t + row0 * H, H), &resid, pk.rows, nullptr, ID, nullptr, 8)) return rc;
     ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
     return MMS_OK;
@@ -534,7 +649,7 @@ int last_block_cls(mms_handle* h, hipStream_t st, const AttW& att, const FfnW& f
     a.k = h->qkv + H; a.v = h->qkv + 2 * H; a.ldkv = 3 * H; a.Sk = S;
     a.key_add = key_add; a.kv_off = pk.off; a.kv_cnt = pk.cnt;
     a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo; a.ldo = H; a.B = (int)n;
-    attend(h, a, st);
+    if (int rc = attend(h, a, st)) return rc;
     if (int rc = gemm(h, st, h->ctx, H, ID, att.wo, att.bo, n, H, H, ACT_NONE, to_f32(h->t, H), &in, nullptr, nullptr, cls, pk.off)) return rc;
     ln_resid(h, st, h->t, att.g, att.b, tmp, n, nullptr, in, cls, pk.off);
     const int I = h->cfg.inter;
@@ -558,11 +673,66 @@ int post_launch(mms_handle* h) {
     return MMS_OK;
 }
 
+// Device-side guard: restores the caller's current device when an ABI call returns (the handle may live on another GPU).
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// label-text tuples: dense [B*10, 8] ids -> distinct tuples + per-row index (batchops.hip)
+// ------------------------------------------------------------------------------------------------
+int ensure_dedup_ws(mms_handle* h, int64_t rows) {
+    if (rows <= h->dd_rows) return MMS_OK;
+    free_pool(h->dd_allocs);
+    h->dd_rows = 0;
+    int cap = 1024;
+    while (cap < 2 * rows) cap <<= 1;
+    void* p;
+    if (int rc = dev_alloc(h, h->dd_allocs, &p, (size_t)cap * 4)) return rc;
+    h->dd_slots = (int*)p;
+    if (int rc = dev_alloc(h, h->dd_allocs, &p, (size_t)rows * 4)) return rc;
+    h->dd_rep = (int*)p;
+    if (int rc = dev_alloc(h, h->dd_allocs, &p, (size_t)rows * 4)) return rc;
+    h->dd_uid = (int*)p;
+    if (int rc = dev_alloc(h, h->dd_allocs, &p, (size_t)rows * 4)) return rc;
+    h->dd_index = (int*)p;
+    if (int rc = dev_alloc(h, h->dd_allocs, &p, 16)) return rc;
+    h->dd_counter = (int*)p;
+    if (int rc = dev_alloc(h, h->dd_allocs, &p, (size_t)rows * MMS_LABEL_LEN * 4)) return rc;
+    h->dd_uniq32 = (int32_t*)p;
+    if (int rc = dev_alloc(h, h->dd_allocs, &p, (size_t)rows * MMS_LABEL_LEN * 8)) return rc;
+    h->dd_uniq64 = (int64_t*)p;
+    h->dd_cap = cap;
+    h->dd_rows = rows;
+    return MMS_OK;
+}
+
+// Finds the distinct tuples of ids[rows][8] (T = int32_t: zk feed, int64_t: lxmert feed): h->dd_uniq32 / dd_uniq64 hold them,
+// h->dd_index the row -> tuple index.  *U needs the count on the host: one 4-byte read + stream sync (the dense feed's price;
+// callers that pass uniq_label_ids / label_index themselves stay fully asynchronous).
+template <typename T>
+int dedup_labels(mms_handle* h, hipStream_t st, const T* ids, int64_t rows, int64_t* U) {
+    if (rows > (int64_t)1 << 30) return h->fail(MMS_ERR_ARG, "too many label tuples in one call");
+    if (int rc = ensure_dedup_ws(h, rows)) return rc;
+    if constexpr (sizeof(T) == 4)
+        launch_label_dedup_i32((const int32_t*)ids, (int)rows, h->dd_slots, h->dd_cap, h->dd_rep, h->dd_uid, h->dd_counter, h->dd_uniq32, h->dd_uniq64, h->dd_index, st);
+    else
+        launch_label_dedup_i64((const int64_t*)ids, (int)rows, h->dd_slots, h->dd_cap, h->dd_rep, h->dd_uid, h->dd_counter, h->dd_uniq32, h->dd_uniq64, h->dd_index, st);
+    int n = 0;
+    HIP_TRY(h, hipMemcpyAsync(&n, h->dd_counter, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    *U = n;
+    return MMS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // zk forward
 // ------------------------------------------------------------------------------------------------
 int zk_label_features(mms_handle* h, hipStream_t st, const int32_t* uniq_ids, int64_t U) {
     if (int rc = ensure_label_ws(h, U)) return rc;
+    h->n_labels = U;
     const int KD = MMS_LABEL_LEN * H;
     for (int64_t u0 = 0; u0 < U; u0 += h->lab_cap) {
         const int64_t n = (U - u0) < h->lab_cap ? (U - u0) : h->lab_cap;
@@ -574,19 +744,27 @@ int zk_label_features(mms_handle* h, hipStream_t st, const int32_t* uniq_ids, in
     return MMS_OK;
 }
 
-int zk_chunk(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, int64_t n, float* logits, float* probs) {
-    const mms_config& c = h->cfg;
-    const int T = c.text_len, S = T + MMS_NBOX;
+// image tokens of pairs [p0, p0+n) (model_triple.py:189-195, pixelbert.py:449-452) -> fp32 [n*10,768] at h->qkv + n*10*768 (the
+// QKV buffer is idle until the encoder starts).  The split box features sit in the (still unused) FFN buffer unless the caller
+// already holds them (featp_shared: the fused three-model entry point splits them once for all members).
+int zk_image_tokens(mms_handle* h, hipStream_t st, const mms_zk_batch* b, const int32_t* label_index, int64_t p0, int64_t n,
+                    const Planes* featp_shared = nullptr) {
     const int64_t NB = n * MMS_NBOX;
-    // --- image tokens (model_triple.py:189-195, pixelbert.py:449-452) ---
-    Planes featp = h->mid;  // split box features live in the (still unused) FFN buffer
-    launch_split_f32(b->feats + p0 * MMS_NBOX * MMS_FEAT, featp.hi, featp.lo, NB * MMS_FEAT, st);
-    float* img = h->qkv;                 // [NB,768] fp32, aliases the (still unused) QKV buffer
+    Planes featp = h->mid;
+    if (featp_shared) featp = *featp_shared;
+    else launch_split_f32(b->feats + p0 * MMS_NBOX * MMS_FEAT, featp.hi, featp.lo, NB * MMS_FEAT, st);
+    float* img = h->qkv;                 // [NB,768] fp32
     float* tok = h->qkv + NB * H;        // [NB,768] fp32
     if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_conv2, h->b_conv2, NB, H, MMS_FEAT, ACT_RELU, to_f32(img, H))) return rc;
-    launch_zk_tokpre(h->lab_feat, b->label_index + p0 * MMS_NBOX, b->boxes_5 + p0 * MMS_NBOX * 5, h->w_dense1, h->b_dense1,
+    launch_zk_tokpre(h->lab_feat, label_index + p0 * MMS_NBOX, (int)h->n_labels, b->boxes_5 + p0 * MMS_NBOX * 5, h->w_dense1, h->b_dense1,
                      img, h->ctx.hi, h->ctx.lo, (int)NB, st);
-    if (int rc = gemm(h, st, h->ctx, H, ID, h->w_femb, h->b_femb, NB, H, H, ACT_NONE, to_f32(tok, H))) return rc;
+    return gemm(h, st, h->ctx, H, ID, h->w_femb, h->b_femb, NB, H, H, ACT_NONE, to_f32(tok, H));
+}
+
+// embeddings + encoder + pooler + AM-softmax head of pairs [p0, p0+n) on the image tokens `tok` [n*10,768]
+int zk_encode(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, int64_t n, const float* tok, float* logits, float* probs) {
+    const mms_config& c = h->cfg;
+    const int T = c.text_len, S = T + MMS_NBOX;
     // --- embeddings + mask (packed: live tokens only, laid out contiguously) ---
     Pack pk;
     if (c.pack_tokens) {
@@ -600,6 +778,7 @@ int zk_chunk(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, i
                         c.vocab, h->x.hi, h->x.lo, (int)n, st);
         launch_zk_mask(b->len_query + p0, b->num_boxes + p0, T, h->key_add, (int)n, st);
     }
+    if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, n * S * H, st);   // layer 0's A operand (rows past the live count are never read)
     // --- encoder ---
     const int nl = (c.stop_after >= 0 && c.stop_after < c.layers) ? c.stop_after : c.layers;
     const bool cls_only = c.stop_after < 0 && c.layers > 0;   // debug runs keep the full hidden state
@@ -620,18 +799,26 @@ int zk_chunk(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, i
     return MMS_OK;
 }
 
-int lds_chunk(mms_handle* h, hipStream_t st, const mms_lds_batch* b, int64_t p0, int64_t n, float* logits, float* probs) {
+int zk_chunk(mms_handle* h, hipStream_t st, const mms_zk_batch* b, const int32_t* label_index, int64_t p0, int64_t n, float* logits, float* probs) {
+    if (int rc = zk_image_tokens(h, st, b, label_index, p0, n)) return rc;
+    return zk_encode(h, st, b, p0, n, h->qkv + n * MMS_NBOX * H, logits, probs);
+}
+
+int lds_chunk(mms_handle* h, hipStream_t st, const mms_lds_batch* b, int64_t p0, int64_t n, float* logits, float* probs,
+              const Planes* featp_shared = nullptr) {
     const mms_config& c = h->cfg;
     const int T = c.text_len, S = T + 2 * MMS_NBOX;
     const int64_t NB = n * MMS_NBOX;
     launch_lds_embed_text(h->E, h->type_tab, h->pos_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, b->segment_ids + p0 * T, T, S,
                           c.vocab, h->x.hi, h->x.lo, (int)n, st);
     Planes featp = h->mid;
-    launch_split_f32(b->features + p0 * MMS_NBOX * MMS_FEAT, featp.hi, featp.lo, NB * MMS_FEAT, st);
+    if (featp_shared) featp = *featp_shared;
+    else launch_split_f32(b->features + p0 * MMS_NBOX * MMS_FEAT, featp.hi, featp.lo, NB * MMS_FEAT, st);
     // featureemb (linear) written straight into rows b*S + T + n of the hidden state (pixelmodel.py:600-601)
     if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_feat, h->b_feat, NB, H, MMS_FEAT, ACT_NONE,
                       to_planes(h->x, H, RowMap{MMS_NBOX, S, T}))) return rc;
     launch_lds_label(h->E, h->w_lab8, b->labelfeat + p0 * MMS_NBOX * MMS_LABEL_LEN, c.vocab, S, T + MMS_NBOX, h->x.hi, h->x.lo, (int)n, st);
+    if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, n * S * H, st);
     const int nl = (c.stop_after >= 0 && c.stop_after < c.layers) ? c.stop_after : c.layers;
     const bool cls_only = c.stop_after < 0 && c.layers > 0;
     for (int i = 0; i < nl; ++i) {
@@ -649,6 +836,7 @@ int lds_chunk(mms_handle* h, hipStream_t st, const mms_lds_batch* b, int64_t p0,
 
 int lx_label_features(mms_handle* h, hipStream_t st, const int64_t* uniq_ids, int64_t U) {
     if (int rc = ensure_label_ws(h, U)) return rc;
+    h->n_labels = U;
     for (int64_t u0 = 0; u0 < U; u0 += h->lab_cap) {
         const int64_t n = (U - u0) < h->lab_cap ? (U - u0) : h->lab_cap;
         launch_lx_label_emb(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, h->w_lconv, h->b_lconv, uniq_ids + u0 * MMS_LABEL_LEN,
@@ -659,7 +847,8 @@ int lx_label_features(mms_handle* h, hipStream_t st, const int64_t* uniq_ids, in
     return MMS_OK;
 }
 
-int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p0, int64_t n, float* logits, float* probs) {
+int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int32_t* label_index, int64_t p0, int64_t n, float* logits,
+             float* probs, const Planes* featp_shared = nullptr) {
     const mms_config& c = h->cfg;
     const int T = c.text_len, V = MMS_NBOX;
     // language rows start at 0 (at most ML of them), vision rows start at ML (at most MV of them)
@@ -668,7 +857,8 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
     float* visn_add = h->key_add2;
     Pack pl, pv;
     Planes featp = h->mid;
-    launch_split_f32(b->feats + p0 * V * MMS_FEAT, featp.hi, featp.lo, MV * MMS_FEAT, st);
+    if (featp_shared) featp = *featp_shared;
+    else launch_split_f32(b->feats + p0 * V * MMS_FEAT, featp.hi, featp.lo, MV * MMS_FEAT, st);
     float* xf = h->qkv;
     if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_visn, h->b_visn, MV, H, MMS_FEAT, ACT_NONE, to_f32(xf, H))) return rc;
     if (c.pack_tokens) {
@@ -679,13 +869,14 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
         launch_lx_embed_lang_packed(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->pk_src[0],
                                     h->pk_rows, (int)ML, h->x.hi, h->x.lo, st);
         launch_lx_visn(xf, h->g_visn, h->be_visn, b->boxes + p0 * V * 4, 4, h->w_box, h->b_box, h->g_box, h->be_box, h->lab_feat,
-                       b->label_index + p0 * V, h->x.hi + ML * H, h->x.lo + ML * H, (int)MV, st, h->pk_src[1], h->pk_rows + 1);
+                       label_index + p0 * V, (int)h->n_labels, h->x.hi + ML * H, h->x.lo + ML * H, (int)MV, st, h->pk_src[1], h->pk_rows + 1);
     } else {
         launch_lx_masks(b->input_mask + p0 * T, b->visual_attention_mask + p0 * V, T, lang_add, visn_add, (int)n, st);
         launch_lx_embed_lang(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->x.hi, h->x.lo, (int)n, st);
         launch_lx_visn(xf, h->g_visn, h->be_visn, b->boxes + p0 * V * 4, 4, h->w_box, h->b_box, h->g_box, h->be_box, h->lab_feat,
-                       b->label_index + p0 * V, h->x.hi + ML * H, h->x.lo + ML * H, (int)MV, st);
+                       label_index + p0 * V, (int)h->n_labels, h->x.hi + ML * H, h->x.lo + ML * H, (int)MV, st);
     }
+    if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, R * H, st);
     int budget = c.stop_after >= 0 ? c.stop_after : (1 << 30);
     for (int i = 0; i < c.layers && budget > 0; ++i, --budget) {
         if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, T, n, lang_add, pl)) return rc;
@@ -711,7 +902,7 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
             a.k = h->qkv + ML * 3 * H + H; a.v = h->qkv + ML * 3 * H + 2 * H; a.Sk = V; a.key_add = visn_add;
             a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo;
             a.q_off = pl.off; a.q_cnt = pl.cnt; a.kv_off = pv.off; a.kv_cnt = pv.cnt;
-            attend(h, a, st);
+            if (int rc = attend(h, a, st)) return rc;
             if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
             ln_resid(h, st, h->t, w.cross.g, w.cross.b, h->y, ML, pl.rows, h->x);
             if (int rc = last_block_cls(h, st, w.lang_self, w.lang_ffn, ACT_GELU_ERF, h->y, h->x, T, n, lang_add, pl)) return rc;
@@ -732,12 +923,12 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
         a.k = h->qkv + ML * 3 * H + H; a.v = h->qkv + ML * 3 * H + 2 * H; a.Sk = V; a.key_add = visn_add;
         a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo;
         a.q_off = pl.off; a.q_cnt = pl.cnt; a.kv_off = pv.off; a.kv_cnt = pv.cnt;
-        attend(h, a, st);
+        if (int rc = attend(h, a, st)) return rc;
         a.q = h->qkv + ML * 3 * H; a.Sq = V;                      // visn <- lang
         a.k = h->qkv + H; a.v = h->qkv + 2 * H; a.Sk = T; a.key_add = lang_add;
         a.o_hi = h->ctx.hi + ML * H; a.o_lo = h->ctx.lo + ML * H;
         a.q_off = pv.off; a.q_cnt = pv.cnt; a.kv_off = pl.off; a.kv_cnt = pl.cnt;
-        attend(h, a, st);
+        if (int rc = attend(h, a, st)) return rc;
         if (c.pack_tokens) {
             if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
             const Planes rv = h->x.at(ML * H);
@@ -758,6 +949,7 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t p
     if (trim_last && budget > 0) {   // compact CLS rows were left in y by last_block_cls
         if (int rc = gemm(h, st, h->y, H, ID, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_planes(h->ctx, H))) return rc;
     } else if (int rc = gemm(h, st, h->x, H, RowMap{1, T, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_planes(h->ctx, H), nullptr, nullptr, pl.off)) return rc;
+    if (b->x_norm) launch_xnorm(h->ctx.hi, h->ctx.lo, b->x_norm + p0 * H, (int)n, st);   // kdd_model.py:204-205
     if (int rc = gemm(h, st, h->ctx, H, ID, h->w_fc0, h->b_fc0, n, 2 * H, H, ACT_GELU_ERF, to_f32(h->hbuf, 2 * H))) return rc;
     launch_lx_head(h->hbuf, h->g_fc2, h->be_fc2, h->w_fc3, h->b_fc3, logits + p0 * 2, probs ? probs + p0 * 2 : nullptr, (int)n, st);
     return MMS_OK;
@@ -788,32 +980,39 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
     *out = nullptr;
     if (cfg->model < 0 || cfg->model > 2) { g_err = "bad model id"; return MMS_ERR_ARG; }
     if (cfg->inter <= 0 || cfg->inter % 128) { g_err = "inter must be a positive multiple of 128"; return MMS_ERR_ARG; }
-    if (cfg->precision < 1 || cfg->precision > 3) { g_err = "precision must be 1, 2 or 3"; return MMS_ERR_ARG; }
+    if (cfg->precision < 1 || cfg->precision > 4) { g_err = "precision must be 1, 2, 3 or 4"; return MMS_ERR_ARG; }
     if (cfg->text_len <= 0 || cfg->text_len > 32 || cfg->text_len + 1 > cfg->max_pos) { g_err = "bad text_len"; return MMS_ERR_ARG; }
-    if (cfg->layers < 0 || cfg->vocab <= 0 || cfg->type_vocab <= 0) { g_err = "bad layer/vocab config"; return MMS_ERR_ARG; }
+    if (cfg->layers < 0 || cfg->vocab <= 0 || cfg->type_vocab < 2) { g_err = "bad layer/vocab config (type_vocab must be >= 2: segment ids 0 / 1)"; return MMS_ERR_ARG; }
+    {   // the attention kernels cover sequences of up to 48 tokens (3 x 3 tiles of 16): zk text+10 boxes, lds text+10+10, lxmert text | 10
+        const int seq = cfg->text_len + (cfg->model == MMS_MODEL_ZK ? MMS_NBOX : cfg->model == MMS_MODEL_LDS ? 2 * MMS_NBOX : 0);
+        if (seq > 48) { g_err = "text_len too long: the sequence (" + std::to_string(seq) + " tokens) exceeds the 48-token attention kernels"; return MMS_ERR_ARG; }
+    }
     if (cfg->pack_tokens && cfg->model == MMS_MODEL_LDS) { g_err = "lds has no attention mask: every token is live, pack_tokens must be 0"; return MMS_ERR_ARG; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) { g_err = std::string("no HIP device: ") + hipGetErrorString(e); return MMS_ERR_HIP; }
     if (cfg->device < 0 || cfg->device >= ndev) { g_err = "bad device ordinal"; return MMS_ERR_ARG; }
-    e = hipSetDevice(cfg->device);
-    if (e != hipSuccess) { g_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return MMS_ERR_HIP; }
     mms_handle* h = new mms_handle();
     h->cfg = *cfg;
-    h->nsplit = cfg->precision;
+    h->f8 = cfg->precision == 4;
+    h->nsplit = h->f8 ? 2 : cfg->precision;
+#ifdef MMS_LAB   // A/B knobs exist in libmmscore_lab.so only; the product library reads no environment variable
     if (const char* e = getenv("MMS_X1_MASK")) h->x1_mask = atoi(e);
     if (const char* e = getenv("MMS_RESID_IN_LN")) h->resid_in_ln = atoi(e);
     if (const char* e = getenv("MMS_ALTERNATE")) h->alternate = atoi(e);
+#endif
     *out = h;
     return MMS_OK;
 }
 
 void mms_destroy(mms_handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->cfg.device);
+    DeviceScope dev(h->cfg.device);
     free_pool(h->w_allocs);
     free_pool(h->ws_allocs);
     free_pool(h->lab_allocs);
+    free_pool(h->dd_allocs);
+    free_pool(h->ens_allocs);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     delete h;
 }
@@ -834,9 +1033,14 @@ int mms_load_weight(mms_handle* h, const char* name, const float* host_data, con
 int mms_finalize(mms_handle* h) {
     if (!h) return MMS_ERR_ARG;
     if (h->finalized) return h->fail(MMS_ERR_STATE, "already finalized");
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    DeviceScope dev(h->cfg.device);
     int rc = h->cfg.model == MMS_MODEL_ZK ? finalize_zk(h) : h->cfg.model == MMS_MODEL_LDS ? finalize_lds(h) : finalize_lxmert(h);
-    if (rc) { free_pool(h->w_allocs); return rc; }
+    if (rc) {   // leave nothing dangling: a retry (after loading the missing tensor) starts from a clean handle
+        free_pool(h->w_allocs);
+        h->w_planes.clear(); h->flop_counter = nullptr; h->timing = false;
+        h->layers.clear(); h->r_layers.clear(); h->x_layers.clear();
+        return rc;
+    }
     h->host.clear();
     h->finalized = true;
     return MMS_OK;
@@ -847,16 +1051,24 @@ int mms_score_zk(mms_handle* h, const mms_zk_batch* b, float* logits, float* pro
     const int64_t B = b->n_pairs;
     if (B < 0 || b->n_uniq_labels < 0) return h->fail(MMS_ERR_ARG, "negative batch size");
     if (B == 0) return MMS_OK;
-    if (!b->num_boxes || !b->boxes_5 || !b->feats || !b->uniq_label_ids || !b->label_index || !b->query_ids || !b->len_query ||
-        !b->labels || !b->segment_ids || b->n_uniq_labels == 0)
+    if (!b->num_boxes || !b->boxes_5 || !b->feats || !b->query_ids || !b->len_query || !b->labels || !b->segment_ids)
         return h->fail(MMS_ERR_ARG, "mms_score_zk: null batch field");
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (b->uniq_label_ids ? (!b->label_index || b->n_uniq_labels == 0) : !b->label_ids)
+        return h->fail(MMS_ERR_ARG, "mms_score_zk: pass label_ids (dense) or uniq_label_ids + label_index");
+    DeviceScope dev(h->cfg.device);
     hipStream_t st = (hipStream_t)stream;
     const int cs = chunk_size(h, B);
     if (int rc = ensure_workspace(h, cs)) return rc;
-    if (int rc = zk_label_features(h, st, b->uniq_label_ids, b->n_uniq_labels)) return rc;
+    const int32_t* uniq = b->uniq_label_ids;
+    const int32_t* index = b->label_index;
+    int64_t U = b->n_uniq_labels;
+    if (!uniq) {
+        if (int rc = dedup_labels<int32_t>(h, st, b->label_ids, B * MMS_NBOX, &U)) return rc;
+        uniq = h->dd_uniq32; index = h->dd_index;
+    }
+    if (int rc = zk_label_features(h, st, uniq, U)) return rc;
     for (int64_t p0 = 0; p0 < B; p0 += cs)
-        if (int rc = zk_chunk(h, st, b, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
+        if (int rc = zk_chunk(h, st, b, index, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
     return post_launch(h);
 }
 
@@ -866,7 +1078,7 @@ int mms_score_lds(mms_handle* h, const mms_lds_batch* b, float* logits, float* p
     if (B < 0) return h->fail(MMS_ERR_ARG, "negative batch size");
     if (B == 0) return MMS_OK;
     if (!b->input_ids || !b->segment_ids || !b->features || !b->labelfeat) return h->fail(MMS_ERR_ARG, "mms_score_lds: null batch field");
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    DeviceScope dev(h->cfg.device);
     hipStream_t st = (hipStream_t)stream;
     const int cs = chunk_size(h, B);
     if (int rc = ensure_workspace(h, cs)) return rc;
@@ -880,22 +1092,130 @@ int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, fl
     const int64_t B = b->n_pairs;
     if (B < 0 || b->n_uniq_labels < 0) return h->fail(MMS_ERR_ARG, "negative batch size");
     if (B == 0) return MMS_OK;
-    if (!b->input_ids || !b->input_mask || !b->uniq_label_ids || !b->label_index || !b->feats || !b->boxes ||
-        !b->visual_attention_mask || b->n_uniq_labels == 0)
+    if (!b->input_ids || !b->input_mask || !b->feats || !b->boxes || !b->visual_attention_mask)
         return h->fail(MMS_ERR_ARG, "mms_score_lxmert: null batch field");
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (b->uniq_label_ids ? (!b->label_index || b->n_uniq_labels == 0) : !b->label_ids)
+        return h->fail(MMS_ERR_ARG, "mms_score_lxmert: pass label_ids (dense) or uniq_label_ids + label_index");
+    DeviceScope dev(h->cfg.device);
     hipStream_t st = (hipStream_t)stream;
     const int cs = chunk_size(h, B);
     if (int rc = ensure_workspace(h, cs)) return rc;
-    if (int rc = lx_label_features(h, st, b->uniq_label_ids, b->n_uniq_labels)) return rc;
+    const int64_t* uniq = b->uniq_label_ids;
+    const int32_t* index = b->label_index;
+    int64_t U = b->n_uniq_labels;
+    if (!uniq) {
+        if (int rc = dedup_labels<int64_t>(h, st, b->label_ids, B * MMS_NBOX, &U)) return rc;
+        uniq = h->dd_uniq64; index = h->dd_index;
+    }
+    if (int rc = lx_label_features(h, st, uniq, U)) return rc;
     for (int64_t p0 = 0; p0 < B; p0 += cs)
-        if (int rc = lx_chunk(h, st, b, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
+        if (int rc = lx_chunk(h, st, b, index, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
     return post_launch(h);
+}
+
+// ---- the three models on the same pairs in one call (BASELINE.json config 5; merge of code/main.py:59) ----
+static int ensure_ens_ws(mms_handle* z, int64_t B, int T, int TL) {
+    if (B <= z->ens_pairs) return MMS_OK;
+    free_pool(z->ens_allocs);
+    z->ens_pairs = 0;
+    void* p;
+    auto get = [&](size_t bytes, void** out) { int rc = dev_alloc(z, z->ens_allocs, &p, bytes); *out = p; return rc; };
+    if (int rc = get((size_t)B * (T + MMS_NBOX) * 4, (void**)&z->ens_seg)) return rc;
+    if (int rc = get((size_t)B * T * 8, (void**)&z->ens_ids64)) return rc;
+    if (int rc = get((size_t)B * T * 8, (void**)&z->ens_seg64)) return rc;
+    if (int rc = get((size_t)B * MMS_NBOX * MMS_LABEL_LEN * 8, (void**)&z->ens_lab64)) return rc;
+    if (int rc = get((size_t)B * TL * 8 * 2, (void**)&z->ens_mask64)) return rc;     // lxmert ids, then mask
+    if (int rc = get((size_t)B * MMS_NBOX * 4, (void**)&z->ens_vmask)) return rc;
+    if (int rc = get((size_t)B * MMS_NBOX * 4 * 4, (void**)&z->ens_boxes4)) return rc;
+    if (int rc = get((size_t)B * 2 * 4 * 4, (void**)&z->ens_logits)) return rc;
+    if (int rc = get((size_t)B * 2 * 4 * 4, (void**)&z->ens_probs)) return rc;
+    z->ens_pairs = B;
+    return MMS_OK;
+}
+
+int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_ensemble_batch* b, const float* weights4, float* merged,
+                       float* member_scores, void* stream) {
+    if (!z || !l || !x) return MMS_ERR_ARG;
+    if (int rc = check_ready(z, MMS_MODEL_ZK, b, merged)) return rc;
+    if (int rc = check_ready(l, MMS_MODEL_LDS, b, merged)) return z->fail(rc, "lds handle: " + l->err);
+    if (int rc = check_ready(x, MMS_MODEL_LXMERT, b, merged)) return z->fail(rc, "lxmert handle: " + x->err);
+    if (z->cfg.device != l->cfg.device || z->cfg.device != x->cfg.device) return z->fail(MMS_ERR_ARG, "mms_score_ensemble: the three handles must live on one device");
+    if (z->cfg.text_len != l->cfg.text_len) return z->fail(MMS_ERR_ARG, "mms_score_ensemble: zk and lds must share text_len (one query feed)");
+    if (z->cfg.stop_after >= 0 || l->cfg.stop_after >= 0 || x->cfg.stop_after >= 0) return z->fail(MMS_ERR_ARG, "mms_score_ensemble: debug handles (stop_after) not supported");
+    const int64_t B = b->n_pairs;
+    if (B < 0) return z->fail(MMS_ERR_ARG, "negative batch size");
+    if (B == 0) return MMS_OK;
+    if (!weights4 || !b->feats || !b->boxes_5 || !b->num_boxes || !b->label_ids || !b->query_ids || !b->len_query || !b->s2f_query_ids ||
+        !b->s2f_len_query || !b->labels || !b->lx_input_ids || !b->lx_input_mask)
+        return z->fail(MMS_ERR_ARG, "mms_score_ensemble: null batch field");
+    DeviceScope dev(z->cfg.device);
+    hipStream_t st = (hipStream_t)stream;
+    const int T = z->cfg.text_len, TL = x->cfg.text_len;
+    // one launch-wave size for the three members (the smallest of their chunk settings)
+    int cs = chunk_size(z, B);
+    { const int c2 = chunk_size(l, B), c3 = chunk_size(x, B); cs = c2 < cs ? c2 : cs; cs = c3 < cs ? c3 : cs; }
+    if (int rc = ensure_workspace(z, cs)) return rc;
+    if (int rc = ensure_workspace(l, cs)) return z->fail(rc, "lds handle: " + l->err);
+    if (int rc = ensure_workspace(x, cs)) return z->fail(rc, "lxmert handle: " + x->err);
+    if (int rc = ensure_ens_ws(z, B, T, TL)) return rc;
+    // ---- feeds in each member's own dtypes ----
+    launch_zk_segment_ids(z->ens_seg, B, T, st);                                   // load_data_v4.py:204
+    launch_i32_to_i64(b->query_ids, z->ens_ids64, B * T, st);                      // lds reads the zk query as int64 (run_pretraining_predict_score.py:526-548)
+    launch_fill_i64(z->ens_seg64, B * T, 0, st);
+    launch_i32_to_i64(b->label_ids, z->ens_lab64, B * MMS_NBOX * MMS_LABEL_LEN, st);
+    int64_t* lx_ids = z->ens_mask64;
+    int64_t* lx_mask = z->ens_mask64 + B * TL;
+    launch_i32_to_i64(b->lx_input_ids, lx_ids, B * TL, st);
+    launch_i32_to_i64(b->lx_input_mask, lx_mask, B * TL, st);
+    launch_box_mask(b->num_boxes, z->ens_vmask, B, st);
+    launch_corners(b->boxes_5, z->ens_boxes4, B, st);
+    // ---- label text: distinct tuples once, encoded by zk's conv stack and by lxmert's label encoder ----
+    int64_t U = 0;
+    if (int rc = dedup_labels<int32_t>(z, st, b->label_ids, B * MMS_NBOX, &U)) return rc;
+    if (int rc = zk_label_features(z, st, z->dd_uniq32, U)) return rc;
+    if (int rc = lx_label_features(x, st, z->dd_uniq64, U)) return z->fail(rc, "lxmert handle: " + x->err);
+    const int32_t* index = z->dd_index;
+
+    mms_zk_batch zb{};
+    zb.n_pairs = B; zb.num_boxes = b->num_boxes; zb.boxes_5 = b->boxes_5; zb.feats = b->feats; zb.query_ids = b->query_ids;
+    zb.len_query = b->len_query; zb.labels = b->labels; zb.segment_ids = z->ens_seg;
+    mms_zk_batch zb2 = zb;
+    zb2.query_ids = b->s2f_query_ids; zb2.len_query = b->s2f_len_query;
+    mms_lds_batch lb{};
+    lb.n_pairs = B; lb.input_ids = z->ens_ids64; lb.segment_ids = z->ens_seg64; lb.features = b->feats; lb.labelfeat = z->ens_lab64;
+    mms_lxmert_batch xb{};
+    xb.n_pairs = B; xb.input_ids = lx_ids; xb.input_mask = lx_mask; xb.feats = b->feats; xb.boxes = z->ens_boxes4;
+    xb.visual_attention_mask = z->ens_vmask;
+    float* lg[4]; float* pr[4];
+    for (int k = 0; k < 4; ++k) { lg[k] = z->ens_logits + (int64_t)k * B * 2; pr[k] = z->ens_probs + (int64_t)k * B * 2; }
+
+    // image tokens of a wave survive zk's first encoder pass in a side buffer (the QKV buffer they are built in gets reused)
+    if (!z->ens_tok) {
+        void* p;
+        if (int rc = dev_alloc(z, z->ws_allocs, &p, (size_t)z->ws_pairs * MMS_NBOX * H * 4)) return rc;   // lives and dies with the workspace
+        z->ens_tok = (float*)p;
+    }
+    for (int64_t p0 = 0; p0 < B; p0 += cs) {
+        const int64_t n = (B - p0) < cs ? (B - p0) : cs;
+        const int64_t NB = n * MMS_NBOX;
+        // the 2048-d box features become operand planes ONCE per wave (zk's FFN buffer; zk itself runs last)
+        Planes featp = z->mid;
+        launch_split_f32(b->feats + p0 * MMS_NBOX * MMS_FEAT, featp.hi, featp.lo, NB * MMS_FEAT, st);
+        if (int rc = lds_chunk(l, st, &lb, p0, n, lg[2], pr[2], &featp)) return z->fail(rc, "lds member: " + l->err);
+        if (int rc = lx_chunk(x, st, &xb, index, p0, n, lg[3], pr[3], &featp)) return z->fail(rc, "lxmert member: " + x->err);
+        if (int rc = zk_image_tokens(z, st, &zb, index, p0, n, &featp)) return rc;
+        HIP_TRY(z, hipMemcpyAsync(z->ens_tok, z->qkv + NB * H, (size_t)NB * H * 4, hipMemcpyDeviceToDevice, st));
+        if (int rc = zk_encode(z, st, &zb, p0, n, z->ens_tok, lg[0], pr[0])) return rc;
+        if (int rc = zk_encode(z, st, &zb2, p0, n, z->ens_tok, lg[1], pr[1])) return rc;
+    }
+    const float* prc[4] = {pr[0], pr[1], pr[2], pr[3]};
+    launch_merge4(prc, weights4, merged, member_scores, B, st);
+    return post_launch(z);
 }
 
 int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out, int64_t* launches_out, double* flops_out) {
     if (!h) return MMS_ERR_ARG;
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    DeviceScope dev(h->cfg.device);
     if (!h->flop_counter) {
         void* p;
         if (int rc = dev_alloc(h, h->w_allocs, &p, 8)) return rc;
@@ -965,6 +1285,33 @@ int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const fl
     return MMS_OK;
 }
 
+int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, int64_t N, const float* bias, int32_t act,
+                    int32_t out_f8, float* c_f32, void* stream) {
+    if (!a_f32 || !w_f32_nk || !c_f32 || M <= 0 || N % 256 || K % 128) { g_err = "mms_dbg_gemm_f8: bad argument (N % 256, K % 128)"; return MMS_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char *a8 = nullptr, *w8 = nullptr, *c8 = nullptr;
+    float* ws = nullptr;
+    DBG_TRY(hipMalloc((void**)&a8, (size_t)M * K));
+    DBG_TRY(hipMalloc((void**)&w8, (size_t)N * K));
+    DBG_TRY(hipMalloc((void**)&ws, (size_t)N * 4));
+    launch_f32_to_f8(a_f32, a8, M * K, st);
+    launch_quant_rows_f8(w_f32_nk, w8, ws, (int)N, (int)K, st);
+    GemmParams p{};
+    p.f8 = 1;
+    p.a_hi = (const bf16*)a8; p.a_lo = p.a_hi; p.lda = (int)(K / 2); p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
+    p.w = (const bf16*)w8; p.col_scale = ws; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)(K / 2); p.act = act;
+    if (out_f8) {
+        DBG_TRY(hipMalloc((void**)&c8, (size_t)M * N));
+        p.out_kind = OUT_F8; p.c_f8 = c8; p.ldf8 = (int)N;
+    } else { p.out_kind = OUT_F32; p.c_f32 = c_f32; p.ldc = (int)N; }
+    if (!launch_gemm_pp_f8(p, st)) { g_err = "mms_dbg_gemm_f8: shape not supported"; return MMS_ERR_ARG; }
+    if (out_f8) launch_f8_to_f32(c8, c_f32, M * N, st);
+    DBG_TRY(hipStreamSynchronize(st));
+    DBG_TRY(hipGetLastError());
+    (void)hipFree(a8); (void)hipFree(w8); (void)hipFree(ws); (void)hipFree(c8);
+    return MMS_OK;
+}
+
 __global__ void k_mask_u16(unsigned short* p, long long n, unsigned short mask) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] &= mask;
 }
@@ -990,7 +1337,11 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     DBG_TRY(hipMalloc((void**)&ap, (size_t)M * K * 4)); DBG_TRY(hipMalloc((void**)&wp, (size_t)N * K * 4));
     DBG_TRY(hipMalloc((void**)&rp, (size_t)M * N * 4)); DBG_TRY(hipMalloc((void**)&cp, (size_t)M * N * 4));
     DBG_TRY(hipMalloc((void**)&cf, (size_t)M * N * 4));
+#ifdef MMS_LAB
     const bool zero_fill = getenv("MMS_GB_ZERO") != nullptr;   // DVFS probe: zero operands draw less power (never a bench number)
+#else
+    const bool zero_fill = false;
+#endif
     if (zero_fill) { DBG_TRY(hipMemset(af, 0, (size_t)M * K * 4)); DBG_TRY(hipMemset(wf, 0, (size_t)N * K * 4)); }
     else
     hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, af, M * K, 1u);
@@ -1000,8 +1351,10 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     launch_split_f32(af, ap, ap + M * K, M * K, 0);
     launch_split_f32(wf, wp, wp + N * K, N * K, 0);
     launch_split_f32(rf, rp, rp + M * N, M * N, 0);
+#ifdef MMS_LAB
     if (const char* e = getenv("MMS_GB_LOMASK"))   // power probe: zero the low mantissa bits of the A lo plane
         hipLaunchKernelGGL(k_mask_u16, dim3(4096), dim3(256), 0, 0, (unsigned short*)(ap + M * K), M * K, (unsigned short)strtol(e, nullptr, 16));
+#endif
     GemmParams p{};
     p.a_hi = ap; p.a_lo = ap + M * K; p.lda = (int)K; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
     p.w = wp; p.w_lo = wp + N * K; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
@@ -1038,7 +1391,7 @@ int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B,
     AttnParams a{};
     a.q = q; a.ldq = H; a.k = k; a.v = v; a.ldkv = H; a.q_base = 0; a.Sq = Sq; a.kv_base = 0; a.Sk = Sk;
     a.key_add = key_add; a.o_hi = op; a.o_lo = op + n; a.ldo = H; a.B = (int)B;
-    launch_attention(a, st);
+    if (!launch_attention(a, st)) { (void)hipFree(op); g_err = "mms_dbg_attention: no kernel for this (Sq, Sk)"; return MMS_ERR_ARG; }
     launch_planes_to_f32(op, op + n, out_f32, n, st);
     DBG_TRY(hipStreamSynchronize(st));
     DBG_TRY(hipGetLastError());

@@ -155,6 +155,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
             const int i = qt * 16 + fk * 4 + r;
             if (i >= Sq) continue;
             const long long off = (long long)(p.o_compact ? b : q0 + i) * p.ldo + h * MMS_HEAD_DIM + fr * 4;
+            if (p.o_f8) {   // precision mode 4: the context feeds an fp8 GEMM, nothing else reads it
+                *reinterpret_cast<unsigned*>(p.o_f8 + off) = pack4_f8(o[qt][0][r], o[qt][1][r], o[qt][2][r], o[qt][3][r]);
+                continue;
+            }
             bf16x4 hi, lo;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -168,13 +172,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         }
 }
 
-void launch_attention(const AttnParams& p, hipStream_t st) {
+// false: no instantiation covers (Sq, Sk) -- sequences beyond 48 tokens; the caller must turn that into an error (a silent
+// no-op would leave stale context rows behind and score garbage)
+bool launch_attention(const AttnParams& p, hipStream_t st) {
     const int qt = (p.Sq + 15) / 16, kt = (p.Sk + 15) / 16;
     const dim3 grid((p.B * MMS_HEADS + 3) / 4), block(256);
-    if (p.B <= 0) return;
+    if (p.B <= 0) return true;
 #define ATTN_CASE(Q, K) \
-    if (qt == Q && kt == K) { hipLaunchKernelGGL((attn_kernel<Q, K>), grid, block, 0, st, p); return; }
+    if (qt == Q && kt == K) { hipLaunchKernelGGL((attn_kernel<Q, K>), grid, block, 0, st, p); return true; }
     ATTN_CASE(1, 1) ATTN_CASE(1, 2) ATTN_CASE(2, 1) ATTN_CASE(2, 2) ATTN_CASE(3, 3)
     ATTN_CASE(1, 3) ATTN_CASE(3, 1) ATTN_CASE(2, 3) ATTN_CASE(3, 2)
 #undef ATTN_CASE
+    return false;
 }

@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define MMS_LN_EPS 1e-12f
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU_TANH = 2, ACT_GELU_ERF = 3, ACT_TANH = 4 };
-enum { OUT_F32 = 0, OUT_PLANES = 1 };
+enum { OUT_F32 = 0, OUT_PLANES = 1, OUT_F8 = 2 };
 
 __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
     hi = (bf16)v;                 // v_cvt_pk_bf16_f32: round-to-nearest-even
@@ -32,6 +32,16 @@ __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
 }
 
 __device__ __forceinline__ float join_bf16(bf16 hi, bf16 lo) { return (float)hi + (float)lo; }
+
+// fp32 -> OCP e4m3fn, round-to-nearest-even, saturating at +-448 (precision mode 4).  v_cvt_pk_fp8_f32 packs two values into
+// one 16-bit half of a dword; the clamp makes the result independent of the instruction's overflow convention.
+__device__ __forceinline__ unsigned pack4_f8(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
 
 // Fast transcendental forms for the GEMM epilogues.  Absolute error <= ~2e-7 (v_exp_f32 / v_rcp_f32 are ~1 ulp),
 // entering GELU only through (1 + t): far inside the 1e-3 logit budget, ~6x fewer VALU ops than libm tanhf/erff.

@@ -1,3 +1,5 @@
+// LAB ONLY (libmmscore_lab.so, `make lab`): the first-generation GEMM kept for A/B runs -- not part of libmmscore.so.
+//
 // bf16 MFMA GEMM with split-plane activations and fused epilogues (gfx950).
 //
 // Covers every dense contraction of the three reference forwards:
@@ -160,44 +162,11 @@ static void launch_ns(const GemmParams& p, int nblk, hipStream_t st) {
     }
 }
 
-static int g_variant = -1;
-void set_gemm_variant(int v) { g_variant = v; }
-int get_gemm_variant() {
-    if (g_variant < 0) {
-        const char* e = getenv("MMS_GEMM_VARIANT");
-        g_variant = e ? atoi(e) : 99;  // 99 = auto: per-shape choice between the two best measured tiles (profiles/r01c_gemm_variants.txt)
-    }
-    return g_variant;
-}
 
-void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
+// lab entry: the v0 128x128 register-staged kernel (no device-side row count)
+void launch_gemm_v0(const GemmParams& p, int nsplit, hipStream_t st) {
     const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
     if (nblk <= 0) return;
-    int variant = get_gemm_variant();
-    if (nsplit == 3) {   // three passes: 256x128 ping-pong phases for large M (variant 27 forces it), 128x128 tile otherwise
-        if ((variant == 27 || (variant == 99 && p.M >= 16384)) && launch_gemm_ppw(p, st)) return;
-        launch_gemm_tile(p, 3, 1, st);
-        return;
-    }
-    if (variant > 100) {   // timing diagnostics (101-103 ring, 201-232 ping-pong): they compute WRONG results on purpose, so they are only
-                           // honoured when MMS_GEMM_DIAG is set as well; otherwise fall back to the per-shape default
-        static const bool diag_ok = getenv("MMS_GEMM_DIAG") != nullptr;
-        if (diag_ok && variant > 200 && variant < 233 && launch_gemm_pp(p, nsplit, variant - 200, st)) return;
-        if (diag_ok && variant >= 101 && variant <= 103 && launch_gemm_ring(p, nsplit, variant, st)) return;
-        variant = 99;
-    }
-    if (variant == 99) {  // auto (profiles/r01c_gemm_variants.txt): 256x256 ping-pong phases for large M; for the small GEMMs
-                          // (CLS-only last block, poolers) 256x256 / 16 waves on wide outputs, 128x256 / 8 waves otherwise
-        if (p.N % 256 == 0 && p.M >= 16384) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)
-        else variant = (p.N >= 1536 && p.N % 256 == 0 && p.M >= 8192) ? 16 : 4;
-    }
-    if (variant == 0 && (p.m_dev || p.flop_counter)) variant = 1;   // the v0 kernel has no device-side row count
-    if (variant == 26) { if (launch_gemm_pp(p, nsplit, 0, st, true)) return; variant = 4; }
-    if (variant == 20) { if (launch_gemm_pp(p, nsplit, 0, st)) return; variant = 4; }
-    if (variant == 11 && launch_gemm_ring(p, nsplit, 4, st)) return;
-    if (variant == 12 && launch_gemm_ring(p, nsplit, 2, st)) return;
-    if (variant > 0 && launch_gemm_tile(p, nsplit, variant, st)) return;
-    if (variant > 0 && launch_gemm_tile(p, nsplit, 1, st)) return;   // N % 256 != 0: 128x128 tile
     if (nsplit == 2) launch_ns<2>(p, nblk, st);
     else launch_ns<1>(p, nblk, st);
 }

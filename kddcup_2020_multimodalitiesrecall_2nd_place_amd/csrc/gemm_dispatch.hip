@@ -1,0 +1,62 @@
+// GEMM dispatch: which tile engine runs a given (M, N, K, passes) contraction.
+//
+// Product library (libmmscore.so): per-shape choice between the kernels a forward can launch -- the 256x256 persistent ping-pong
+// engine (gemm_pp.hip) for the big encoder GEMMs, its 256x128 three-pass cut (gemm_ppw.hip) for precision mode 3, and the
+// register-staged tiles of gemm_tile.hip for the small ones (CLS-only last block, poolers, heads, label text).  No environment
+// variable is read here.  `set_gemm_variant` is a TEST hook (mms_set_gemm_variant): it can only select among these product kernels.
+//
+// Lab library (libmmscore_lab.so, `make lab`, -DMMS_LAB): additionally honours MMS_GEMM_VARIANT and reaches the superseded A/B
+// kernels (gemm.hip v0, gemm_ring.hip, the LDS-DMA double-buffer tile) and -- with MMS_GEMM_DIAG -- the timing-only DIAG
+// instantiations of gemm_pp.hip, which compute WRONG results by design.  None of that code is in the product binary.
+#include <cstdlib>
+
+#include "kernels.h"
+
+static int g_variant = -1;
+void set_gemm_variant(int v) { g_variant = v; }
+int get_gemm_variant() {
+    if (g_variant < 0) {
+#ifdef MMS_LAB
+        const char* e = getenv("MMS_GEMM_VARIANT");
+        g_variant = e ? atoi(e) : 99;
+#else
+        g_variant = 99;  // auto: per-shape choice between the best measured tiles (profiles/r01c_gemm_variants.txt)
+#endif
+    }
+    return g_variant;
+}
+
+void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0) return;
+    int variant = get_gemm_variant();
+    if (nsplit == 3) {   // three passes: 256x128 ping-pong phases for large M (variant 27 forces it), 128x128 tile otherwise
+        if ((variant == 27 || (variant == 99 && p.M >= 16384)) && launch_gemm_ppw(p, st)) return;
+        launch_gemm_tile(p, 3, 1, st);
+        return;
+    }
+#ifdef MMS_LAB
+    if (variant > 100) {   // timing diagnostics (101-103 ring, 201-232 ping-pong): WRONG results on purpose, only with MMS_GEMM_DIAG
+        static const bool diag_ok = getenv("MMS_GEMM_DIAG") != nullptr;
+        if (diag_ok && variant > 200 && variant < 233 && launch_gemm_pp(p, nsplit, variant - 200, st)) return;
+        if (diag_ok && variant >= 101 && variant <= 103 && launch_gemm_ring(p, nsplit, variant, st)) return;
+        variant = 99;
+    }
+    if (variant == 0 && !(p.m_dev || p.flop_counter)) { launch_gemm_v0(p, nsplit, st); return; }
+    if (variant == 11 && launch_gemm_ring(p, nsplit, 4, st)) return;
+    if (variant == 12 && launch_gemm_ring(p, nsplit, 2, st)) return;
+#endif
+    if (variant != 1 && variant != 4 && variant != 16 && variant != 20 && variant != 26
+#ifdef MMS_LAB
+        && variant != 3
+#endif
+    ) variant = 99;
+    if (variant == 99) {  // auto (profiles/r01c_gemm_variants.txt): 256x256 ping-pong phases for large M; for the small GEMMs
+                          // (CLS-only last block, poolers) 256x256 / 16 waves on wide outputs, 128x256 / 8 waves otherwise
+        if (p.N % 256 == 0 && p.M >= 16384) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)
+        else variant = (p.N >= 1536 && p.N % 256 == 0 && p.M >= 8192) ? 16 : 4;
+    }
+    if (variant == 26) { if (launch_gemm_pp(p, nsplit, 0, st, true)) return; variant = 4; }
+    if (variant == 20) { if (launch_gemm_pp(p, nsplit, 0, st)) return; variant = 4; }
+    if (launch_gemm_tile(p, nsplit, variant, st)) return;
+    launch_gemm_tile(p, nsplit, 1, st);   // N % 256 != 0: 128x128 tile
+}

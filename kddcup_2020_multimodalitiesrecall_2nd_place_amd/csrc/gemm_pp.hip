@@ -55,8 +55,12 @@ __device__ __forceinline__ void pp_barrier() {
 
 // DIAG (timing diagnostics only, results WRONG): bit 0 drops the phase barriers, bit 1 the in-loop LDS-DMA issue, bit 2 the in-loop ds_reads,
 // bit 3 re-reads the first two K-stages (always cache hits)
-template <int NSPLIT, int ACT, int DIAG, bool PERSIST>
+// F8 (precision mode 4): the A and W planes hold e4m3 bytes -- a 64-byte stage row is 64 k-values instead of 32 -- and every
+// fragment pair feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (the low and the high 8 bytes of the ds_read_b128; the k order inside the
+// contraction is the same permutation in both operands).  Staging, ring, phases and epilogue are the bf16 engine's.
+template <int NSPLIT, int ACT, int DIAG, bool PERSIST, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
+    static_assert(!F8 || NSPLIT == 1, "fp8 operands are single-plane");
     constexpr int BM = 256, BN = 256, WAVES_N = 4, NW = 8, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int PLANE = 256 * 64;                 // one operand plane of a stage: 256 rows x 32 bf16
     constexpr int SLOT = (NSPLIT + 1) * PLANE;
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     int Meff = p.M;
     if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
     if (!(DIAG & 32) && p.flop_counter && blockIdx.x == 0 && tid == 0)
-        atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
+        atomicAdd(p.flop_counter, (F8 ? 4ull : 2ull) * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
     const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM, nblk = nbm * nbn;
     int vb = blockIdx.x;                 // virtual block id; PERSIST: the workgroup walks vb, vb + gridDim.x, ... (gridDim.x % 8 == 0)
     if (vb >= nblk) return;
@@ -137,8 +141,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (F8) {
+                        typedef __attribute__((ext_vector_type(2))) long i64x2;
+                        const i64x2 bw = __builtin_bit_cast(i64x2, b[j]), aw = __builtin_bit_cast(i64x2, a[pl][i]);
+                        acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bw[0], aw[0], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+                        acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bw[1], aw[1], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+                    } else
                     acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[pl][i], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);   // swapped: C^T fragment
+                }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -257,22 +268,31 @@ static int pp_cu_count() {
     return n_cu;
 }
 
-template <int NSPLIT, int DIAG, bool PERSIST = false>
+template <int NSPLIT, int DIAG, bool PERSIST = false, bool F8 = false>
 static void launch_pp_ns(const GemmParams& p, hipStream_t st) {
     const int nblk = ((p.M + 255) / 256) * (p.N / 256);
     const dim3 grid(PERSIST && nblk > pp_cu_count() ? pp_cu_count() : nblk), block(512);
     switch (p.act) {
-        case ACT_RELU: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_RELU, DIAG, PERSIST>), grid, block, 0, st, p); break;
-        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_TANH, DIAG, PERSIST>), grid, block, 0, st, p); break;
-        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_ERF, DIAG, PERSIST>), grid, block, 0, st, p); break;
-        case ACT_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_TANH, DIAG, PERSIST>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_NONE, DIAG, PERSIST>), grid, block, 0, st, p); break;
+        case ACT_RELU: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_RELU, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
+        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_TANH, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
+        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_ERF, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
+        case ACT_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_TANH, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_NONE, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
     }
+}
+
+// precision mode 4: e4m3 operands (p.f8 set; p.lda / p.K in byte PAIRS), any M, N % 256 == 0, K (in fp8 elements) % 128 == 0
+bool launch_gemm_pp_f8(const GemmParams& p, hipStream_t st) {
+    if (p.M <= 0) return true;
+    if (!p.f8 || p.N % 256 || p.K % 64) return false;
+    launch_pp_ns<1, 0, true, true>(p, st);
+    return true;
 }
 
 bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist) {
     if (p.M <= 0) return true;
     if (p.N % 256 || p.K % 64 || nsplit > 2) return false;
+#ifdef MMS_LAB
     if (diag) {   // timing diagnostics (two-pass only)
         if (nsplit != 2) return false;
         switch (diag) {
@@ -297,6 +317,9 @@ bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, b
         }
         return true;
     }
+#else
+    if (diag) return false;   // the timing-only (wrong-result) instantiations exist in libmmscore_lab.so only
+#endif
     if (persist) { if (nsplit == 2) launch_pp_ns<2, 0, true>(p, st); else launch_pp_ns<1, 0, true>(p, st); }
     else if (nsplit == 2) launch_pp_ns<2, 0>(p, st); else launch_pp_ns<1, 0>(p, st);
     return true;

@@ -15,6 +15,14 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
     f32x4 bias4[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.col_scale) {   // fp8 weights: the accumulator is in units of the weight row's quantisation scale
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.col_scale + col + 16 * j);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) acc[i][j] *= s4;
+        }
+    }
     const bool f32_out = p.out_kind == OUT_F32, resid = p.r_hi != nullptr;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -44,6 +52,12 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
                 for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT);
                 *reinterpret_cast<f32x4*>(dst + 16 * j) = v;
             }
+        } else if (p.out_kind == OUT_F8) {
+            unsigned char* d8 = p.c_f8 + orow * p.ldf8 + col;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<unsigned*>(d8 + 16 * j) = pack4_f8(apply_act(acc[i][j][0], ACT), apply_act(acc[i][j][1], ACT),
+                                                                     apply_act(acc[i][j][2], ACT), apply_act(acc[i][j][3], ACT));
         } else {
             bf16* dh = p.c_hi + orow * p.ldp + col;
             bf16* dl = p.c_lo + orow * p.ldp + col;

@@ -25,13 +25,21 @@ struct GemmParams {
     RowMap rmap; const int* r_index;  // residual row of logical row r: r_index ? r_index[r] : rmap(r)
     unsigned long long* flop_counter;  // optional: block 0 adds 2*M_eff*N*K (executed algorithmic FLOPs)
     int reverse;                 // 1: walk the tiles from the last row panel to the first (cache-direction alternation, api.hip)
+    // precision mode 4 (fp8 operands, gemm_pp.hip only): a_hi / w point at e4m3 bytes and lda / K count PAIRS of them (= the same
+    // 2-byte units as the bf16 planes, so every address in the tile engine is unchanged); col_scale[n] = the weight row's
+    // quantisation scale, applied to the accumulator before the bias; OUT_F8 stores e4m3 bytes at c_f8[row * ldf8 + col]
+    int f8;
+    const float* col_scale;
+    unsigned char* c_f8; int ldf8;
 };
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
+void launch_gemm_v0(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm.hip (lab only)
 bool launch_gemm_ring(const GemmParams& p, int nsplit, int nslot, hipStream_t st);      // gemm_ring.hip (variants 11: 4 slots, 12: 2 slots)
 bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist = false);                     // gemm_pp.hip (variant 20: 256x256 ping-pong phases)
+bool launch_gemm_pp_f8(const GemmParams& p, hipStream_t st);                            // gemm_pp.hip with e4m3 operands (precision mode 4)
 bool launch_gemm_ppw(const GemmParams& p, hipStream_t st);                               // gemm_ppw.hip: precision mode 3 (A and W split), 256x128 ping-pong phases
-void set_gemm_variant(int v);   // 0 = gemm.hip kernel, >0 = gemm_tile.hip configurations
+void set_gemm_variant(int v);   // test hook, see gemm_dispatch.hip
 int get_gemm_variant();
 
 // ---------------------------------------------------------------------------------------------
@@ -44,6 +52,7 @@ struct AttnParams {
     int q_base, Sq, kv_base, Sk;
     const float* key_add;        // additive mask indexed by kv row (relative to kv_base) or nullptr
     bf16* o_hi; bf16* o_lo; int ldo;
+    unsigned char* o_f8;         // precision mode 4: the context goes out as e4m3 bytes (same row stride ldo) INSTEAD of the planes
     int B;
     // packed (ragged) mode: per-pair first row and live-token count; nullptr = dense (b*S, S).
     // Sq / Sk are then the MAXIMUM lengths (tile selection).
@@ -52,13 +61,14 @@ struct AttnParams {
     int o_compact;               // 1: Sq == 1 and the output row is b (CLS-only last layer)
     int reverse;                 // 1: last pair first
 };
-void launch_attention(const AttnParams& p, hipStream_t st);
+bool launch_attention(const AttnParams& p, hipStream_t st);   // false: (Sq, Sk) beyond the instantiated tiles (> 48 tokens)
 
 // ---------------------------------------------------------------------------------------------
 // Row-wise kernels (one wavefront per 768-wide row)                   (rowops.hip)
 // ---------------------------------------------------------------------------------------------
 // optional residual of the LayerNorm input: row r adds planes row (r_index ? r_index[r] : rmap(r)) before normalising
-struct LnResid { const bf16* hi = nullptr; const bf16* lo = nullptr; int ld = 0; RowMap rmap{0, 0, 0}; const int* r_index = nullptr; int reverse = 0; };
+struct LnResid { const bf16* hi = nullptr; const bf16* lo = nullptr; int ld = 0; RowMap rmap{0, 0, 0}; const int* r_index = nullptr; int reverse = 0;
+                 unsigned char* o_f8 = nullptr; };   // o_f8: additionally write the row as e4m3 bytes (row stride ldo; precision mode 4)
 void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta,
                          bf16* o_hi, bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev = nullptr, LnResid res = LnResid());
 void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipStream_t st);
@@ -67,7 +77,7 @@ void launch_mean8(const float* in, float* out, int U, hipStream_t st);
 
 // zk (code/imagebert_zk/model_triple.py:162-214, pixelbert.py:541-621)
 void launch_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab, bf16* o_hi, bf16* o_lo, hipStream_t st);
-void launch_zk_tokpre(const float* labfeat, const int* lab_index, const float* boxes5, const float* Wd,
+void launch_zk_tokpre(const float* labfeat, const int* lab_index, int n_labels, const float* boxes5, const float* Wd,
                       const float* bd, const float* img, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st);
 void launch_zk_embed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
                      const float* beta, const int* query_ids, const int* segment_ids, const float* tok,
@@ -108,10 +118,34 @@ void launch_lx_label_emb(const float* E, const float* pos_tab, const float* type
                          const int64_t* uniq_ids, int vocab, bf16* o_hi, bf16* o_lo, int U, hipStream_t st);
 void launch_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes, int box_dim,
                     const float* Wb, const float* bb, const float* g_y, const float* b_y, const float* z,
-                    const int* lab_index, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st,
+                    const int* lab_index, int n_labels, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st,
                     const int* src = nullptr, const int* rows_dev = nullptr);
 void launch_ln_f32(const float* in, const float* gamma, const float* beta, float* out, int M, hipStream_t st);
 void launch_lx_masks(const int64_t* input_mask, const float* visual_mask, int T, float* lang_add,
                      float* visn_add, int B, hipStream_t st);
 void launch_lx_head(const float* h, const float* gamma, const float* beta, const float* W, const float* b,
                     float* logits, float* probs, int B, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Per-batch bookkeeping (batchops.hip): label-tuple de-duplication, feed conversions of the fused three-model entry point
+// ---------------------------------------------------------------------------------------------
+// slots: int[cap], cap a power of two >= 2 * rows; rep / uid / index: int[rows]; counter: int (number of distinct tuples on return);
+// uniq32 / uniq64: [rows,8] worst case, either may be nullptr
+void launch_label_dedup_i32(const int32_t* ids, int rows, int* slots, int cap, int* rep, int* uid, int* counter, int32_t* uniq32,
+                            int64_t* uniq64, int* index, hipStream_t st);
+void launch_label_dedup_i64(const int64_t* ids, int rows, int* slots, int cap, int* rep, int* uid, int* counter, int32_t* uniq32,
+                            int64_t* uniq64, int* index, hipStream_t st);
+void launch_i32_to_i64(const int32_t* in, int64_t* out, long long n, hipStream_t st);
+void launch_fill_i64(int64_t* out, long long n, int64_t v, hipStream_t st);
+void launch_zk_segment_ids(int32_t* out, long long B, int T, hipStream_t st);
+void launch_box_mask(const int32_t* num_boxes, float* mask, long long B, hipStream_t st);
+void launch_corners(const float* boxes5, float* boxes4, long long B, hipStream_t st);
+void launch_merge4(const float* const probs[4], const float w[4], float* merged, float* members, long long n, hipStream_t st);
+void launch_xnorm(const bf16* hi, const bf16* lo, float* out, int rows, hipStream_t st);
+
+// precision mode 4 helpers (rowops.hip)
+void launch_planes_to_f8(const bf16* hi, const bf16* lo, unsigned char* out, long long n, hipStream_t st);
+void launch_f32_to_f8(const float* in, unsigned char* out, long long n, hipStream_t st);
+void launch_f8_to_f32(const unsigned char* in, float* out, long long n, hipStream_t st);
+// weight rows [N][K] fp32 -> e4m3 bytes + one power-of-two scale per row: the smallest 2^e with max|w| / 2^e <= 448
+void launch_quant_rows_f8(const float* w, unsigned char* out, float* scale, int N, int K, hipStream_t st);

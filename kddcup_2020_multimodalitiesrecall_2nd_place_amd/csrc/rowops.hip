@@ -78,6 +78,11 @@ __device__ __forceinline__ void row_ln(Row& x, const float* gamma, const float* 
         x.v[t * 4 + 3] = (x.v[t * 4 + 3] - mean) * inv * g.w + b.w;
     }
 }
+__device__ __forceinline__ void row_store_f8(const Row& x, unsigned char* p) {   // e4m3 bytes, 4 per lane per 256-column third
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        *reinterpret_cast<unsigned*>(p + t * 256 + lane_id() * 4) = pack4_f8(x.v[t * 4], x.v[t * 4 + 1], x.v[t * 4 + 2], x.v[t * 4 + 3]);
+}
 __device__ __forceinline__ long long clamp_id(long long id, int vocab) {
     return id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
 }
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(256) void k_ln_to_planes(const float* in, int ld, c
     }
     row_ln(x, gamma, beta);
     row_store_planes(x, o_hi + (long long)row * ldo, o_lo + (long long)row * ldo);
+    if (res.o_f8) row_store_f8(x, res.o_f8 + (long long)row * ldo);
 }
 void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta, bf16* o_hi,
                          bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev, LnResid res) {
@@ -166,6 +172,66 @@ void launch_planes_to_f32(const bf16* hi, const bf16* lo, float* out, long long 
     hipLaunchKernelGGL(k_planes_to_f32, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, hi, lo, out, n4);
 }
 
+// ---- precision mode 4: e4m3 operand bytes ----
+__global__ __launch_bounds__(256) void k_planes_to_f8(const bf16* hi, const bf16* lo, unsigned* out, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const bf16x4 h = reinterpret_cast<const bf16x4*>(hi)[i];
+        const bf16x4 l = reinterpret_cast<const bf16x4*>(lo)[i];
+        out[i] = pack4_f8(join_bf16(h[0], l[0]), join_bf16(h[1], l[1]), join_bf16(h[2], l[2]), join_bf16(h[3], l[3]));
+    }
+}
+void launch_planes_to_f8(const bf16* hi, const bf16* lo, unsigned char* out, long long n, hipStream_t st) {
+    const long long n4 = n / 4;
+    if (n4 > 0) hipLaunchKernelGGL(k_planes_to_f8, dim3((unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256)), dim3(256), 0, st, hi, lo, (unsigned*)out, n4);
+}
+__global__ __launch_bounds__(256) void k_f32_to_f8(const float4* in, unsigned* out, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 f = in[i];
+        out[i] = pack4_f8(f.x, f.y, f.z, f.w);
+    }
+}
+void launch_f32_to_f8(const float* in, unsigned char* out, long long n, hipStream_t st) {
+    const long long n4 = n / 4;
+    if (n4 > 0) hipLaunchKernelGGL(k_f32_to_f8, dim3((unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256)), dim3(256), 0, st, (const float4*)in, (unsigned*)out, n4);
+}
+__device__ __forceinline__ float e4m3_to_f32(unsigned v) {   // OCP e4m3fn decode
+    const unsigned s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+    float x = e == 0 ? ldexpf((float)m, -9) : ldexpf(1.0f + m * 0.125f, (int)e - 7);
+    if (e == 15 && m == 7) x = __builtin_nanf("");
+    return s ? -x : x;
+}
+__global__ __launch_bounds__(256) void k_f8_to_f32(const unsigned char* in, float* out, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = e4m3_to_f32(in[i]);
+}
+void launch_f8_to_f32(const unsigned char* in, float* out, long long n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_f8_to_f32, dim3((unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256)), dim3(256), 0, st, in, out, n);
+}
+// one wavefront per weight row: scale = the smallest power of two with max|w| / scale <= 448 (division by it is exact), bytes = e4m3(w / scale)
+__global__ __launch_bounds__(256) void k_quant_rows_f8(const float* w, unsigned char* out, float* scale, int N, int K) {
+    const int row = wave_row();
+    if (row >= N) return;
+    const float* src = w + (long long)row * K;
+    float m = 0.f;
+    for (int k = lane_id() * 4; k < K; k += 256) {
+        const float4 f = *reinterpret_cast<const float4*>(src + k);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    int ex = 0;
+    const float fr = frexpf(m, &ex);                       // m = fr * 2^ex, fr in [0.5, 1); 448 = 0.875 * 2^9
+    const int e = m > 0.f ? (fr <= 0.875f ? ex - 9 : ex - 8) : 0;
+    const float inv = ldexpf(1.0f, -e);
+    if (lane_id() == 0) scale[row] = ldexpf(1.0f, e);
+    for (int k = lane_id() * 4; k < K; k += 256) {
+        const float4 f = *reinterpret_cast<const float4*>(src + k);
+        *reinterpret_cast<unsigned*>(out + (long long)row * K + k) = pack4_f8(f.x * inv, f.y * inv, f.z * inv, f.w * inv);
+    }
+}
+void launch_quant_rows_f8(const float* w, unsigned char* out, float* scale, int N, int K, hipStream_t st) {
+    if (N > 0) hipLaunchKernelGGL(k_quant_rows_f8, row_grid(N), dim3(256), 0, st, w, out, scale, N, K);
+}
+
 __global__ __launch_bounds__(256) void k_mean8(const float* in, float* out, int U) {
     const int row = wave_row();
     if (row >= U) return;
@@ -204,23 +270,23 @@ void launch_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab, bf1
 }
 
 // model_triple.py:190-195: mean(relu(conv1)) [by unique label] + kdd_dense1(boxes_5) + relu(conv2(feats))
-__global__ __launch_bounds__(256) void k_zk_tokpre(const float* labfeat, const int* lab_index, const float* boxes5,
+__global__ __launch_bounds__(256) void k_zk_tokpre(const float* labfeat, const int* lab_index, int n_labels, const float* boxes5,
                                                    const float* Wd, const float* bd, const float* img,
                                                    bf16* o_hi, bf16* o_lo, int rows) {
     const int row = wave_row();
     if (row >= rows) return;
     Row x;
-    row_load(x, labfeat + (long long)lab_index[row] * MMS_HIDDEN);
+    row_load(x, labfeat + clamp_id(lab_index[row], n_labels) * MMS_HIDDEN);   // a bad index must not read outside the table
     row_add(x, bd);
 #pragma unroll
     for (int k = 0; k < 5; ++k) row_axpy(x, boxes5[(long long)row * 5 + k], Wd + k * MMS_HIDDEN);
     row_add(x, img + (long long)row * MMS_HIDDEN);
     row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
 }
-void launch_zk_tokpre(const float* labfeat, const int* lab_index, const float* boxes5, const float* Wd,
+void launch_zk_tokpre(const float* labfeat, const int* lab_index, int n_labels, const float* boxes5, const float* Wd,
                       const float* bd, const float* img, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st) {
     if (rows > 0)
-        hipLaunchKernelGGL(k_zk_tokpre, row_grid(rows), dim3(256), 0, st, labfeat, lab_index, boxes5, Wd, bd, img, o_hi, o_lo, rows);
+        hipLaunchKernelGGL(k_zk_tokpre, row_grid(rows), dim3(256), 0, st, labfeat, lab_index, n_labels, boxes5, Wd, bd, img, o_hi, o_lo, rows);
 }
 
 // pixelbert.py:580-621: concat text || image tokens, + token_type[segment_ids], + positions
@@ -444,7 +510,7 @@ void launch_lx_label_emb(const float* E, const float* pos_tab, const float* type
 // VisualFeatEncoder, modeling.py:519-531: (LN(Wf f) + LN(Wb b) + LN(Wl conv(label))) / 3
 __global__ __launch_bounds__(256) void k_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes,
                                                  int box_dim, const float* Wb, const float* bb, const float* g_y,
-                                                 const float* b_y, const float* z, const int* lab_index,
+                                                 const float* b_y, const float* z, const int* lab_index, int n_labels,
                                                  bf16* o_hi, bf16* o_lo, int rows, const int* src_map, const int* rows_dev) {
     const int orow = wave_row();
     if (orow >= rows || (rows_dev && orow >= *rows_dev)) return;
@@ -463,18 +529,18 @@ __global__ __launch_bounds__(256) void k_lx_visn(const float* xf, const float* g
     }
     row_ln(y, g_y, b_y);
     Row zz;
-    row_load(zz, z + (long long)lab_index[row] * MMS_HIDDEN);
+    row_load(zz, z + clamp_id(lab_index[row], n_labels) * MMS_HIDDEN);
 #pragma unroll
     for (int i = 0; i < 12; ++i) x.v[i] = (x.v[i] + y.v[i] + zz.v[i]) / 3.0f;
     row_store_planes(x, o_hi + (long long)orow * MMS_HIDDEN, o_lo + (long long)orow * MMS_HIDDEN);
 }
 void launch_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes, int box_dim,
                     const float* Wb, const float* bb, const float* g_y, const float* b_y, const float* z,
-                    const int* lab_index, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st, const int* src,
+                    const int* lab_index, int n_labels, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st, const int* src,
                     const int* rows_dev) {
     if (rows > 0)
         hipLaunchKernelGGL(k_lx_visn, row_grid(rows), dim3(256), 0, st, xf, g_x, b_x, boxes, box_dim, Wb, bb, g_y, b_y, z,
-                           lab_index, o_hi, o_lo, rows, src, rows_dev);
+                           lab_index, n_labels, o_hi, o_lo, rows, src, rows_dev);
 }
 
 // modeling.py:890-910: additive masks (1 - m) * -10000 for language and visual keys

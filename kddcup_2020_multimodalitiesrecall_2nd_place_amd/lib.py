@@ -13,6 +13,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmmscore.so")
+# `make -C csrc lab`: the product sources built with -DMMS_LAB plus the superseded A/B kernels and timing-only diagnostics.
+# Only the scripts under tools/ load it (``lib.load(lib.LAB_LIB_PATH)`` before anything else touches the library).
+LAB_LIB_PATH = os.path.join(_HERE, "csrc", "libmmscore_lab.so")
 
 MODEL_ZK, MODEL_LDS, MODEL_LXMERT = 0, 1, 2
 MODEL_IDS = {"zk": MODEL_ZK, "lds": MODEL_LDS, "lxmert": MODEL_LXMERT}
@@ -33,7 +36,7 @@ class ZkBatch(C.Structure):
     _fields_ = [("n_pairs", C.c_int64), ("num_boxes", C.c_void_p), ("boxes_5", C.c_void_p), ("feats", C.c_void_p),
                 ("uniq_label_ids", C.c_void_p), ("n_uniq_labels", C.c_int64), ("label_index", C.c_void_p),
                 ("query_ids", C.c_void_p), ("len_query", C.c_void_p), ("labels", C.c_void_p),
-                ("segment_ids", C.c_void_p)]
+                ("segment_ids", C.c_void_p), ("label_ids", C.c_void_p)]
 
 
 class LdsBatch(C.Structure):
@@ -44,28 +47,37 @@ class LdsBatch(C.Structure):
 class LxmertBatch(C.Structure):
     _fields_ = [("n_pairs", C.c_int64), ("input_ids", C.c_void_p), ("input_mask", C.c_void_p),
                 ("uniq_label_ids", C.c_void_p), ("n_uniq_labels", C.c_int64), ("label_index", C.c_void_p),
-                ("feats", C.c_void_p), ("boxes", C.c_void_p), ("visual_attention_mask", C.c_void_p)]
+                ("feats", C.c_void_p), ("boxes", C.c_void_p), ("visual_attention_mask", C.c_void_p),
+                ("label_ids", C.c_void_p), ("x_norm", C.c_void_p)]
+
+
+class EnsembleBatch(C.Structure):
+    _fields_ = [("n_pairs", C.c_int64), ("feats", C.c_void_p), ("boxes_5", C.c_void_p), ("num_boxes", C.c_void_p),
+                ("label_ids", C.c_void_p), ("query_ids", C.c_void_p), ("len_query", C.c_void_p),
+                ("s2f_query_ids", C.c_void_p), ("s2f_len_query", C.c_void_p), ("labels", C.c_void_p),
+                ("lx_input_ids", C.c_void_p), ("lx_input_mask", C.c_void_p)]
 
 
 EXPORTS = ("mms_version", "mms_global_error", "mms_create", "mms_destroy", "mms_last_error", "mms_load_weight",
-           "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_gemm_timing",
-           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_attention", "mms_dbg_layernorm", "mms_set_gemm_variant",
+           "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_score_ensemble", "mms_gemm_timing",
+           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_attention", "mms_dbg_layernorm", "mms_set_gemm_variant",
            "mms_dbg_gemm_bench")
 
 _lib = None
 
 
-def load():
+def load(path=None):
     """dlopen libmmscore.so and declare prototypes.  Raises MmsError if the library is absent."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise MmsError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise MmsError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
     # torch must be imported first: it bundles the HIP runtime (libamdhip64.so.7) that owns the device
     # buffers/streams we are handed; libmmscore binds to that already-loaded copy by SONAME.
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.mms_version.restype = C.c_int
     lib.mms_global_error.restype = C.c_char_p
@@ -79,6 +91,8 @@ def load():
     lib.mms_score_zk.argtypes = [vp, C.POINTER(ZkBatch), vp, vp, vp]
     lib.mms_score_lds.argtypes = [vp, C.POINTER(LdsBatch), vp, vp, vp]
     lib.mms_score_lxmert.argtypes = [vp, C.POINTER(LxmertBatch), vp, vp, vp]
+    lib.mms_score_ensemble.argtypes = [vp, vp, vp, C.POINTER(EnsembleBatch), C.POINTER(C.c_float), vp, vp, vp]
+    lib.mms_dbg_gemm_f8.argtypes = [vp, i64, i64, vp, i64, vp, i32, i32, vp, vp]
     lib.mms_gemm_timing.argtypes = [vp, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.mms_debug_read_x.argtypes = [vp, vp, i64, vp]
     lib.mms_dbg_gemm.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, i32, i32, i32, vp, vp]

@@ -98,19 +98,39 @@ def predict_tsv_native(scorer, tsv_path, vocab_path, label_table, out_path, sen2
     return qid, pid, score
 
 
+def ensemble_feed(zk_feed: dict, s2f_feed: dict, lx_feed: dict) -> dict:
+    """The fused entry point's feed (``scorers.EnsembleScorer.prepare``) from the three per-model featurizer batches of the
+    SAME records: image side and label ids once (zk layout), the two zk query variants, the lxmert-flavour query."""
+    return {"feats": zk_feed["np_images_features"], "boxes_5": zk_feed["np_boxes_5"], "num_boxes": zk_feed["num_boxes"],
+            "label_ids": zk_feed["np_idx_class_labels"], "query_ids": zk_feed["np_idx_query_"], "len_query": zk_feed["len_query_"],
+            "s2f_query_ids": s2f_feed["np_idx_query_"], "s2f_len_query": s2f_feed["len_query_"], "labels": zk_feed["labels"],
+            "lx_input_ids": lx_feed["input_ids"], "lx_input_mask": lx_feed["input_mask"]}
+
+
 class EnsembleScorer:
-    """BASELINE.json config 5 host side: the three models score the same pair shard on the same GPU and are merged
-    pre-gather with main.py:59's weights, so the exchange step stays one fp32 per pair.
+    """BASELINE.json config 5, TSV records -> merged scores: the three models score the same pair shard on the same GPU in ONE
+    library call (``scorers.EnsembleScorer`` -> ``mms_score_ensemble``) and are merged pre-gather with main.py:59's weights, so
+    the exchange step stays one fp32 per pair.
 
     ``zk`` is used twice -- once on the query as given, once on the ``sen2forest`` rewrite (evaluate_normal_sen2fs.py,
     load_data_v4.py:153-154) -- exactly the four tables main.py merges.  The product-uniqueness filter is global over
     queries and therefore runs on rank 0 after the gather (``ensemble.uniqueness_filter``).
+
+    The fused call reads ONE label-id tensor; the TF-flavour and the lxmert-flavour tokenizer must therefore agree on the class
+    names (they differ only in ``max_input_chars_per_word`` and the never-split specials, neither of which a class name hits);
+    ``score_lines`` checks it on every batch.
     """
 
     WEIGHTS = (0.2, 0.2, 0.3, 0.3)
 
     def __init__(self, zk, lds, lxmert):
+        from .scorers import EnsembleScorer as Fused
         self.zk, self.lds, self.lxmert = zk, lds, lxmert
+        self.fused = Fused(zk, lds, lxmert, self.WEIGHTS)
+
+    def _score(self, zk_feed, s2f_feed, lx_feed):
+        merged, mem = self.fused(ensemble_feed(zk_feed, s2f_feed, lx_feed))
+        return merged.double().cpu().numpy(), tuple(m for m in mem.cpu().numpy())
 
     def score_lines(self, tsv_lines, label_table, tok_tf, tok_hf, batch_pairs: int = 8192):
         """tok_tf: WordPieceTokenizer as the TF sub-projects build it; tok_hf: the lxmert (HF) flavour."""
@@ -118,32 +138,36 @@ class EnsembleScorer:
         rec = [F.read_line(l, label_table, tok_tf) for l in lines]
         rec_s2f = [F.read_line(l, label_table, tok_tf, sen2forest=True) for l in lines]
         rec_hf = [F.read_line(l, label_table, tok_hf) for l in lines]
-        qid, pid, s1 = score_records(self.zk, rec, batch_pairs)
-        _, _, s2 = score_records(self.zk, rec_s2f, batch_pairs)
-        _, _, s3 = score_records(self.lds, rec, batch_pairs)
-        _, _, s4 = score_records(self.lxmert, rec_hf, batch_pairs)
-        w = self.WEIGHTS
-        merged = w[0] * s1.astype(np.float64) + w[1] * s2 + w[2] * s3 + w[3] * s4
-        return qid, pid, merged, (s1, s2, s3, s4)
+        merged, parts = [], [[], [], [], []]
+        for s in range(0, len(rec), batch_pairs):
+            zf = F.zk_batch(rec[s:s + batch_pairs], self.zk.cfg.text_len)
+            lf = F.lxmert_batch(rec_hf[s:s + batch_pairs], self.lxmert.cfg.text_len)
+            if not np.array_equal(zf["np_idx_class_labels"], lf["boxes_label_input_ids"]):
+                raise ValueError("the two tokenizer flavours disagree on a class name: the fused entry point takes one label-id tensor")
+            m, p4 = self._score(zf, F.zk_batch(rec_s2f[s:s + batch_pairs], self.zk.cfg.text_len), lf)
+            merged.append(m)
+            for k in range(4):
+                parts[k].append(p4[k])
+        cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+        qid = np.array([r.query_id for r in rec], np.int64)
+        pid = np.array([r.product_id for r in rec], np.int64)
+        return qid, pid, cat(merged, np.float64), tuple(cat(x, np.float32) for x in parts)
 
     def score_tsv_native(self, tsv_path, vocab_path, label_table, batch_pairs: int = 16384, threads: int = 0):
         """``score_lines`` on a TSV file through libmmfeat: every span batch is decoded three times (zk flavour, zk with the
-        sen2forest rewrite, lxmert flavour -- the lds feed is the zk one with int64 ids) and scored by the four passes."""
+        sen2forest rewrite, lxmert flavour) and scored by one fused call."""
         from .featurizer_native import NativeFeaturizer
         mk = lambda m: NativeFeaturizer(vocab_path, label_table, m, threads=threads, pinned=True, reuse_buffers=True)
         nf_zk, nf_s2f, nf_lx = mk("zk"), mk("zk"), mk("lxmert")
-        nf_lds = mk("lds")                                    # layout only: re-labels the zk arrays
-        qids, pids, parts = [], [], [[], [], [], []]
+        qids, pids, merged, parts = [], [], [], [[], [], [], []]
         for base, getbytes, starts, ends in nf_zk.iter_spans(tsv_path, batch_pairs):
             a = nf_zk._run(base, getbytes, starts, ends, False)
             qids.append(a["query_id"].copy())
             pids.append(a["product_id"].copy())
-            feeds = (nf_zk._layout(a), nf_s2f._layout(nf_s2f._run(base, getbytes, starts, ends, True)), nf_lds._layout(a),
-                     nf_lx._layout(nf_lx._run(base, getbytes, starts, ends, False)))
-            for k, (sc, feed) in enumerate(zip((self.zk, self.zk, self.lds, self.lxmert), feeds)):
-                parts[k].append(score_batch(sc, feed)[1][:, 1].float().cpu().numpy())
+            m, p4 = self._score(nf_zk._layout(a), nf_s2f._layout(nf_s2f._run(base, getbytes, starts, ends, True)),
+                                nf_lx._layout(nf_lx._run(base, getbytes, starts, ends, False)))
+            merged.append(m)
+            for k in range(4):
+                parts[k].append(p4[k])
         cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
-        s1, s2, s3, s4 = (cat(x, np.float32) for x in parts)
-        w = self.WEIGHTS
-        merged = w[0] * s1.astype(np.float64) + w[1] * s2 + w[2] * s3 + w[3] * s4
-        return cat(qids, np.int64), cat(pids, np.int64), merged, (s1, s2, s3, s4)
+        return cat(qids, np.int64), cat(pids, np.int64), cat(merged, np.float64), tuple(cat(x, np.float32) for x in parts)

@@ -7,10 +7,12 @@ replaces, so the reference's predict drivers can call it unchanged:
                                fed by evaluate_normal.py:227-238) -> ``(loss, probs[B,2], [loss])``
 * ``LdsScorer.__call__``     <- ``bertmodel(..., features, ...)`` (code/imagebert_lds/src/run_pretraining_predict_score.py:288-336)
                                -> ``next_sentence_prob[B,2]``
-* ``LxmertScorer.forward``   <- ``KDDModel.forward`` (code/lxmert/src/tasks/kdd_model.py:183-214) -> ``(x_norm, None, logit[B,2])``
+* ``LxmertScorer.forward``   <- ``KDDModel.forward`` (code/lxmert/src/tasks/kdd_model.py:183-214) -> ``(x_norm[B,768], None, logit[B,2])``
+* ``EnsembleScorer``         <- what ``code/main.py:41-59`` merges: the four members on the same pairs, one C call
 
-All arithmetic of the forward runs in libmmscore (HIP, gfx950).  torch is used here only to own
-device buffers and the stream, and for index bookkeeping (de-duplicating label-text tuples).
+All arithmetic of the forward runs in libmmscore (HIP, gfx950), including the de-duplication of the label-text tuples
+(``dedup_labels=True`` hands the dense ``[B,10,8]`` ids to the library).  torch is used here only to own device buffers
+and the stream.
 Inputs may be numpy arrays or torch tensors (host or device); outputs follow the input kind.
 """
 from __future__ import annotations
@@ -29,8 +31,8 @@ def _is_np(x):
 class _Base:
     def __init__(self, cfg, weights: dict, precision="auto", device: int = 0, chunk_pairs: int = 0,
                  stop_after: int = -1, dedup_labels: bool = True, pack_tokens: bool = True):
-        """precision: 1 / 2 / 3 or "auto" = ``weights.auto_precision``: 2 for bf16-representable matrices,
-        3 for a real fp32 checkpoint."""
+        """precision: 1 / 2 / 3 / 4 (4 = fp8 weights and activations on the big encoder GEMMs, outside the
+        1e-3 contract) or "auto" = ``weights.auto_precision``: 2 for bf16-representable matrices, 3 for a real fp32 checkpoint."""
         if not torch.cuda.is_available():
             raise _lib.MmsError("no HIP device visible: the scorers have no CPU path")
         if precision == "auto":
@@ -51,12 +53,12 @@ class _Base:
         return t.to(device=self.device, dtype=dtype, non_blocking=True).contiguous()
 
     def _labels(self, label_ids, dtype):
-        """[B,10,8] ids -> (uniq [U,8], index [B*10] int32).  Index bookkeeping only."""
+        """[B,10,8] ids -> (dense ids, None, None): the library finds the distinct tuples itself; or, with
+        ``dedup_labels=False``, (None, ids as [B*10,8], arange): every tuple is encoded, the dense reference graph."""
         lab = self._dev(label_ids, dtype).reshape(-1, LABEL_LEN)
         if self.dedup_labels:
-            uniq, inv = torch.unique(lab, dim=0, return_inverse=True)
-            return uniq.contiguous(), inv.to(torch.int32).contiguous()
-        return lab, torch.arange(lab.shape[0], device=self.device, dtype=torch.int32)
+            return lab, None, None
+        return None, lab, torch.arange(lab.shape[0], device=self.device, dtype=torch.int32)
 
     def _run(self, struct, n, keep):
         logits = torch.empty((n, 2), device=self.device, dtype=torch.float32)
@@ -86,15 +88,16 @@ class ZkScorer(_Base):
         B = q.shape[0]
         if segment_ids is None:  # load_data_v4.py:204
             segment_ids = torch.tensor([0] * T + [1] * N_BOX, dtype=torch.int32).repeat(B, 1)
-        uniq, idx = self._labels(np_idx_class_labels, torch.int32)
+        dense, uniq, idx = self._labels(np_idx_class_labels, torch.int32)
         t = dict(num_boxes=self._dev(num_boxes, torch.int32), boxes=self._dev(np_boxes_5, torch.float32),
-                 feats=self._dev(np_images_features, torch.float32), uniq=uniq, idx=idx, q=q,
+                 feats=self._dev(np_images_features, torch.float32), dense=dense, uniq=uniq, idx=idx, q=q,
                  lq=self._dev(len_query_, torch.int32), labels=self._dev(labels, torch.int64),
                  seg=self._dev(segment_ids, torch.int32))
         assert t["feats"].shape == (B, N_BOX, 2048) and t["boxes"].shape == (B, N_BOX, 5) and q.shape[1] == T
-        s = _lib.ZkBatch(B, t["num_boxes"].data_ptr(), t["boxes"].data_ptr(), t["feats"].data_ptr(), uniq.data_ptr(),
-                         uniq.shape[0], idx.data_ptr(), q.data_ptr(), t["lq"].data_ptr(), t["labels"].data_ptr(),
-                         t["seg"].data_ptr())
+        s = _lib.ZkBatch(B, t["num_boxes"].data_ptr(), t["boxes"].data_ptr(), t["feats"].data_ptr(),
+                         uniq.data_ptr() if uniq is not None else None, uniq.shape[0] if uniq is not None else 0,
+                         idx.data_ptr() if idx is not None else None, q.data_ptr(), t["lq"].data_ptr(), t["labels"].data_ptr(),
+                         t["seg"].data_ptr(), dense.data_ptr() if dense is not None else None)
         return s, B, t
 
     def score_prepared(self, prepared):
@@ -139,20 +142,25 @@ class LdsScorer(_Base):
 
 
 class LxmertScorer(_Base):
-    def prepare(self, input_ids, boxes_label_input_ids, input_mask, feats, boxes, visual_attention_mask):
+    def prepare(self, input_ids, boxes_label_input_ids, input_mask, feats, boxes, visual_attention_mask, want_x_norm=False):
         ids = self._dev(input_ids, torch.int64)
         B = ids.shape[0]
         if input_mask is None:  # modeling.py:878-879
             input_mask = torch.ones_like(ids)
         if visual_attention_mask is None:
             visual_attention_mask = torch.ones((B, N_BOX), dtype=torch.float32)
-        uniq, idx = self._labels(boxes_label_input_ids, torch.int64)
-        t = dict(ids=ids, mask=self._dev(input_mask, torch.int64), uniq=uniq, idx=idx,
+        dense, uniq, idx = self._labels(boxes_label_input_ids, torch.int64)
+        t = dict(ids=ids, mask=self._dev(input_mask, torch.int64), dense=dense, uniq=uniq, idx=idx,
                  feats=self._dev(feats, torch.float32), boxes=self._dev(boxes, torch.float32),
                  vm=self._dev(visual_attention_mask, torch.float32))
+        if want_x_norm:
+            t["x_norm"] = torch.empty((B, 768), device=self.device, dtype=torch.float32)
         assert t["feats"].shape == (B, N_BOX, 2048) and t["boxes"].shape == (B, N_BOX, 4)
-        s = _lib.LxmertBatch(B, ids.data_ptr(), t["mask"].data_ptr(), uniq.data_ptr(), uniq.shape[0], idx.data_ptr(),
-                             t["feats"].data_ptr(), t["boxes"].data_ptr(), t["vm"].data_ptr())
+        s = _lib.LxmertBatch(B, ids.data_ptr(), t["mask"].data_ptr(), uniq.data_ptr() if uniq is not None else None,
+                             uniq.shape[0] if uniq is not None else 0, idx.data_ptr() if idx is not None else None,
+                             t["feats"].data_ptr(), t["boxes"].data_ptr(), t["vm"].data_ptr(),
+                             dense.data_ptr() if dense is not None else None,
+                             t["x_norm"].data_ptr() if want_x_norm and B > 0 else None)
         return s, B, t
 
     def score_prepared(self, prepared):
@@ -161,15 +169,71 @@ class LxmertScorer(_Base):
 
     def forward(self, input_ids, boxes_label_input_ids, segment_ids, input_mask, boxes_label_segment_ids,
                 boxes_label_input_mask, feats, boxes, visual_attention_mask):
-        """Same positional signature as KDDModel.forward.  segment ids are all-zero in the reference
-        feed (kdd_model.py:97-100 passes None) and the label mask is computed but unused there
-        (modeling.py:579,900-902); the discarded MLM head (kdd_model.py:201-202) is not computed."""
+        """Same positional signature and return tuple as KDDModel.forward: ``(x_norm, lang_prediction_scores, logit)``
+        with x_norm = pooled / max(||pooled||, 1e-12) (kdd_model.py:204-205).  segment ids are all-zero in the reference
+        feed (kdd_model.py:97-100 passes None) and the label mask is computed but unused there (modeling.py:579,900-902);
+        the MLM head's output (kdd_model.py:201-202) is discarded by every caller and is not computed: None."""
         as_np = _is_np(feats)
-        logits, _ = self.score_prepared(self.prepare(input_ids, boxes_label_input_ids, input_mask, feats, boxes,
-                                                     visual_attention_mask))
-        return (None, None, logits.cpu().numpy() if as_np else logits)
+        prep = self.prepare(input_ids, boxes_label_input_ids, input_mask, feats, boxes, visual_attention_mask, want_x_norm=True)
+        logits, _ = self.score_prepared(prep)
+        x_norm = prep[2]["x_norm"]
+        return (x_norm.cpu().numpy() if as_np else x_norm, None, logits.cpu().numpy() if as_np else logits)
 
     __call__ = forward
+
+
+class EnsembleScorer:
+    """The four members code/main.py:41-59 merges -- zk on the query, zk on its sen2forest rewrite, lds, lxmert -- on the SAME
+    pairs in ONE library call (``mms_score_ensemble``, BASELINE.json config 5): box features split once per launch wave, label
+    tuples de-duplicated once, zk's image-token stage run once for both query variants, merged score
+    ``0.2*zk + 0.2*zk_s2f + 0.3*lds + 0.3*lxmert`` computed on the device so that the exchange step stays one fp32 per pair."""
+
+    WEIGHTS = (0.2, 0.2, 0.3, 0.3)   # main.py:59
+
+    def __init__(self, zk: "ZkScorer", lds: "LdsScorer", lxmert: "LxmertScorer", weights=WEIGHTS):
+        self.zk, self.lds, self.lxmert = zk, lds, lxmert
+        self.device = zk.device
+        self.w = (_lib.C.c_float * 4)(*weights)
+        self.lib = _lib.load()
+
+    def prepare(self, feed: dict):
+        """feed keys (numpy or torch, any integer dtype): feats [B,10,2048], boxes_5 [B,10,5], num_boxes [B], label_ids
+        [B,10,8], query_ids / s2f_query_ids [B,20], len_query / s2f_len_query [B], labels [B], lx_input_ids /
+        lx_input_mask [B,23]."""
+        d = self.zk._dev
+        i32 = torch.int32
+        t = dict(feats=d(feed["feats"], torch.float32), boxes=d(feed["boxes_5"], torch.float32), nb=d(feed["num_boxes"], i32),
+                 lab=d(feed["label_ids"], i32), q=d(feed["query_ids"], i32), lq=d(feed["len_query"], i32),
+                 q2=d(feed["s2f_query_ids"], i32), lq2=d(feed["s2f_len_query"], i32), labels=d(feed["labels"], torch.int64),
+                 lx=d(feed["lx_input_ids"], i32), lxm=d(feed["lx_input_mask"], i32))
+        B = t["q"].shape[0]
+        assert t["feats"].shape == (B, N_BOX, 2048) and t["boxes"].shape == (B, N_BOX, 5) and t["lab"].shape == (B, N_BOX, LABEL_LEN)
+        assert t["q"].shape[1] == self.zk.cfg.text_len == self.lds.cfg.text_len and t["lx"].shape[1] == self.lxmert.cfg.text_len
+        s = _lib.EnsembleBatch(B, t["feats"].data_ptr(), t["boxes"].data_ptr(), t["nb"].data_ptr(), t["lab"].data_ptr(),
+                               t["q"].data_ptr(), t["lq"].data_ptr(), t["q2"].data_ptr(), t["lq2"].data_ptr(),
+                               t["labels"].data_ptr(), t["lx"].data_ptr(), t["lxm"].data_ptr())
+        return s, B, t
+
+    def score_prepared(self, prepared, members: bool = True):
+        """-> (merged [B], member scores [4,B] or None), device fp32."""
+        s, B, keep = prepared
+        merged = torch.empty((B,), device=self.device, dtype=torch.float32)
+        mem = torch.empty((4, B), device=self.device, dtype=torch.float32) if members else None
+        if B > 0:
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.lib.mms_score_ensemble(self.zk.handle._h, self.lds.handle._h, self.lxmert.handle._h, _lib.C.byref(s), self.w,
+                                             merged.data_ptr(), mem.data_ptr() if members else None, st)
+            if rc != 0:
+                raise _lib.MmsError("mms_score_ensemble failed (%d): %s" % (rc, self.lib.mms_last_error(self.zk.handle._h).decode()))
+        self._keep = keep
+        return merged, mem
+
+    def __call__(self, feed: dict, members: bool = True):
+        return self.score_prepared(self.prepare(feed), members)
+
+    def close(self):
+        for m in (self.zk, self.lds, self.lxmert):
+            m.close()
 
 
 def make_scorer(cfg, weights, **kw):

@@ -40,6 +40,12 @@ class PairSet:
     def n(self):
         return int(self.query_id.shape[0])
 
+    def take(self, idx) -> "PairSet":
+        """Sub-set of pairs (slice or index array): a rank's shard of a job, a test's sample."""
+        ix = np.arange(self.n)[idx]
+        return PairSet(self.query_id[ix], self.product_id[ix], [self.query_tokens[i] for i in ix], self.num_boxes[ix], self.corners[ix],
+                       None if self.feats is None else self.feats[ix], self.class_id[ix], self.class_table, self.relevance[ix])
+
 
 def make_class_table(n_classes: int = 33, vocab: int = 21128, seed: int = SEED) -> np.ndarray:
     u = uniform01("class_table/len", n_classes, seed)
@@ -93,6 +99,18 @@ def make_pairs(n_queries: int, cands, *, seed: int = SEED, vocab: int = 21128, n
     relevance = (uniform01(t + "rel", B, seed) < 0.2).astype(np.int64)
     return PairSet(query_id, product_id, query_tokens, num_boxes, corners, feats, class_id,
                    make_class_table(n_classes, vocab, seed), relevance)
+
+
+def sen2forest_variant(ps: PairSet) -> PairSet:
+    """The second zk member of the ensemble scores the same pairs on a REWRITTEN query (``sen department of`` -> ``forest
+    style``, load_data_v4.py:153-154): three WordPieces become two for the queries that contain the phrase.  Synthetic
+    stand-in: every third query (by id) with >= 3 body tokens has its first three tokens replaced by two fixed ids."""
+    out = ps.take(slice(None))
+    toks = []
+    for q, body in zip(ps.query_id, ps.query_tokens):
+        toks.append([2000, 2001] + list(body[3:]) if (int(q) % 3 == 0 and len(body) >= 3) else list(body))
+    out.query_tokens = toks
+    return out
 
 
 def _label_ids(ps: PairSet) -> np.ndarray:

@@ -119,8 +119,8 @@ def _tf_embeddings(g: _Gen, cfg):
     g.ln_tf("bert/embeddings/LayerNorm")
 
 
-def make_zk_weights(cfg: ZkConfig = ZkConfig(), seed: int = 20200823, bf16_matrices: bool = True):
-    g = _Gen(seed, bf16_matrices)
+def make_zk_weights(cfg: ZkConfig = ZkConfig(), seed: int = 20200823, bf16_matrices: bool = True, _gen=None):
+    g = _gen or _Gen(seed, bf16_matrices)
     _tf_embeddings(g, cfg)
     g.mat("kdd_conv1/weights", (1, LABEL_LEN, HIDDEN, HIDDEN), 0.25)  # inputs are 0.05-std embeddings
     g.vec("kdd_conv1/biases", (HIDDEN,), 0.1)
@@ -135,8 +135,8 @@ def make_zk_weights(cfg: ZkConfig = ZkConfig(), seed: int = 20200823, bf16_matri
     return g.out
 
 
-def make_lds_weights(cfg: LdsConfig = LdsConfig(), seed: int = 20200823, bf16_matrices: bool = True):
-    g = _Gen(seed + 1, bf16_matrices)
+def make_lds_weights(cfg: LdsConfig = LdsConfig(), seed: int = 20200823, bf16_matrices: bool = True, _gen=None):
+    g = _gen or _Gen(seed + 1, bf16_matrices)
     _tf_embeddings(g, cfg)
     g.vec("bert/embeddings/word_embeddings_labelembedding", (LABEL_LEN, 1), 2.0)
     g.mat("featureemb/fully_connected/weights", (FEAT_DIM, HIDDEN), _STD_F)
@@ -165,8 +165,8 @@ def _pt_ffn(g: _Gen, inter_name: str, out_name: str, inter: int):
 
 
 def make_lxmert_weights(cfg: LxmertConfig = LxmertConfig(), seed: int = 20200823,
-                        bf16_matrices: bool = True):
-    g = _Gen(seed + 2, bf16_matrices)
+                        bf16_matrices: bool = True, _gen=None):
+    g = _gen or _Gen(seed + 2, bf16_matrices)
     b = "lxrt_encoder.model.bert."
     g.vec(b + "embeddings.word_embeddings.weight", (cfg.vocab, HIDDEN), _STD_E)
     g.vec(b + "embeddings.position_embeddings.weight", (cfg.max_pos, HIDDEN), _STD_E)
@@ -228,14 +228,8 @@ def _shapes_from_generator(cfg):
 
         def vec(self, name, shape, std, mean=0.0):
             self.out[name] = tuple(shape)
-    g = _Rec(0, False)
-    mod = globals()
-    saved = mod["_Gen"]
-    mod["_Gen"] = lambda seed, bf16: g       # the make_* functions only use .mat/.vec/.ln_* of the generator object
-    try:
-        {"zk": make_zk_weights, "lds": make_lds_weights, "lxmert": make_lxmert_weights}[cfg.name](cfg)
-    finally:
-        mod["_Gen"] = saved
+    g = _Rec(0, False)       # the make_* functions only use .mat / .vec / .ln_* of the generator they are handed
+    {"zk": make_zk_weights, "lds": make_lds_weights, "lxmert": make_lxmert_weights}[cfg.name](cfg, _gen=g)
     return dict(g.out)
 
 
@@ -305,8 +299,11 @@ def auto_precision(weights: dict) -> int:
         dims = sorted(d for d in v.shape if d > 1)
         # the GEMM operands: dense / conv kernels with both dimensions >= 256 (embedding tables, 5->768 box projections, 768->2
         # heads stay fp32 in the HIP path whatever the mode)
-        if len(dims) >= 2 and dims[-2] >= 256 and "embedding" not in k and v.dtype == np.float32:
-            if np.any(np.ascontiguousarray(v).view(np.uint32) & np.uint32(0xFFFF)):
+        if len(dims) >= 2 and dims[-2] >= 256 and "embedding" not in k and v.dtype.kind == "f":
+            # the library receives fp32 (lib.Handle.load_weights casts): test the values it will see, whatever the export's dtype
+            # (a float64 / float16 .npz is as much a real checkpoint as a float32 one)
+            v32 = np.ascontiguousarray(v, dtype=np.float32)
+            if np.any(v32.view(np.uint32) & np.uint32(0xFFFF)):
                 return 3
     return 2
 

@@ -44,7 +44,8 @@ GEMM_CASES = [
 ]
 
 
-GEMM_VARIANTS = [0, 1, 3, 4, 11, 12, 16, 20, 26, 99]
+# the tile engines a forward can launch (gemm_dispatch.hip): 128x128, 128x256, 256x256/16 waves, 256x256 persistent ping-pong
+GEMM_VARIANTS = [1, 4, 16, 26]
 
 
 @pytest.fixture

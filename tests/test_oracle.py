@@ -133,3 +133,103 @@ def test_seeded_generators_are_deterministic_and_bf16_exact():
     assert np.array_equal(ps1.feats, ps2.feats) and ps1.n == ps2.n
     assert ps1.num_boxes.min() >= 1 and ps1.num_boxes.max() <= 10
     assert (ps1.feats[np.arange(10)[None, :] >= ps1.num_boxes[:, None]] == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tf_pins.npz / kdd_amcos.npz / lxmert_fp32ckpt.npz: the pieces of the TF models (zk, lds) whose arithmetic the imported PyTorch
+# reference shares, and the fp32-checkpoint route (tests/golden/make_lxmert_golden.py tfpins | amcos | fp32ckpt)
+# ---------------------------------------------------------------------------------------------------------------------
+def _zk12_weights(dtype=np.float64):
+    return {k: v.astype(dtype) for k, v in weights.make_zk_weights(ZkConfig(layers=12, vocab=4096)).items()}
+
+
+def test_tf_pooler_matches_reference_bertpooler():
+    g, _ = load_golden("tf_pins.npz")
+    x = weights.normal("tfpins/pool_x", (6, 30, 768), 20200823).astype(np.float64)
+    assert np.abs(O.tf_pooler(x, _zk12_weights()) - g["pooler"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("name", ["zk", "lds"])
+def test_text_rows_of_embedding_output_match_reference_bertembeddings(name):
+    """LayerNorm is per row and text rows get word + position 0..19 + token type 0 in zk (pixelbert.py:541-621), lds
+    (pixelmodel.py:506-602) and the reference's BertEmbeddings (modeling.py:269-297) alike."""
+    g, meta = load_golden("tf_pins.npz")
+    ids = g["textemb_ids"]
+    w = _zk12_weights()
+    B = ids.shape[0]
+    if name == "zk":
+        ps = synth.make_pairs(1, B, vocab=meta["vocab"], tag="/textemb")
+        b = synth.zk_batch(ps, 20)
+        b["np_idx_query_"] = ids.astype(np.int32)
+        b = {k: (np.asarray(v, np.float64) if np.asarray(v).dtype.kind == "f" else v) for k, v in b.items()}
+        rows = O.zk_embeddings(b, w)[:, :20]
+    else:
+        wl = {k: v.astype(np.float64) for k, v in weights.make_lds_weights(LdsConfig(layers=0, vocab=4096)).items()}
+        for k in ("word_embeddings", "token_type_embeddings", "position_embeddings", "LayerNorm/gamma", "LayerNorm/beta"):
+            wl["bert/embeddings/" + k] = w["bert/embeddings/" + k]     # the golden was made with the zk-seeded tables
+        ps = synth.make_pairs(1, B, vocab=meta["vocab"], tag="/textemb")
+        b = synth.lds_batch(ps, 20)
+        b["input_ids"] = ids
+        b = {k: (np.asarray(v, np.float64) if np.asarray(v).dtype.kind == "f" else v) for k, v in b.items()}
+        rows = O.lds_embeddings(b, wl)[:, :20]
+    assert np.abs(rows - g["textemb"]).max() < 3e-6
+
+
+@pytest.mark.parametrize("S", [30, 40])
+def test_twelve_layer_tf_encoder_stack_matches_reference(S):
+    """pixelbert.transformer_model at the depth zk / lds run it == 12 chained reference BertLayers (tanh-GELU)."""
+    g, _ = load_golden("tf_pins.npz")
+    w = _zk12_weights()
+    x = weights.normal("tfpins/stack_x/S%d" % S, (3, S, 768), 20200823).astype(np.float64)
+    mask = g["stack12_S%d_mask" % S].astype(np.float64)
+    add = (1.0 - mask) * -10000.0 if S == 30 else None
+    for i in range(12):
+        x = O.tf_encoder_layer(x, w, i, add)
+    # rows of fully masked... every query row is computed (only keys are masked): compare everything
+    assert np.abs(x - g["stack12_S%d" % S]).max() < 5e-5
+
+
+def test_am_head_cosine_core_matches_reference():
+    """kdd_model.py:204-210 under task_match + task_amsloss: x_norm @ w_norm == cos of model_triple.py:56-70 (zk head with
+    scale 1 and margin 0); x_norm itself is the first element of KDDModel.forward's return tuple."""
+    g, meta = load_golden("kdd_amcos.npz")
+    am = weights.normal(meta["am_seed_name"], (768, 2), 20200823, 0.05).astype(np.float64)
+    pooled = g["pooled"].astype(np.float64)
+    logits, _ = O.zk_head(pooled, np.zeros(len(pooled), np.int64), {"cls/seq_relationship/am_kernel": am}, scale=1.0, margin=0.0)
+    assert np.abs(logits - g["cos"]).max() < 2e-6
+    xn = pooled / np.maximum(np.linalg.norm(pooled, axis=1, keepdims=True), 1e-12)
+    assert np.abs(xn - g["x_norm"]).max() < 2e-6
+
+
+def fp32ckpt_case():
+    g, meta = load_golden("lxmert_fp32ckpt.npz")
+    cfg = LxmertConfig(l_layers=meta["l_layers"], r_layers=meta["r_layers"], x_layers=meta["x_layers"], vocab=meta["vocab"], inter=meta["inter"])
+    w = weights.make_lxmert_weights(cfg, bf16_matrices=False)
+    ps = synth.make_pairs(meta["n_queries"], tuple(meta["cands"]), vocab=cfg.vocab, tag=meta["tag"])
+    # the checkpoint as the reference saves it (kdd_model.py:131-152): every state_dict key, unused heads included, under
+    # DataParallel's ``module.`` prefix for half of the cases the importer has to take
+    sd = {}
+    for k, shape in meta["state_dict_keys"].items():
+        sd["module." + k] = torch.from_numpy(w[k]) if k in w else torch.zeros(shape)
+    return g, cfg, w, sd, synth.lxmert_batch(ps, cfg.text_len)
+
+
+def test_fp32_checkpoint_route_oracle_matches_reference():
+    g, cfg, w, sd, b = fp32ckpt_case()
+    imported = weights.from_torch_state_dict(cfg, sd)
+    assert set(imported) == set(w) and all(np.array_equal(imported[k], w[k]) for k in w)
+    assert weights.auto_precision(imported) == 3
+    inter = {}
+    logits, _ = O.forward(cfg, imported, b, np.float64, inter)
+    assert vecrel(logits, g["logit"]).max() < 2e-5
+    xn = inter["pooled"] / np.maximum(np.linalg.norm(inter["pooled"], axis=1, keepdims=True), 1e-12)
+    assert np.abs(xn - g["x_norm"]).max() < 2e-5
+
+
+def test_auto_precision_sees_through_the_export_dtype():
+    cfg = small_cfg("zk", layers=1)
+    w = weights.make_weights(cfg, bf16_matrices=False)
+    assert weights.auto_precision({k: v.astype(np.float64) for k, v in w.items()}) == 3
+    w2 = weights.make_weights(cfg)
+    assert weights.auto_precision({k: v.astype(np.float64) for k, v in w2.items()}) == 2
+    assert weights.expected_shapes(cfg) == weights.expected_shapes(cfg)

@@ -57,6 +57,15 @@ def _worker(rank, world, port, out):
           and torch.equal(all_p, torch.arange(per_q.sum()).long() * 7))
     s2, _, _ = sharding.gather_scores(scores)
     ok = ok and torch.equal(s2, all_s)
+    # static shard sizes (known to every rank up front): one collective per step, no size exchange
+    counts = sharding.shard_sizes(qop, n_q, world)
+    ok = ok and counts[rank] == e - s and sum(counts) == per_q.sum()
+    s3, q3, p3 = sharding.gather_scores(scores, qid, pid, counts=counts)
+    ok = ok and torch.equal(s3, all_s) and torch.equal(q3, all_q) and torch.equal(p3, all_p)
+    # equal shards take the no-padding route
+    eq = torch.full((4,), float(rank))
+    s4, _, _ = sharding.gather_scores(eq, counts=[4] * world)
+    ok = ok and torch.equal(s4, torch.arange(world).float().repeat_interleave(4))
     out[rank] = bool(ok)
     dist.destroy_process_group()
 

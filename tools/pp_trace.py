@@ -14,7 +14,7 @@ from kddcup_2020_multimodalitiesrecall_2nd_place_amd import lib  # noqa: E402
 N, K = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2304, 768)
 VARIANT = 232
 M = 122880
-l = lib.load()
+l = lib.load(lib.LAB_LIB_PATH)   # lab build: `make -C kddcup_2020_multimodalitiesrecall_2nd_place_amd/csrc lab`
 ms = C.c_float(0)
 assert l.mms_dbg_gemm_bench(M, N, K, 2, 0, 0, 0, VARIANT, 1, C.byref(ms)) == 0, l.mms_global_error()
 t = np.fromfile("/tmp/pp_trace.bin", np.uint64).reshape(-1, 5).astype(np.int64)

@@ -3,7 +3,8 @@ for every MMS_X1_MASK (1 qkv, 2 att-out, 4 ffn-up, 8 ffn-down).  Experiment only
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from kddcup_2020_multimodalitiesrecall_2nd_place_amd import scorers, synth, weights
+from kddcup_2020_multimodalitiesrecall_2nd_place_amd import lib, scorers, synth, weights
+lib.load(lib.LAB_LIB_PATH)   # MMS_X1_MASK is honoured by the lab build only (`make -C .../csrc lab`)
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd.config import ZkConfig, LxmertConfig
 from oracle import np_models as O
 for cfg in (ZkConfig(), LxmertConfig()):
