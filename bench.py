@@ -215,7 +215,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # backend "nccl" == RCCL over xGMI; MMS_BENCH_BACKEND=gloo (+ MMS_BENCH_SHARE_GPU=1) only exists for single-GPU test boxes
-        dist.init_process_group(os.environ.get("MMS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        # the process-group backends announce themselves on stdout ("[Gloo] Rank 0 is connected to ..."): the contract is ONE line
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(os.environ.get("MMS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     dev = torch.device("cuda", local)
     gather_dev = dev if os.environ.get("MMS_BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")
 

@@ -43,3 +43,37 @@ def lxmert_case_from_meta(meta):
     cands = meta["cands"] if isinstance(meta["cands"], int) else tuple(meta["cands"])
     ps = synth.make_pairs(meta["n_queries"], cands, vocab=cfg.vocab, tag=meta["tag"])
     return cfg, weights.make_lxmert_weights(cfg), synth.lxmert_batch(ps, cfg.text_len)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def fp32ckpt_case():
+    g, meta = load_golden("lxmert_fp32ckpt.npz")
+    cfg = LxmertConfig(l_layers=meta["l_layers"], r_layers=meta["r_layers"], x_layers=meta["x_layers"], vocab=meta["vocab"], inter=meta["inter"])
+    w = weights.make_lxmert_weights(cfg, bf16_matrices=False)
+    ps = synth.make_pairs(meta["n_queries"], tuple(meta["cands"]), vocab=cfg.vocab, tag=meta["tag"])
+    # the checkpoint as the reference saves it (kdd_model.py:131-152): every state_dict key, unused heads included, under
+    # DataParallel's ``module.`` prefix for half of the cases the importer has to take
+    sd = {}
+    for k, shape in meta["state_dict_keys"].items():
+        sd["module." + k] = _torch().from_numpy(w[k]) if k in w else _torch().zeros(shape)
+    return g, cfg, w, sd, synth.lxmert_batch(ps, cfg.text_len)
+
+
+def act_ref(x, act):
+    """numpy reference of the GEMM epilogue activations (lib.ACT_*)."""
+    import math
+    from scipy.special import erf
+    from kddcup_2020_multimodalitiesrecall_2nd_place_amd import lib
+    if act == lib.ACT_RELU:
+        return np.maximum(x, 0)
+    if act == lib.ACT_GELU_TANH:
+        return x * 0.5 * (1 + np.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))
+    if act == lib.ACT_GELU_ERF:
+        return x * 0.5 * (1 + erf(x / math.sqrt(2)))
+    if act == lib.ACT_TANH:
+        return np.tanh(x)
+    return x

@@ -30,3 +30,21 @@ def test_bench_prints_one_contract_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert d["value"] > 20 * c["value"]
+    assert c["hip_vs_port_max_vecrel"] < 1e-3                     # the CPU port's sample doubles as a check of the HIP logits
+    assert d["ms_per_step_median_hipevent"] > 0
+    sec = d["secondary"]
+    assert sec["value_incl_h2d"]["value"] > 0 and sec["value_incl_h2d"]["value"] <= d["value"] * 1.05
+    p3 = sec["precision3"]
+    assert p3["precision_mode"] == 3 and p3["value"] > 0 and p3["parity_max_vecrel_vs_fp32_port"] < 1e-3
+    assert sec["lds"]["value"] > 0 and sec["lxmert"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_ensemble_and_fp8_lines():
+    for extra in (["--model", "ensemble"], ["--precision", "4"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--queries", "30", "--no-cpu",
+                              "--no-secondary"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+        assert d["value"] > 0 and d["roofline"]["achieved"] > 0
+        assert ("ensemble" in d["config"]["workload"]) == (extra[0] == "--model")

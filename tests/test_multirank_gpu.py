@@ -1,0 +1,58 @@
+"""GPU suite: the N > 1 path with the HIP scorer on a single-GPU box (ranks share the device, gloo exchange) -- SURVEY.md section 8(e),
+BASELINE.json config 4 (testB-like ragged shards) -- and bench.py's own rank spawning."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_hip_scoring_equals_single_rank_bitwise(world, tmp_path):
+    out = tmp_path / "res.json"
+    port = _port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), str(out)], env=env, cwd=ROOT))
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    res = json.load(open(out))
+    assert res["ok"] is True and sum(res["counts"]) == res["pairs"]
+
+
+def test_bench_gpus2_spawns_two_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE: the bench starts its own ranks.  On this
+    one-GPU box the ranks share device 0 and exchange over gloo; on the driver's node they get one GPU each and RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MMS_BENCH_SHARE_GPU="1", MMS_BENCH_BACKEND="gloo")
+    for wl, scaling in (("bench", "weak"), ("testB", "strong")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--queries", "40",
+                              "--workload", wl], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
+        total = d["config"]["pairs_total"]
+        assert abs(d["value"] - total * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-3
+        assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
+        if wl == "bench":
+            assert total == 2 * 40 * 30
+    # a --gpus that contradicts the launcher's WORLD_SIZE is an error, not a silent 1-rank run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT,
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "contradicts" in (bad.stderr + bad.stdout)

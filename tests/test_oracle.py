@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import lxmert_case_from_meta, load_golden, small_cfg, vecrel
+from helpers import fp32ckpt_case, lxmert_case_from_meta, load_golden, small_cfg, vecrel
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd import synth, weights
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd.config import LdsConfig, LxmertConfig, ZkConfig, flops_per_pair
 from oracle import np_models as O
@@ -199,19 +199,6 @@ def test_am_head_cosine_core_matches_reference():
     assert np.abs(logits - g["cos"]).max() < 2e-6
     xn = pooled / np.maximum(np.linalg.norm(pooled, axis=1, keepdims=True), 1e-12)
     assert np.abs(xn - g["x_norm"]).max() < 2e-6
-
-
-def fp32ckpt_case():
-    g, meta = load_golden("lxmert_fp32ckpt.npz")
-    cfg = LxmertConfig(l_layers=meta["l_layers"], r_layers=meta["r_layers"], x_layers=meta["x_layers"], vocab=meta["vocab"], inter=meta["inter"])
-    w = weights.make_lxmert_weights(cfg, bf16_matrices=False)
-    ps = synth.make_pairs(meta["n_queries"], tuple(meta["cands"]), vocab=cfg.vocab, tag=meta["tag"])
-    # the checkpoint as the reference saves it (kdd_model.py:131-152): every state_dict key, unused heads included, under
-    # DataParallel's ``module.`` prefix for half of the cases the importer has to take
-    sd = {}
-    for k, shape in meta["state_dict_keys"].items():
-        sd["module." + k] = torch.from_numpy(w[k]) if k in w else torch.zeros(shape)
-    return g, cfg, w, sd, synth.lxmert_batch(ps, cfg.text_len)
 
 
 def test_fp32_checkpoint_route_oracle_matches_reference():

@@ -1,0 +1,342 @@
+"""GPU suite, round 2: the fused three-model entry point (BASELINE.json config 5), the fp8 mode, the dense-label feed, x_norm, the
+fp32-checkpoint importer route against the reference's own logits, full-size property tests for lds / lxmert and the ensemble,
+sequence-length guards."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import TOL_P2, act_ref, fp32ckpt_case, small_cfg, vecrel
+from kddcup_2020_multimodalitiesrecall_2nd_place_amd import lib, pipeline, scorers, synth, weights
+from kddcup_2020_multimodalitiesrecall_2nd_place_amd.config import LdsConfig, LxmertConfig, ZkConfig
+from oracle import fp8 as F8
+from oracle import np_models as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _members(cfgs, **kw):
+    ws = {n: weights.make_weights(c) for n, c in cfgs.items()}
+    sc = {n: scorers.make_scorer(cfgs[n], ws[n], **kw) for n in cfgs}
+    return ws, sc
+
+
+def _feeds(cfgs, ps, feats=None):
+    if feats is not None:
+        ps.feats = feats
+    zb = synth.zk_batch(ps, cfgs["zk"].text_len)
+    zb2 = synth.zk_batch(synth.sen2forest_variant(ps), cfgs["zk"].text_len)
+    lb = synth.lds_batch(ps, cfgs["lds"].text_len)
+    xb = synth.lxmert_batch(ps, cfgs["lxmert"].text_len)
+    return zb, zb2, lb, xb
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 5: fused ensemble
+# ---------------------------------------------------------------------------------------------------------------------
+def test_fused_ensemble_full_model_size_matches_oracle_merged_scores():
+    """BASELINE.json config 5 at full model size (12-layer zk / lds, 9-5-5 lxmert): merged score of mms_score_ensemble against
+    0.2*zk + 0.2*zk(sen2forest) + 0.3*lds + 0.3*lxmert of the fp64 oracle's four forwards (code/main.py:59)."""
+    cfgs = {"zk": ZkConfig(), "lds": LdsConfig(), "lxmert": LxmertConfig()}
+    ws, sc = _members(cfgs)
+    ps = synth.make_pairs(3, 4, tag="/ens_full")                      # query 10002 (% 3 == 0) gets the rewritten variant
+    zb, zb2, lb, xb = _feeds(cfgs, ps)
+    ens = scorers.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
+    merged, mem = ens(pipeline.ensemble_feed(zb, zb2, xb))
+    torch.cuda.synchronize()
+    merged, mem = merged.cpu().numpy(), mem.cpu().numpy()
+    ens.close()
+    r = [O.forward(cfgs["zk"], ws["zk"], zb, np.float64)[1][:, 1], O.forward(cfgs["zk"], ws["zk"], zb2, np.float64)[1][:, 1],
+         O.forward(cfgs["lds"], ws["lds"], lb, np.float64)[1][:, 1], O.forward(cfgs["lxmert"], ws["lxmert"], xb, np.float64)[1][:, 1]]
+    for k in range(4):
+        assert np.abs(mem[k] - r[k]).max() < 1e-3, (k, np.abs(mem[k] - r[k]).max())
+    ref = 0.2 * r[0] + 0.2 * r[1] + 0.3 * r[2] + 0.3 * r[3]
+    print("\n[ensemble, full size] max |merged - oracle| %.2e" % np.abs(merged - ref).max())
+    assert np.abs(merged - ref).max() < 1e-3
+    assert not np.allclose(mem[0], mem[1])                            # the rewrite changed at least one query
+
+
+def test_fused_ensemble_equals_four_separate_calls_and_chunks():
+    """The fused call shares the feature split, the label de-duplication and zk's image-token stage; none of that may change a
+    score: bit-identical to the four single-model calls, also when the batch is cut into ragged launch waves."""
+    cfgs = {n: small_cfg(n) for n in ("zk", "lds", "lxmert")}
+    ws, sc = _members(cfgs)
+    ps = synth.make_pairs(7, (3, 9), vocab=cfgs["zk"].vocab, tag="/ens_eq")
+    zb, zb2, lb, xb = _feeds(cfgs, ps)
+    sep = [scorers.score_batch(sc["zk"], zb)[1][:, 1], scorers.score_batch(sc["zk"], zb2)[1][:, 1],
+           scorers.score_batch(sc["lds"], lb)[1][:, 1], scorers.score_batch(sc["lxmert"], xb)[1][:, 1]]
+    ens = scorers.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
+    merged, mem = ens(pipeline.ensemble_feed(zb, zb2, xb))
+    for k in range(4):
+        assert torch.equal(mem[k], sep[k]), k
+    w = ens.WEIGHTS
+    exp = ((w[0] * sep[0] + w[1] * sep[1]) + w[2] * sep[2]) + w[3] * sep[3]
+    assert torch.equal(merged, exp)
+    ens.close()
+    _, sc2 = _members(cfgs, chunk_pairs=5)
+    ens2 = scorers.EnsembleScorer(sc2["zk"], sc2["lds"], sc2["lxmert"])
+    merged2, _ = ens2(pipeline.ensemble_feed(zb, zb2, xb))
+    assert (merged2 - merged).abs().max() < 1e-6
+    m0, mem0 = ens2({k: v[:0] for k, v in pipeline.ensemble_feed(zb, zb2, xb).items()})
+    assert m0.shape == (0,) and mem0.shape == (4, 0)
+    ens2.close()
+
+
+def test_full_size_ensemble_properties():
+    """config 5 at the headline size (1000 x 30 pairs, full models): a subset against the oracle, permutation equivariance."""
+    cfgs = {"zk": ZkConfig(), "lds": LdsConfig(), "lxmert": LxmertConfig()}
+    ws, sc = _members(cfgs)
+    ps = synth.make_pairs(1000, 30, tag="/ens_size", with_feats=False)
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    feats = torch.randn((ps.n, 10, 2048), device=dev, generator=g).clamp_(min=0)
+    feats *= (torch.arange(10, device=dev)[None, :] < torch.as_tensor(ps.num_boxes, device=dev)[:, None])[:, :, None]
+    zb, zb2, lb, xb = _feeds(cfgs, ps, feats)
+    feed = pipeline.ensemble_feed(zb, zb2, xb)
+    ens = scorers.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
+    m1, mem1 = ens(feed)
+    m1b, _ = ens(feed)
+    assert torch.equal(m1, m1b) and torch.isfinite(m1).all() and (m1 >= 0).all() and (m1 <= 1.0 + 1e-6).all()
+    idx = np.sort(np.random.RandomState(0).choice(ps.n, 6, replace=False))
+    ti = torch.as_tensor(idx, device=dev)
+    cut = lambda b: {k: (v[ti].cpu().numpy() if torch.is_tensor(v) else v[idx]) for k, v in b.items()}
+    r = (0.2 * O.forward(cfgs["zk"], ws["zk"], cut(zb), np.float64)[1][:, 1] + 0.2 * O.forward(cfgs["zk"], ws["zk"], cut(zb2), np.float64)[1][:, 1]
+         + 0.3 * O.forward(cfgs["lds"], ws["lds"], cut(lb), np.float64)[1][:, 1] + 0.3 * O.forward(cfgs["lxmert"], ws["lxmert"], cut(xb), np.float64)[1][:, 1])
+    assert np.abs(m1.cpu().numpy()[idx] - r).max() < 1e-3
+    perm = np.random.RandomState(1).permutation(ps.n)
+    tp = torch.as_tensor(perm, device=dev)
+    fp = {k: (v[tp] if torch.is_tensor(v) else v[perm]) for k, v in feed.items()}
+    mp_, _ = ens(fp)
+    assert (mp_ - m1[tp]).abs().max() < 2e-5
+    ens.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# full-size property tests for lds and lxmert (zk has test_parity_gpu.test_full_size_workload_properties)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["lds", "lxmert"])
+def test_full_size_workload_properties(name):
+    cfg = {"lds": LdsConfig(), "lxmert": LxmertConfig()}[name]
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(1000, 30, tag="/fullsize_" + name, with_feats=False)
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(321)
+    feats = torch.randn((ps.n, 10, 2048), device=dev, generator=g).clamp_(min=0)
+    feats *= (torch.arange(10, device=dev)[None, :] < torch.as_tensor(ps.num_boxes, device=dev)[:, None])[:, :, None]
+    ps.feats = feats
+    b = synth.batch_for(cfg, ps)
+    for k in b:                                                      # duplicate pair 7 into the last slot
+        if hasattr(b[k], "__len__") and len(b[k]) == ps.n:
+            b[k][-1] = b[k][7]
+    s = scorers.make_scorer(cfg, w, chunk_pairs=8192)
+    l1, p1 = scorers.score_batch(s, b)
+    l1b, _ = scorers.score_batch(s, b)
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l1b) and torch.equal(l1[-1], l1[7])
+    assert torch.isfinite(l1).all() and (p1.sum(1) - 1).abs().max() < 1e-6
+    l1 = l1.cpu().numpy()
+    idx = np.sort(np.random.RandomState(0).choice(ps.n, 12, replace=False))
+    ti = torch.as_tensor(idx, device=dev)
+    sub = {k: (v[ti].cpu().numpy() if torch.is_tensor(v) else (v[idx] if hasattr(v, "__len__") and len(v) == ps.n else v)) for k, v in b.items()}
+    ref, _ = O.forward(cfg, w, sub, np.float64)
+    assert vecrel(l1[idx], ref).max() < TOL_P2
+    perm = np.random.RandomState(1).permutation(ps.n)
+    tp = torch.as_tensor(perm, device=dev)
+    bp = {k: (v[tp] if torch.is_tensor(v) else (v[perm] if hasattr(v, "__len__") and len(v) == ps.n else v)) for k, v in b.items()}
+    lp, _ = scorers.score_batch(s, bp)
+    assert np.abs(lp.cpu().numpy() - l1[perm]).max() < 3e-4
+    s.close()
+    s2 = scorers.make_scorer(cfg, w, chunk_pairs=3001)
+    l2, _ = scorers.score_batch(s2, b)
+    assert np.abs(l2.cpu().numpy() - l1).max() < 3e-4
+    s2.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 4 shape on one GPU: testB-like ragged candidate sets through the HIP path
+# ---------------------------------------------------------------------------------------------------------------------
+def test_testB_like_set_single_gpu_matches_shardwise_scoring():
+    """994 queries x 8..30 candidates (run_pretraining_predict_score.py:566): scoring the whole job equals scoring each of 8
+    contiguous query blocks on its own (what 8 ranks do) -- pairs are independent, shard boundaries are inert.  Not bit for bit at
+    THIS size: the GEMM engine is chosen per launch by its row count (M >= 16384 rows: persistent ping-pong tiles, below: register-
+    staged tiles; gemm_dispatch.hip), and the two engines sum K in different orders, so a 29 k-pair launch and a 3.6 k-pair launch
+    differ in fp32 round-off (~1e-5 relative on the logits).  Launches in the same regime ARE bit-identical
+    (test_multirank_gpu.py compares ranks against a single rank that way)."""
+    from kddcup_2020_multimodalitiesrecall_2nd_place_amd import sharding
+    cfg = ZkConfig(layers=2)
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(994, (8, 30), tag="/testB", with_feats=False)
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    feats = torch.randn((ps.n, 10, 2048), device=dev, generator=g).clamp_(min=0)
+    feats *= (torch.arange(10, device=dev)[None, :] < torch.as_tensor(ps.num_boxes, device=dev)[:, None])[:, :, None]
+    ps.feats = feats
+    b = synth.zk_batch(ps, cfg.text_len)
+    s = scorers.ZkScorer(cfg, w)
+    whole, _ = scorers.score_batch(s, b)
+    qop = ps.query_id - ps.query_id.min()
+    counts = sharding.shard_sizes(qop, 994, 8)
+    assert sum(counts) == ps.n and len(set(counts)) > 1             # ragged shards
+    parts = []
+    for r in range(8):
+        lo, hi = sharding.query_block(994, 8, r)
+        a, e = sharding.pair_slice_for_queries(qop, lo, hi)
+        parts.append(scorers.score_batch(s, {k: v[a:e] for k, v in b.items()})[0])
+    assert (torch.cat(parts) - whole).abs().max() < 2e-4
+    # same engine regime on both sides: two half-size launches against their own quarters stay bitwise
+    half = scorers.score_batch(s, {k: v[:500] for k, v in b.items()})[0]          # 500 x 30 padded rows < 16384: register-staged tiles
+    q = torch.cat([scorers.score_batch(s, {k: v[i:i + 125] for k, v in b.items()})[0] for i in range(0, 500, 125)])
+    assert torch.equal(half, q)
+    s.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# boundary: x_norm, dense label feed, guards
+# ---------------------------------------------------------------------------------------------------------------------
+def test_lxmert_forward_returns_x_norm():
+    cfg = small_cfg("lxmert")
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(2, 3, vocab=cfg.vocab, tag="/xnorm")
+    b = synth.lxmert_batch(ps, cfg.text_len)
+    s = scorers.LxmertScorer(cfg, w, chunk_pairs=4)
+    x_norm, mlm, logit = s(b["input_ids"], b["boxes_label_input_ids"], None, b["input_mask"], None, b["boxes_label_input_mask"], b["feats"],
+                           b["boxes"], b["visual_attention_mask"])
+    s.close()
+    inter = {}
+    ref, _ = O.forward(cfg, w, b, np.float64, inter)
+    xn = inter["pooled"] / np.maximum(np.linalg.norm(inter["pooled"], axis=1, keepdims=True), 1e-12)
+    assert mlm is None and x_norm.shape == (ps.n, 768)
+    assert np.abs(x_norm - xn).max() < 2e-5 and np.abs(np.linalg.norm(x_norm, axis=1) - 1).max() < 1e-5
+    assert vecrel(logit, ref).max() < TOL_P2
+
+
+def test_dense_and_prededuplicated_label_feeds_agree_bitwise():
+    for name in ("zk", "lxmert"):
+        cfg = small_cfg(name)
+        w = weights.make_weights(cfg)
+        ps = synth.make_pairs(6, (4, 9), vocab=cfg.vocab, tag="/labfeed")
+        b = synth.batch_for(cfg, ps)
+        a = scorers.make_scorer(cfg, w, dedup_labels=True)
+        c = scorers.make_scorer(cfg, w, dedup_labels=False)
+        la, _ = scorers.score_batch(a, b)
+        lc, _ = scorers.score_batch(c, b)
+        assert torch.equal(la, lc), name
+        a.close(); c.close()
+
+
+def test_sequences_beyond_the_attention_kernels_are_rejected():
+    """lds with text_len 29..32 would need 49..52-token attention: mms_create refuses instead of scoring garbage."""
+    l = lib.load()
+    c = lib.Config()
+    c.model, c.layers, c.vocab, c.inter, c.max_pos, c.type_vocab, c.text_len, c.precision = lib.MODEL_LDS, 1, 512, 256, 64, 2, 30, 2
+    h = C.c_void_p()
+    assert l.mms_create(C.byref(c), C.byref(h)) == 1 and b"48-token" in l.mms_global_error()
+    c.text_len = 28
+    assert l.mms_create(C.byref(c), C.byref(h)) == 0
+    l.mms_destroy(h)
+    c.type_vocab = 1
+    assert l.mms_create(C.byref(c), C.byref(h)) == 1
+    q = torch.zeros((2, 64, 64), device="cuda")
+    out = torch.zeros((2, 64, 768), device="cuda")
+    assert l.mms_dbg_attention(q.data_ptr(), q.data_ptr(), q.data_ptr(), 2, 49, 49, None, out.data_ptr(), None) == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (f)4: a checkpoint as the reference saves it -> importer -> precision auto -> HIP, against the REFERENCE's logits
+# ---------------------------------------------------------------------------------------------------------------------
+def test_fp32_state_dict_through_importer_matches_reference_logits():
+    g, cfg, w, sd, b = fp32ckpt_case()
+    imported = weights.from_torch_state_dict(cfg, sd)
+    s = scorers.LxmertScorer(cfg, imported)                           # precision="auto"
+    assert s.precision == 3
+    x_norm, _, logit = s(b["input_ids"], b["boxes_label_input_ids"], None, b["input_mask"], None, b["boxes_label_input_mask"], b["feats"],
+                         b["boxes"], b["visual_attention_mask"])
+    s.close()
+    e = vecrel(logit, g["logit"]).max()
+    print("\n[fp32 checkpoint -> importer -> mode 3] vec-rel vs the reference's own logits: %.2e" % e)
+    assert e < TOL_P2
+    assert np.abs(x_norm - g["x_norm"]).max() < 1e-4
+    s2 = scorers.LxmertScorer(cfg, imported, precision=2)             # what rounding that checkpoint to bf16 would cost
+    _, _, logit2 = s2(b["input_ids"], b["boxes_label_input_ids"], None, b["input_mask"], None, b["boxes_label_input_mask"], b["feats"],
+                      b["boxes"], b["visual_attention_mask"])
+    s2.close()
+    assert vecrel(logit2, g["logit"]).max() > 3 * e
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# precision mode 4 (fp8): kernel exact on its quantised operands; model-level deviation MEASURED and bounded loosely
+# ---------------------------------------------------------------------------------------------------------------------
+F8_CASES = [(300, 768, 2304, lib.ACT_NONE, False), (257, 768, 3072, lib.ACT_GELU_TANH, True), (64, 3072, 768, lib.ACT_NONE, False),
+            (1000, 768, 768, lib.ACT_NONE, False), (520, 128, 256, lib.ACT_GELU_ERF, True), (16500, 256, 512, lib.ACT_NONE, False)]
+
+
+@pytest.mark.parametrize("case", F8_CASES)
+def test_gemm_fp8_matches_numpy_on_the_quantised_operands(case):
+    M, K, N, act, out_f8 = case
+    l = lib.load()
+    a = weights.normal("f8/a/%d/%d" % (M, K), (M, K), 1)
+    a[0, :8] = [500.0, -700.0, 448.0, 1e-4, 2 ** -10, 3 * 2 ** -10, 0.0, -0.0]      # saturation, flush, ties
+    w = weights.normal("f8/w/%d/%d" % (N, K), (N, K), 1, 1.0 / np.sqrt(K))
+    bias = weights.normal("f8/b/%d" % N, (N,), 1, 0.1)
+    out = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    da, dw, db = _dev(a), _dev(w), _dev(bias)
+    rc = l.mms_dbg_gemm_f8(da.data_ptr(), M, K, dw.data_ptr(), N, db.data_ptr(), act, int(out_f8), out.data_ptr(), None)
+    assert rc == 0, l.mms_global_error()
+    wq, _ = F8.quant_weight_rows(w)
+    ref = act_ref(F8.e4m3_round(a) @ wq.T + bias, act)
+    got = out.cpu().numpy().astype(np.float64)
+    if out_f8:                       # the kernel rounds its fp32 result to e4m3: identical up to fp32-vs-fp64 ties
+        refq = F8.e4m3_round(ref)
+        bad = np.abs(got - refq) > 0
+        assert bad.mean() < 2e-3, bad.mean()
+        assert (np.abs(got - ref)[bad] <= np.maximum(np.abs(ref)[bad], 2 ** -6) * 2 ** -3 + 1e-9).all()   # off by one e4m3 step at most
+    else:
+        # not the 2e-7 of an fp32 fma chain: the fp8 MFMA sums its 32 exact products per instruction in a narrower internal format
+        # (measured 7e-6 .. 1.5e-5 of max |ref| here); two orders of magnitude below one e4m3 step all the same
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 5e-5, np.abs(got - ref).max() / np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name", ["zk", "lds", "lxmert"])
+def test_precision4_fp8_measured_deviation(name):
+    """fp8 weights + activations are OUTSIDE the 1e-3 contract ('report measured deviation').  Measured here
+    at full depth against the fp64 oracle: logit vec-rel error, |delta score|, nDCG@5 on a valid-like set."""
+    from kddcup_2020_multimodalitiesrecall_2nd_place_amd import ndcg
+    cfg = {"zk": ZkConfig(), "lds": LdsConfig(), "lxmert": LxmertConfig()}[name]
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(6, (8, 14), tag="/f8dev")
+    b = synth.batch_for(cfg, ps)
+    if name == "zk":
+        b["labels"] = ps.relevance.astype(np.int64)
+    ref, ref_p = O.forward(cfg, w, b, np.float64)
+    s = scorers.make_scorer(cfg, w, precision=4)
+    lg, pr = scorers.score_batch(s, b)
+    got, got_p = lg.cpu().numpy(), pr.cpu().numpy()
+    s.close()
+    s2 = scorers.make_scorer(cfg, w, precision=2)
+    got2 = scorers.score_batch(s2, b)[0].cpu().numpy()
+    s2.close()
+    e = vecrel(got, ref)
+    truth = {}
+    for q, p_, r in zip(ps.query_id, ps.product_id, ps.relevance):
+        truth.setdefault(str(int(q)), [])
+        if r:
+            truth[str(int(q))].append(str(int(p_)))
+    truth = {q: v for q, v in truth.items() if v}
+    n_ref = ndcg.ndcg_from_arrays(ps.query_id, ps.product_id, ref_p[:, 1], truth)
+    n_got = ndcg.ndcg_from_arrays(ps.query_id, ps.product_id, got_p[:, 1], truth)
+    print("\n[%s, precision 4 (fp8)] logit vec-rel median %.3e max %.3e | max |d score| %.3e | nDCG@5 oracle %.4f fp8 %.4f (mode 2 max vec-rel %.1e)"
+          % (name, np.median(e), e.max(), np.abs(got_p[:, 1] - ref_p[:, 1]).max(), n_ref, n_got, vecrel(got2, ref).max()))
+    assert np.isfinite(got).all()
+    assert np.median(e) < 0.35                               # sanity bound only: the numbers printed above are the result (a pair
+                                                             # whose fp64 logits nearly cancel can show a vec-rel above 1)
+    # fp8 must still rank like the model: score correlation with the oracle
+    assert np.corrcoef(got_p[:, 1], ref_p[:, 1])[0, 1] > 0.8
