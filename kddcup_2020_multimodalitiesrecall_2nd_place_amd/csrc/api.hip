@@ -96,11 +96,24 @@ struct mms_handle {
     int64_t dd_rows = 0; int dd_cap = 0;
     int *dd_slots = nullptr, *dd_rep = nullptr, *dd_uid = nullptr, *dd_counter = nullptr, *dd_index = nullptr;
     int32_t* dd_uniq32 = nullptr; int64_t* dd_uniq64 = nullptr;
+    // lxmert distinct-query stage: the language stream of the first l_layers runs once per distinct (input_ids, input_mask)
+    // row; lq_store holds its output rows, dense by (query, token), for the pair chunks to copy from
+    std::vector<void*> lq_allocs;
+    int64_t lq_pairs = 0, lq_store_q = 0, lq_sub = 0;
+    int *lq_slots = nullptr, *lq_rep = nullptr, *lq_uid = nullptr, *lq_counter = nullptr, *lq_rows_of = nullptr, *lq_index = nullptr;
+    int lq_cap = 0;
+    int64_t *lq_ids = nullptr, *lq_mask = nullptr;
+    Planes lq_store;
+    bool lq_active = false;
     // fused three-model entry point: feed conversions and member outputs, sized for ens_pairs
     std::vector<void*> ens_allocs;
     int64_t ens_pairs = 0;
     int32_t* ens_seg = nullptr; int64_t *ens_ids64 = nullptr, *ens_seg64 = nullptr, *ens_lab64 = nullptr, *ens_mask64 = nullptr;
     float *ens_vmask = nullptr, *ens_boxes4 = nullptr, *ens_logits = nullptr, *ens_probs = nullptr, *ens_tok = nullptr;
+    // second zk member: pairs whose query the rewrite changed (flags, per-wave offsets / lists / counts, compacted feeds and outputs)
+    int *ens_diff = nullptr, *ens_doff = nullptr, *ens_dlist = nullptr, *ens_dcount = nullptr;
+    int32_t *ens_cq = nullptr, *ens_clen = nullptr, *ens_cnb = nullptr; int64_t* ens_clab = nullptr;
+    float *ens_ctok = nullptr, *ens_clog = nullptr, *ens_cprob = nullptr; int64_t ens_cpairs = 0;
 
     // ---- gemm timing ----
     bool timing = false;
@@ -847,6 +860,77 @@ int lx_label_features(mms_handle* h, hipStream_t st, const int64_t* uniq_ids, in
     return MMS_OK;
 }
 
+// Distinct-query stage (packed mode only).  In modeling.py:568-593 the language stream passes its l_layers BertLayers before it
+// ever meets the image, so their output depends on (input_ids, input_mask) alone -- and a query arrives with its whole candidate
+// set (8..30 pairs, run_pretraining_predict_score.py:566 / kdd_data.py).  The reference recomputes it per pair; here the distinct
+// rows are found on the device (batchops.hip), embedded and run through the l_layers ONCE, stored dense by (query, token), and
+// lx_chunk copies each pair's live language rows from the store.  Per-row arithmetic is unchanged (same kernels, same weights).
+// Skipped (lq_active = false -> the per-pair path) when fewer than half of the pairs share their query with another pair.
+int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t B, int cs) {
+    const mms_config& c = h->cfg;
+    h->lq_active = false;
+    if (!c.pack_tokens || c.stop_after >= 0 || c.layers <= 0 || B < 2) return MMS_OK;
+    const int T = c.text_len;
+    if (B > h->lq_pairs) {
+        free_pool(h->lq_allocs);
+        h->lq_pairs = 0; h->lq_store_q = 0; h->lq_sub = 0;
+        int cap = 1024;
+        while (cap < 2 * B) cap <<= 1;
+        void* p;
+        auto get = [&](size_t bytes, void** out) { int rc = dev_alloc(h, h->lq_allocs, &p, bytes); *out = p; return rc; };
+        if (int rc = get((size_t)cap * 4, (void**)&h->lq_slots)) return rc;
+        if (int rc = get((size_t)B * 4, (void**)&h->lq_rep)) return rc;
+        if (int rc = get((size_t)B * 4, (void**)&h->lq_uid)) return rc;
+        if (int rc = get((size_t)B * 4, (void**)&h->lq_rows_of)) return rc;
+        if (int rc = get((size_t)B * 4, (void**)&h->lq_index)) return rc;
+        if (int rc = get(16, (void**)&h->lq_counter)) return rc;
+        h->lq_cap = cap;
+        h->lq_pairs = B;
+    }
+    launch_query_dedup(b->input_ids, b->input_mask, T, (int)B, h->lq_slots, h->lq_cap, h->lq_rep, h->lq_uid, h->lq_counter, h->lq_rows_of,
+                       h->lq_index, st);
+    int nq = 0;
+    HIP_TRY(h, hipMemcpyAsync(&nq, h->lq_counter, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    const int64_t Q = nq;
+    if (Q * 2 > B) return MMS_OK;                       // little sharing: not worth the extra copy
+    if (Q > h->lq_store_q) {                            // store planes (dense [Q, T] rows) live outside the chunk workspace
+        if (h->lq_store.hi) { (void)hipFree(h->lq_store.hi); h->lq_store.hi = nullptr; }
+        void* p = nullptr;
+        HIP_TRY(h, hipMalloc(&p, (size_t)Q * T * H * 4));
+        h->lq_store.hi = (bf16*)p; h->lq_store.lo = h->lq_store.hi + Q * T * H;
+        h->lq_store_q = Q;
+    }
+    if (cs > h->lq_sub) {                               // gathered inputs of one sub-batch of distinct queries
+        void* p;
+        if (int rc = dev_alloc(h, h->lq_allocs, &p, (size_t)cs * T * 8)) return rc;
+        h->lq_ids = (int64_t*)p;
+        if (int rc = dev_alloc(h, h->lq_allocs, &p, (size_t)cs * T * 8)) return rc;
+        h->lq_mask = (int64_t*)p;
+        h->lq_sub = cs;
+    }
+    for (int64_t u0 = 0; u0 < Q; u0 += cs) {
+        const int64_t n = (Q - u0) < cs ? (Q - u0) : cs;
+        launch_gather_i64_rows(b->input_ids, h->lq_rows_of + u0, T, n, h->lq_ids, st);
+        launch_gather_i64_rows(b->input_mask, h->lq_rows_of + u0, T, n, h->lq_mask, st);
+        launch_lx_pack_plan(h->lq_mask, nullptr, T, (int)n, h->pk_off[0], h->pk_cnt[0], h->pk_src[0], h->key_add, h->pk_rows, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, st);
+        Pack pl;
+        pl.off = h->pk_off[0]; pl.cnt = h->pk_cnt[0]; pl.rows = h->pk_rows;
+        launch_lx_embed_lang_packed(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, h->lq_ids, T, c.vocab, h->pk_src[0], h->pk_rows,
+                                    (int)(n * T), h->x.hi, h->x.lo, st);
+        if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, n * T * H, st);
+        for (int i = 0; i < c.layers; ++i) {
+            if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, T, n, h->key_add, pl)) return rc;
+            if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * T, ACT_GELU_ERF, pl)) return rc;
+        }
+        // packed row r holds token pk_src[r] = u_local * T + t  ->  store row (u0 + u_local) * T + t
+        launch_rows_scatter(h->x.hi, h->x.lo, h->pk_src[0], h->pk_rows, (int)(n * T), h->lq_store.hi + u0 * T * H, h->lq_store.lo + u0 * T * H, st);
+    }
+    h->lq_active = true;
+    return MMS_OK;
+}
+
 int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int32_t* label_index, int64_t p0, int64_t n, float* logits,
              float* probs, const Planes* featp_shared = nullptr) {
     const mms_config& c = h->cfg;
@@ -866,8 +950,11 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
                             h->pk_src[0], lang_add, h->pk_rows, h->pk_off[1], h->pk_cnt[1], h->pk_src[1], visn_add, h->pk_rows + 1, st);
         pl.off = h->pk_off[0]; pl.cnt = h->pk_cnt[0]; pl.rows = h->pk_rows;
         pv.off = h->pk_off[1]; pv.cnt = h->pk_cnt[1]; pv.rows = h->pk_rows + 1;
-        launch_lx_embed_lang_packed(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->pk_src[0],
-                                    h->pk_rows, (int)ML, h->x.hi, h->x.lo, st);
+        if (h->lq_active)   // language rows after the l_layers, copied from the distinct-query store (pair p0 + src / T, token src % T)
+            launch_rows_gather(h->lq_store.hi, h->lq_store.lo, h->pk_src[0], h->lq_index + p0, T, h->pk_rows, (int)ML, h->x.hi, h->x.lo, st);
+        else
+            launch_lx_embed_lang_packed(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->pk_src[0],
+                                        h->pk_rows, (int)ML, h->x.hi, h->x.lo, st);
         launch_lx_visn(xf, h->g_visn, h->be_visn, b->boxes + p0 * V * 4, 4, h->w_box, h->b_box, h->g_box, h->be_box, h->lab_feat,
                        label_index + p0 * V, (int)h->n_labels, h->x.hi + ML * H, h->x.lo + ML * H, (int)MV, st, h->pk_src[1], h->pk_rows + 1);
     } else {
@@ -878,7 +965,7 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
     }
     if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, R * H, st);
     int budget = c.stop_after >= 0 ? c.stop_after : (1 << 30);
-    for (int i = 0; i < c.layers && budget > 0; ++i, --budget) {
+    for (int i = 0; i < c.layers && budget > 0 && !h->lq_active; ++i, --budget) {
         if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, T, n, lang_add, pl)) return rc;
         if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, ML, ACT_GELU_ERF, pl)) return rc;
     }
@@ -1013,6 +1100,8 @@ void mms_destroy(mms_handle* h) {
     free_pool(h->lab_allocs);
     free_pool(h->dd_allocs);
     free_pool(h->ens_allocs);
+    free_pool(h->lq_allocs);
+    if (h->lq_store.hi) (void)hipFree(h->lq_store.hi);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     delete h;
 }
@@ -1108,6 +1197,7 @@ int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, fl
         uniq = h->dd_uniq64; index = h->dd_index;
     }
     if (int rc = lx_label_features(h, st, uniq, U)) return rc;
+    if (int rc = lx_query_stage(h, st, b, B, cs)) return rc;
     for (int64_t p0 = 0; p0 < B; p0 += cs)
         if (int rc = lx_chunk(h, st, b, index, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
     return post_launch(h);
@@ -1129,6 +1219,11 @@ static int ensure_ens_ws(mms_handle* z, int64_t B, int T, int TL) {
     if (int rc = get((size_t)B * MMS_NBOX * 4 * 4, (void**)&z->ens_boxes4)) return rc;
     if (int rc = get((size_t)B * 2 * 4 * 4, (void**)&z->ens_logits)) return rc;
     if (int rc = get((size_t)B * 2 * 4 * 4, (void**)&z->ens_probs)) return rc;
+    if (int rc = get((size_t)B * 4, (void**)&z->ens_diff)) return rc;
+    if (int rc = get((size_t)B * 4, (void**)&z->ens_doff)) return rc;
+    if (int rc = get((size_t)B * 4, (void**)&z->ens_dlist)) return rc;
+    if (int rc = get((size_t)(B / 64 + 16) * 4, (void**)&z->ens_dcount)) return rc;
+    z->ens_cpairs = 0;
     z->ens_pairs = B;
     return MMS_OK;
 }
@@ -1186,6 +1281,7 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
     mms_lxmert_batch xb{};
     xb.n_pairs = B; xb.input_ids = lx_ids; xb.input_mask = lx_mask; xb.feats = b->feats; xb.boxes = z->ens_boxes4;
     xb.visual_attention_mask = z->ens_vmask;
+    if (int rc = lx_query_stage(x, st, &xb, B, cs)) return z->fail(rc, "lxmert member: " + x->err);
     float* lg[4]; float* pr[4];
     for (int k = 0; k < 4; ++k) { lg[k] = z->ens_logits + (int64_t)k * B * 2; pr[k] = z->ens_probs + (int64_t)k * B * 2; }
 
@@ -1194,6 +1290,43 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
         void* p;
         if (int rc = dev_alloc(z, z->ws_allocs, &p, (size_t)z->ws_pairs * MMS_NBOX * H * 4)) return rc;   // lives and dies with the workspace
         z->ens_tok = (float*)p;
+    }
+    // second zk member: the rewrite (load_data_v4.py:153-154) touches only queries that contain the phrase; every other pair's second
+    // forward would repeat the first one bit for bit, so only the changed pairs are encoded again (per launch wave: flags -> scan ->
+    // compact list; the per-wave counts come back in one small read)
+    launch_query_differs(b->query_ids, b->len_query, b->s2f_query_ids, b->s2f_len_query, T, (int)B, z->ens_diff, st);
+    const int n_waves = (int)((B + cs - 1) / cs);
+    if (n_waves > (int)(B / 64 + 16)) return z->fail(MMS_ERR_ARG, "mms_score_ensemble: chunk_pairs too small for this batch");
+    for (int wv = 0; wv < n_waves; ++wv) {
+        const int64_t p0 = (int64_t)wv * cs, n = (B - p0) < cs ? (B - p0) : cs;
+        launch_plan_scan(z->ens_diff + p0, (int)n, z->ens_doff + p0, z->ens_dcount + wv, st);
+        launch_compact_list(z->ens_diff + p0, z->ens_doff + p0, (int)n, z->ens_dlist + p0, st);
+    }
+    std::vector<int> changed(n_waves);
+    HIP_TRY(z, hipMemcpyAsync(changed.data(), z->ens_dcount, (size_t)n_waves * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(z, hipStreamSynchronize(st));
+    {
+        int64_t need = 0;
+        for (int v : changed) need = v > need ? v : need;
+        if (need > z->ens_cpairs) {
+            void* p;
+            const int S = T + MMS_NBOX; (void)S;
+            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * T * 4)) return rc;
+            z->ens_cq = (int32_t*)p;
+            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * 4)) return rc;
+            z->ens_clen = (int32_t*)p;
+            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * 4)) return rc;
+            z->ens_cnb = (int32_t*)p;
+            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * 8)) return rc;
+            z->ens_clab = (int64_t*)p;
+            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * MMS_NBOX * H * 4)) return rc;
+            z->ens_ctok = (float*)p;
+            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * 2 * 4)) return rc;
+            z->ens_clog = (float*)p;
+            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * 2 * 4)) return rc;
+            z->ens_cprob = (float*)p;
+            z->ens_cpairs = need;
+        }
     }
     for (int64_t p0 = 0; p0 < B; p0 += cs) {
         const int64_t n = (B - p0) < cs ? (B - p0) : cs;
@@ -1206,7 +1339,21 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
         if (int rc = zk_image_tokens(z, st, &zb, index, p0, n, &featp)) return rc;
         HIP_TRY(z, hipMemcpyAsync(z->ens_tok, z->qkv + NB * H, (size_t)NB * H * 4, hipMemcpyDeviceToDevice, st));
         if (int rc = zk_encode(z, st, &zb, p0, n, z->ens_tok, lg[0], pr[0])) return rc;
-        if (int rc = zk_encode(z, st, &zb2, p0, n, z->ens_tok, lg[1], pr[1])) return rc;
+        const int64_t n2 = changed[p0 / cs];
+        if (n2 > 0) {   // the changed pairs of this wave, compacted: rewritten query + their rows of the shared image tokens
+            const int* list = z->ens_dlist + p0;
+            launch_gather_rows_i32(b->s2f_query_ids + p0 * T, list, T, n2, z->ens_cq, st);
+            launch_gather_rows_i32(b->s2f_len_query + p0, list, 1, n2, z->ens_clen, st);
+            launch_gather_rows_i32(b->num_boxes + p0, list, 1, n2, z->ens_cnb, st);
+            launch_gather_rows_i64(b->labels + p0, list, 1, n2, z->ens_clab, st);
+            launch_gather_rows_f32x4(z->ens_tok, list, MMS_NBOX * H, n2, z->ens_ctok, st);
+            mms_zk_batch zc = zb2;
+            zc.n_pairs = n2; zc.query_ids = z->ens_cq; zc.len_query = z->ens_clen; zc.num_boxes = z->ens_cnb; zc.labels = z->ens_clab;
+            zc.segment_ids = z->ens_seg;                                  // the same 0 x T, 1 x 10 pattern for every pair
+            if (int rc = zk_encode(z, st, &zc, 0, n2, z->ens_ctok, z->ens_clog, z->ens_cprob)) return rc;
+        }
+        launch_select_rows2(z->ens_diff + p0, z->ens_doff + p0, lg[0] + p0 * 2, z->ens_clog, (int)n, lg[1] + p0 * 2, st);
+        launch_select_rows2(z->ens_diff + p0, z->ens_doff + p0, pr[0] + p0 * 2, z->ens_cprob, (int)n, pr[1] + p0 * 2, st);
     }
     const float* prc[4] = {pr[0], pr[1], pr[2], pr[3]};
     launch_merge4(prc, weights4, merged, member_scores, B, st);

@@ -86,6 +86,100 @@ void dedup(const T* ids, int rows, int* slots, int cap, int* rep, int* uid, int*
     hipLaunchKernelGGL(k_dedup_index, grid, block, 0, st, rows, rep, uid, index);
 }
 
+// ---- lxmert query de-duplication: key = (input_ids[T], input_mask[T]) of a pair; the language stream of the first l_layers
+// depends on nothing else (modeling.py:568-593: lang_feats only meets the image in the x_layers), and a query comes with 8..30
+// candidates, so those layers run once per DISTINCT query and their rows are copied to the query's pairs.
+__device__ __forceinline__ unsigned qhash(const int64_t* ids, const int64_t* mask, int T) {
+    unsigned h = 0x9E3779B9u;
+    for (int i = 0; i < T; ++i) {
+        h ^= (unsigned)ids[i] * 2u + (unsigned)(mask[i] != 0) + 0x7F4A7C15u + (h << 6) + (h >> 2);
+        h *= 0x85EBCA6Bu;
+        h ^= h >> 13;
+    }
+    return h;
+}
+__device__ __forceinline__ bool qeq(const int64_t* a, const int64_t* am, const int64_t* b, const int64_t* bm, int T) {
+    bool e = true;
+    for (int i = 0; i < T; ++i) e = e && a[i] == b[i] && am[i] == bm[i];
+    return e;
+}
+__global__ __launch_bounds__(256) void k_qdedup_insert(const int64_t* ids, const int64_t* mask, int T, int rows, int* slots, unsigned cmask,
+                                                       int* rep) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const int64_t *mi = ids + (long long)r * T, *mm = mask + (long long)r * T;
+    unsigned h = qhash(mi, mm, T) & cmask;
+    for (;;) {
+        int s = slots[h];
+        if (s < 0) {
+            const int old = atomicCAS(&slots[h], -1, r);
+            s = old < 0 ? r : old;
+        }
+        if (s == r || qeq(ids + (long long)s * T, mask + (long long)s * T, mi, mm, T)) { rep[r] = s; return; }
+        h = (h + 1) & cmask;
+    }
+}
+// claimants take consecutive numbers; rows_of[u] = the pair row that holds distinct query u
+__global__ __launch_bounds__(256) void k_qdedup_number(int rows, const int* rep, int* uid, int* counter, int* rows_of) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows || rep[r] != r) return;
+    const int u = atomicAdd(counter, 1);
+    uid[r] = u;
+    rows_of[u] = r;
+}
+__global__ __launch_bounds__(256) void k_gather_i64_rows(const int64_t* in, const int* rows_of, int T, long long n, int64_t* out) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = in[(long long)rows_of[i / T] * T + i % T];
+}
+// plane rows: dst[dst_base + map(r)] = src[r]  (scatter, idx == nullptr)  or  dst[r] = src[idx[map(r) / T] * T + map(r) % T]  (gather)
+__global__ __launch_bounds__(256) void k_rows_scatter(const bf16* s_hi, const bf16* s_lo, const int* map, const int* rows_dev, int max_rows,
+                                                      bf16* d_hi, bf16* d_lo) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= max_rows || row >= *rows_dev) return;
+    const long long so = (long long)row * MMS_HIDDEN, d = (long long)map[row] * MMS_HIDDEN;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        *reinterpret_cast<bf16x4*>(d_hi + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_hi + so + t * 256 + lane * 4);
+        *reinterpret_cast<bf16x4*>(d_lo + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_lo + so + t * 256 + lane * 4);
+    }
+}
+__global__ __launch_bounds__(256) void k_rows_gather(const bf16* s_hi, const bf16* s_lo, const int* map, const int* idx, int T, const int* rows_dev,
+                                                     int max_rows, bf16* d_hi, bf16* d_lo) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= max_rows || row >= *rows_dev) return;
+    const int m = map[row];
+    const long long so = ((long long)idx[m / T] * T + m % T) * MMS_HIDDEN, d = (long long)row * MMS_HIDDEN;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        *reinterpret_cast<bf16x4*>(d_hi + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_hi + so + t * 256 + lane * 4);
+        *reinterpret_cast<bf16x4*>(d_lo + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_lo + so + t * 256 + lane * 4);
+    }
+}
+
+// ---- second zk member of the ensemble: only the pairs whose query the sen2forest rewrite actually changed are re-encoded ----
+__global__ __launch_bounds__(256) void k_query_differs(const int32_t* q1, const int32_t* l1, const int32_t* q2, const int32_t* l2, int T, int n,
+                                                       int* diff) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    bool d = l1[b] != l2[b];
+    for (int i = 0; i < T; ++i) d = d || q1[(long long)b * T + i] != q2[(long long)b * T + i];
+    diff[b] = d ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_compact_list(const int* diff, const int* off, int n, int* list) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < n && diff[b]) list[off[b]] = b;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_rows(const T* in, const int* list, int width, long long n, T* out) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = in[(long long)list[i / width] * width + i % width];
+}
+// out[b] = diff[b] ? changed[off[b]] : same[b]   for 2-wide rows (logits / probs)
+__global__ __launch_bounds__(256) void k_select_rows2(const int* diff, const int* off, const float* same, const float* changed, int n, float* out) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    const float2 v = diff[b] ? reinterpret_cast<const float2*>(changed)[off[b]] : reinterpret_cast<const float2*>(same)[b];
+    reinterpret_cast<float2*>(out)[b] = v;
+}
+
 __global__ __launch_bounds__(256) void k_i32_to_i64(const int32_t* in, int64_t* out, long long n) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = in[i];
 }
@@ -148,6 +242,47 @@ void launch_label_dedup_i32(const int32_t* ids, int rows, int* slots, int cap, i
 void launch_label_dedup_i64(const int64_t* ids, int rows, int* slots, int cap, int* rep, int* uid, int* counter, int32_t* uniq32,
                             int64_t* uniq64, int* index, hipStream_t st) {
     if (rows > 0) dedup<int64_t>(ids, rows, slots, cap, rep, uid, counter, uniq32, uniq64, index, st);
+}
+void launch_query_dedup(const int64_t* ids, const int64_t* mask, int T, int rows, int* slots, int cap, int* rep, int* uid, int* counter,
+                        int* rows_of, int* index, hipStream_t st) {
+    if (rows <= 0) return;
+    (void)hipMemsetAsync(slots, 0xFF, (size_t)cap * 4, st);
+    (void)hipMemsetAsync(counter, 0, 4, st);
+    const dim3 grid((rows + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_qdedup_insert, grid, block, 0, st, ids, mask, T, rows, slots, (unsigned)(cap - 1), rep);
+    hipLaunchKernelGGL(k_qdedup_number, grid, block, 0, st, rows, rep, uid, counter, rows_of);
+    hipLaunchKernelGGL(k_dedup_index, grid, block, 0, st, rows, rep, uid, index);
+}
+void launch_gather_i64_rows(const int64_t* in, const int* rows_of, int T, long long n_rows, int64_t* out, hipStream_t st) {
+    if (n_rows > 0) hipLaunchKernelGGL(k_gather_i64_rows, flat_grid(n_rows * T), dim3(256), 0, st, in, rows_of, T, n_rows * T, out);
+}
+void launch_rows_scatter(const bf16* s_hi, const bf16* s_lo, const int* map, const int* rows_dev, int max_rows, bf16* d_hi, bf16* d_lo,
+                         hipStream_t st) {
+    if (max_rows > 0) hipLaunchKernelGGL(k_rows_scatter, dim3((max_rows + 3) / 4), dim3(256), 0, st, s_hi, s_lo, map, rows_dev, max_rows, d_hi, d_lo);
+}
+void launch_rows_gather(const bf16* s_hi, const bf16* s_lo, const int* map, const int* idx, int T, const int* rows_dev, int max_rows,
+                        bf16* d_hi, bf16* d_lo, hipStream_t st) {
+    if (max_rows > 0) hipLaunchKernelGGL(k_rows_gather, dim3((max_rows + 3) / 4), dim3(256), 0, st, s_hi, s_lo, map, idx, T, rows_dev, max_rows, d_hi, d_lo);
+}
+void launch_query_differs(const int32_t* q1, const int32_t* l1, const int32_t* q2, const int32_t* l2, int T, int n, int* diff, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_query_differs, dim3((n + 255) / 256), dim3(256), 0, st, q1, l1, q2, l2, T, n, diff);
+}
+void launch_compact_list(const int* diff, const int* off, int n, int* list, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_compact_list, dim3((n + 255) / 256), dim3(256), 0, st, diff, off, n, list);
+}
+void launch_gather_rows_i32(const int32_t* in, const int* list, int width, long long n_rows, int32_t* out, hipStream_t st) {
+    if (n_rows > 0) hipLaunchKernelGGL((k_gather_rows<int32_t>), flat_grid(n_rows * width), dim3(256), 0, st, in, list, width, n_rows * width, out);
+}
+void launch_gather_rows_i64(const int64_t* in, const int* list, int width, long long n_rows, int64_t* out, hipStream_t st) {
+    if (n_rows > 0) hipLaunchKernelGGL((k_gather_rows<int64_t>), flat_grid(n_rows * width), dim3(256), 0, st, in, list, width, n_rows * width, out);
+}
+void launch_gather_rows_f32x4(const float* in, const int* list, int width, long long n_rows, float* out, hipStream_t st) {   // width % 4 == 0
+    if (n_rows > 0)
+        hipLaunchKernelGGL((k_gather_rows<float4>), flat_grid(n_rows * (width / 4)), dim3(256), 0, st, (const float4*)in, list, width / 4,
+                           n_rows * (width / 4), (float4*)out);
+}
+void launch_select_rows2(const int* diff, const int* off, const float* same, const float* changed, int n, float* out, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_select_rows2, dim3((n + 255) / 256), dim3(256), 0, st, diff, off, same, changed, n, out);
 }
 void launch_i32_to_i64(const int32_t* in, int64_t* out, long long n, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_i32_to_i64, flat_grid(n), dim3(256), 0, st, in, out, n);

@@ -135,6 +135,24 @@ void launch_label_dedup_i32(const int32_t* ids, int rows, int* slots, int cap, i
                             int64_t* uniq64, int* index, hipStream_t st);
 void launch_label_dedup_i64(const int64_t* ids, int rows, int* slots, int cap, int* rep, int* uid, int* counter, int32_t* uniq32,
                             int64_t* uniq64, int* index, hipStream_t st);
+// distinct (input_ids, input_mask) rows of a lxmert batch: index[b] = distinct-query number of pair b, rows_of[u] = a pair row holding query u
+void launch_query_dedup(const int64_t* ids, const int64_t* mask, int T, int rows, int* slots, int cap, int* rep, int* uid, int* counter,
+                        int* rows_of, int* index, hipStream_t st);
+void launch_gather_i64_rows(const int64_t* in, const int* rows_of, int T, long long n_rows, int64_t* out, hipStream_t st);
+// packed plane rows r < *rows_dev:  scatter: d[map[r]] = s[r];  gather: d[r] = s[idx[map[r] / T] * T + map[r] % T]
+void launch_rows_scatter(const bf16* s_hi, const bf16* s_lo, const int* map, const int* rows_dev, int max_rows, bf16* d_hi, bf16* d_lo,
+                         hipStream_t st);
+void launch_rows_gather(const bf16* s_hi, const bf16* s_lo, const int* map, const int* idx, int T, const int* rows_dev, int max_rows,
+                        bf16* d_hi, bf16* d_lo, hipStream_t st);
+// ensemble, second zk member: diff[b] = the rewritten query of pair b differs from the original; compact list of those pairs; row gathers;
+// out[b] = diff[b] ? changed[off[b]] : same[b] on [n,2] rows
+void launch_query_differs(const int32_t* q1, const int32_t* l1, const int32_t* q2, const int32_t* l2, int T, int n, int* diff, hipStream_t st);
+void launch_compact_list(const int* diff, const int* off, int n, int* list, hipStream_t st);
+void launch_gather_rows_i32(const int32_t* in, const int* list, int width, long long n_rows, int32_t* out, hipStream_t st);
+void launch_gather_rows_i64(const int64_t* in, const int* list, int width, long long n_rows, int64_t* out, hipStream_t st);
+void launch_gather_rows_f32x4(const float* in, const int* list, int width, long long n_rows, float* out, hipStream_t st);
+void launch_select_rows2(const int* diff, const int* off, const float* same, const float* changed, int n, float* out, hipStream_t st);
+void launch_plan_scan(const int* cnt, int n, int* off, int* total_dev, hipStream_t st);   // exclusive scan of n counts (rowops.hip)
 void launch_i32_to_i64(const int32_t* in, int64_t* out, long long n, hipStream_t st);
 void launch_fill_i64(int64_t* out, long long n, int64_t v, hipStream_t st);
 void launch_zk_segment_ids(int32_t* out, long long B, int T, hipStream_t st);

@@ -640,6 +640,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_scan(const int* cnt, int 
     if (tid == 0) *rows_dev = total;
 }
 
+void launch_plan_scan(const int* cnt, int n, int* off, int* total_dev, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PLAN_THREADS), 0, st, cnt, n, off, total_dev);
+}
+
 __global__ __launch_bounds__(256) void k_zk_plan_count(const int* len_query, const int* num_boxes, int T, int n, int* cnt) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= n) return;
@@ -702,6 +706,7 @@ __global__ __launch_bounds__(256) void k_lx_plan_count(const int64_t* input_mask
     int live = 0;
     for (int s = 0; s < T; ++s) live += input_mask[(long long)b * T + s] != 0;
     l_cnt[b] = live == 0 ? T : live + (input_mask[(long long)b * T] == 0 ? 1 : 0);
+    if (!visual_mask) return;   // language-only plan (distinct-query stage)
     int lv = 0;
     for (int j = 0; j < MMS_NBOX; ++j) lv += visual_mask[(long long)b * MMS_NBOX + j] != 0.f;
     v_cnt[b] = lv == 0 ? MMS_NBOX : lv;
@@ -722,6 +727,7 @@ __global__ __launch_bounds__(256) void k_lx_plan_fill(const int64_t* input_mask,
             ++c;
         }
     }
+    if (!visual_mask) return;
     live = 0;
     for (int j = 0; j < V; ++j) live += visual_mask[(long long)b * V + j] != 0.f;
     base = v_off[b]; c = 0;
@@ -740,7 +746,7 @@ void launch_lx_pack_plan(const int64_t* input_mask, const float* visual_mask, in
     const dim3 grid((n + 255) / 256);
     hipLaunchKernelGGL(k_lx_plan_count, grid, dim3(256), 0, st, input_mask, visual_mask, T, n, l_cnt, v_cnt);
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PLAN_THREADS), 0, st, l_cnt, n, l_off, l_rows);
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PLAN_THREADS), 0, st, v_cnt, n, v_off, v_rows);
+    if (visual_mask) hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PLAN_THREADS), 0, st, v_cnt, n, v_off, v_rows);
     hipLaunchKernelGGL(k_lx_plan_fill, grid, dim3(256), 0, st, input_mask, visual_mask, T, n, l_off, l_src, l_add, v_off, v_src, v_add);
 }
 

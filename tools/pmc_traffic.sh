@@ -7,7 +7,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc -o ${tag}_$c -- python $R/bench.py --steps 1 --warmup 0 --no-cpu "$@" > $R/gpurun_out/pmc/${tag}_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc -o ${tag}_$c -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-secondary "$@" > $R/gpurun_out/pmc/${tag}_$c.log 2>&1
 done
 python - <<PY
 import csv, json, collections
