@@ -340,3 +340,49 @@ def test_precision4_fp8_measured_deviation(name):
                                                              # whose fp64 logits nearly cancel can show a vec-rel above 1)
     # fp8 must still rank like the model: score correlation with the oracle
     assert np.corrcoef(got_p[:, 1], ref_p[:, 1])[0, 1] > 0.8
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# work shared between pairs: lxmert's language layers once per distinct query; the ensemble's second zk member only where the
+# rewrite changed the query
+# ---------------------------------------------------------------------------------------------------------------------
+def test_lxmert_distinct_query_stage_equals_per_pair_scoring():
+    """A query's candidates share the l_layers language stream (modeling.py:568-593).  Scoring a batch (stage active: every query
+    has several candidates) must equal scoring each pair alone (a 1-pair call cannot share anything) and the fp64 oracle; masks
+    that differ inside one query's candidates must NOT be merged."""
+    cfg = small_cfg("lxmert", l_layers=3)
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(5, (2, 6), vocab=cfg.vocab, tag="/lq")
+    b = synth.lxmert_batch(ps, cfg.text_len)
+    b["input_mask"][1, 2] = 0                   # same ids as pair 0 (same query), different mask -> a different distinct row
+    b["input_ids"][3] = b["input_ids"][0]       # a later pair repeating the first query (non-contiguous sharing)
+    b["input_mask"][3] = b["input_mask"][0]
+    ref, _ = O.forward(cfg, w, b, np.float64)
+    for chunk in (0, 4):
+        s = scorers.LxmertScorer(cfg, w, chunk_pairs=chunk)
+        batch = scorers.score_batch(s, b)[0].cpu().numpy()
+        single = np.concatenate([scorers.score_batch(s, {k: v[i:i + 1] for k, v in b.items()})[0].cpu().numpy() for i in range(ps.n)])
+        s.close()
+        assert vecrel(batch, ref).max() < TOL_P2
+        assert np.abs(batch - single).max() < 1e-5, np.abs(batch - single).max()
+    s = scorers.LxmertScorer(cfg, w, precision=4)      # the fp8 mode goes through the same stage
+    assert np.isfinite(scorers.score_batch(s, b)[0].cpu().numpy()).all()
+    s.close()
+
+
+def test_ensemble_second_zk_member_with_no_and_all_queries_changed():
+    cfgs = {n: small_cfg(n) for n in ("zk", "lds", "lxmert")}
+    ws, sc = _members(cfgs, chunk_pairs=6)
+    ps = synth.make_pairs(4, (3, 5), vocab=cfgs["zk"].vocab, tag="/ens_s2f")
+    zb, zb2, lb, xb = _feeds(cfgs, ps)
+    ens = scorers.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
+    _, m_same = ens(pipeline.ensemble_feed(zb, zb, xb))                       # rewrite changed nothing: member 1 == member 0
+    assert torch.equal(m_same[0], m_same[1])
+    allch = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in zb.items()}
+    allch["np_idx_query_"][:, 1] = 2000                                       # every query rewritten
+    _, m_all = ens(pipeline.ensemble_feed(zb, allch, xb))
+    sep = scorers.score_batch(sc["zk"], allch)[1][:, 1]
+    assert torch.equal(m_all[1], sep) and torch.equal(m_all[0], m_same[0])
+    _, m_mix = ens(pipeline.ensemble_feed(zb, zb2, xb))
+    assert torch.equal(m_mix[1], scorers.score_batch(sc["zk"], zb2)[1][:, 1])
+    ens.close()
