@@ -69,6 +69,12 @@ typedef struct mms_config {
     int32_t pack_tokens;      /* zk/lxmert: 1 = drop padded tokens whose keys are masked (identical logits: a masked
                                  key's softmax weight is exactly 0 in fp32); 0 = dense padded rows like the reference.
                                  lds has no mask (pixelmodel.py:189-190) and must use 0 */
+    int32_t fuse_layernorm;   /* 1: the N = 768 projections (attention output, FFN down) of launches with >= 16384 rows add the
+                                 residual and apply the LayerNorm in their GEMM epilogue (gemm_pp_ln.h: the three column tiles of
+                                 a row panel exchange row statistics across workgroups; precision modes 2 and 4), instead of
+                                 writing the fp32 sum for a separate LayerNorm kernel.  Same results to fp32 round-off; 12 -> 6 KB
+                                 of HBM traffic per row and LayerNorm, but measured NOT faster on MI355X, so the
+                                 default is 0 */
 } mms_config;
 
 /* zk feed, code/imagebert_zk/evaluate_normal.py:141-152.  np_idx_class_labels [B,10,8] is either passed as the reference
@@ -172,6 +178,10 @@ int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const fl
  * W: per-output-channel scale max|w|/448, e4m3 RNE of w/scale) */
 int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, int64_t N, const float* bias, int32_t act,
                     int32_t out_f8, float* c_f32, void* stream);
+/* out = LayerNorm(A W^T + bias + resid) over N = 768 through the GEMM with the fused LayerNorm epilogue (gemm_pp_ln.h) and the
+ * LayerNorm kernel queued behind it; *mode_out = 1 when the launch ran fused, 2 when it took the plain two-kernel route */
+int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, const float* bias, const float* resid_f32,
+                    const float* gamma, const float* beta, int32_t f8, float* c_f32, int32_t* mode_out, void* stream);
 /* test hook: force one of the PRODUCT tile engines for every GEMM (1, 4, 16: register-staged tiles; 26: persistent ping-pong;
  * 27: three-pass ping-pong; anything else = per-shape default) / time one GEMM shape on random data */
 int mms_set_gemm_variant(int32_t variant);

@@ -87,6 +87,11 @@ struct mms_handle {
     // token, device-side live row totals (stream 0: zk tokens or lxmert language, stream 1: lxmert vision)
     int *pk_off[2] = {nullptr, nullptr}, *pk_cnt[2] = {nullptr, nullptr}, *pk_src[2] = {nullptr, nullptr}, *pk_rows = nullptr;
     unsigned long long* flop_counter = nullptr;
+    // fused residual + LayerNorm epilogue (gemm_pp_ln.h): per-row statistics granules, per-launch control words (check-in count,
+    // fused / plain decision), launch tag.  ln_slot counts the fused launches of the current call.
+    float* ln_stats = nullptr; int* ln_ctl = nullptr; int ln_slot = 0; unsigned ln_tag = 0;
+    static constexpr int LN_SLOTS = 2048;
+    int fuse_ln = 0;       // mms_config.fuse_layernorm (lab build: env MMS_FUSE_LN overrides)
     // label-text workspace, sized for lab_cap unique labels
     int64_t lab_cap = 0;
     Planes lab_planes; float *lab_f32 = nullptr, *lab_feat = nullptr; int64_t lab_feat_cap = 0;
@@ -468,6 +473,11 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     }
     if (int rc = dev_alloc(h, h->ws_allocs, &p, 16)) return rc;
     h->pk_rows = (int*)p;
+    if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(rows + 256) * 3 * 2 * 8)) return rc;
+    h->ln_stats = (float*)p;
+    HIP_TRY(h, hipMemset(p, 0, (size_t)(rows + 256) * 3 * 2 * 8));
+    if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)mms_handle::LN_SLOTS * 2 * 4)) return rc;
+    h->ln_ctl = (int*)p;
     h->ws_pairs = pairs;
     return MMS_OK;
 }
@@ -572,6 +582,61 @@ int gemm_f8(mms_handle* h, hipStream_t st, const unsigned char* a8, int lda, con
     return MMS_OK;
 }
 
+void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, const float* b, Planes out, int64_t M, const int* m_dev,
+              const Planes& resid, RowMap rmap, const int* r_index, const int* skip);
+
+// out = LayerNorm(A W^T + bias + resid) for the N = 768 projections, the LayerNorm fused into the GEMM epilogue when the launch is big
+// enough for the persistent ping-pong engine (gemm_pp_ln.h).  Returns MMS_OK with *fused = false when the caller has to take the
+// two-kernel route itself (small M, precision modes 1 / 3, no control slot left).
+int gemm_ln(mms_handle* h, hipStream_t st, bool f8, const Planes& a, int lda, const bf16* w, const unsigned char* w8, const float* wscale,
+            const float* bias, int64_t M, int K, const Planes& resid, const float* g, const float* b, const Planes& out, float* t,
+            const int* m_dev, bool* fused) {
+    *fused = false;
+    if (!h->fuse_ln || M < 16384 || !(f8 || h->nsplit == 2) || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
+    if (f8 ? (K % 128 != 0) : (K % 64 != 0)) return MMS_OK;
+    GemmParams p{};
+    if (f8) {
+        p.f8 = 1; p.a_hi = (const bf16*)a.f8; p.a_lo = p.a_hi; p.lda = lda / 2; p.w = (const bf16*)w8; p.col_scale = wscale; p.K = K / 2;
+    } else {
+        p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.w = w; p.K = K;
+    }
+    p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
+    p.bias = bias; p.M = (int)M; p.N = H; p.act = ACT_NONE;
+    p.r_hi = resid.hi; p.r_lo = resid.lo; p.ldr = H;
+    p.c_hi = out.hi; p.c_lo = out.lo; p.ldp = H; p.c_f8 = out.f8; p.ldf8 = H;
+    p.out_kind = OUT_F32; p.c_f32 = t; p.ldc = H;                    // the plain route of the same launch
+    p.m_dev = m_dev;
+    p.ln_gamma = g; p.ln_beta = b; p.ln_stats = h->ln_stats; p.ln_tag = ++h->ln_tag; p.ln_ctl = h->ln_ctl + 2 * h->ln_slot;
+
+    if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
+    const int* skip = p.ln_ctl + 1;
+    h->ln_slot += 1;
+    if (h->timing) {
+        if (h->ev_used + 2 > h->ev.size()) {
+            h->ev.resize(h->ev_used + 2);
+            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used]));
+            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used + 1]));
+        }
+        p.flop_counter = h->flop_counter;
+        HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
+        if (!launch_gemm_pp_ln(p, h->nsplit, st)) return h->fail(MMS_ERR_ARG, "gemm_ln: shape not supported");
+        HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
+        h->ev_used += 2;
+        h->gemm_launches += 1;
+    } else if (!launch_gemm_pp_ln(p, h->nsplit, st)) return h->fail(MMS_ERR_ARG, "gemm_ln: shape not supported");
+    // queued behind the GEMM: does the LayerNorm only if that launch had to take the plain route (ln_ctl[1] != 1)
+    ln_resid(h, st, t, g, b, out, M, m_dev, resid, RowMap{0, 0, 0}, nullptr, skip);
+    *fused = true;
+    return MMS_OK;
+}
+
+// every score call starts with fresh control words for its fused launches
+int ln_begin_call(mms_handle* h, hipStream_t st) {
+    h->ln_slot = 0;
+    if (h->ln_ctl) HIP_TRY(h, hipMemsetAsync(h->ln_ctl, 0, (size_t)mms_handle::LN_SLOTS * 2 * 4, st));
+    return MMS_OK;
+}
+
 GemmOut to_f32(float* p, int ldc) { GemmOut o; o.f32 = p; o.ldc = ldc; return o; }
 GemmOut to_planes(Planes p, int ldp, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.pl = p; o.ldp = ldp; o.cmap = m; return o; }
 const RowMap ID{0, 0, 0};
@@ -579,8 +644,9 @@ const RowMap ID{0, 0, 0};
 // LayerNorm closing a residual sub-layer: out = LN(t + resid).  The residual rides here (default) or was already added
 // by the producing GEMM's epilogue (h->resid_in_ln == 0); the arithmetic is the same fp32 (acc + bias) + resid either way.
 void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, const float* b, Planes out, int64_t M, const int* m_dev,
-              const Planes& resid, RowMap rmap = RowMap{0, 0, 0}, const int* r_index = nullptr) {
+              const Planes& resid, RowMap rmap = RowMap{0, 0, 0}, const int* r_index = nullptr, const int* skip = nullptr) {
     LnResid r;
+    r.skip = skip;
     if (h->resid_in_ln) { r.hi = resid.hi; r.lo = resid.lo; r.ld = H; r.rmap = rmap; r.r_index = r_index; }
     if (h->alternate) { r.reverse = h->flip; h->flip ^= 1; }
     r.o_f8 = out.f8;
@@ -619,6 +685,10 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     if (f8) a.o_f8 = h->ctx.f8 + row0 * H;
     if (int rc = attend(h, a, st)) return rc;
     const Planes resid = in.at(row0 * H);
+    bool fused = false;
+    if (int rc = gemm_ln(h, st, f8, h->ctx.at(row0 * H), H, w.wo, w.wo8, w.wos, w.bo, M, H, resid, w.g, w.b, out.at(row0 * H), h->t + row0 * H,
+                         pk.rows, &fused)) return rc;
+    if (fused) return MMS_OK;
     if (f8) {
         if (int rc = gemm_f8(h, st, h->ctx.f8 + row0 * H, H, w.wo8, w.wos, w.bo, M, H, H, ACT_NONE, to_f32(h->t + row0 * H, H), pk.rows)) return rc;
     } else if (int rc = gemm(h, st, h->ctx.at(row0 * H), H, ID, w.wo, w.bo, M, H, H, ACT_NONE,
@@ -632,13 +702,18 @@ int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes ou
               const Pack& pk = Pack()) {
     const int I = h->cfg.inter;
     const Planes resid = in.at(row0 * H);
+    bool fused = false;
     if (h->f8 && in.f8) {
         if (int rc = gemm_f8(h, st, in.f8 + row0 * H, H, w.wi8, w.wis, w.bi, M, I, H, act, to_planes(h->mid, I), pk.rows)) return rc;
+        if (int rc = gemm_ln(h, st, true, h->mid, I, w.wd, w.wd8, w.wds, w.bd, M, I, resid, w.g, w.b, out.at(row0 * H), h->t + row0 * H, pk.rows, &fused)) return rc;
+        if (fused) return MMS_OK;
         if (int rc = gemm_f8(h, st, h->mid.f8, I, w.wd8, w.wds, w.bd, M, H, I, ACT_NONE, to_f32(h->t + row0 * H, H), pk.rows)) return rc;
         ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
         return MMS_OK;
     }
     if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I), nullptr, pk.rows, nullptr, ID, nullptr, 4)) return rc;
+    if (int rc = gemm_ln(h, st, false, h->mid, I, w.wd, w.wd8, w.wds, w.bd, M, I, resid, w.g, w.b, out.at(row0 * H), h->t + row0 * H, pk.rows, &fused)) return rc;
+    if (fused) return MMS_OK;
     if (int rc = gemm(h, st, h->mid, I, ID, w.wd, w.bd, M, H, I, ACT_NONE, to_f32(h->t + row0 * H, H), &resid, pk.rows, nullptr, ID, nullptr, 8)) return rc;
     ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
     return MMS_OK;
@@ -1082,8 +1157,10 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
     mms_handle* h = new mms_handle();
     h->cfg = *cfg;
     h->f8 = cfg->precision == 4;
+    h->fuse_ln = cfg->fuse_layernorm != 0;
     h->nsplit = h->f8 ? 2 : cfg->precision;
 #ifdef MMS_LAB   // A/B knobs exist in libmmscore_lab.so only; the product library reads no environment variable
+    if (const char* e = getenv("MMS_FUSE_LN")) h->fuse_ln = atoi(e);
     if (const char* e = getenv("MMS_X1_MASK")) h->x1_mask = atoi(e);
     if (const char* e = getenv("MMS_RESID_IN_LN")) h->resid_in_ln = atoi(e);
     if (const char* e = getenv("MMS_ALTERNATE")) h->alternate = atoi(e);
@@ -1155,6 +1232,7 @@ int mms_score_zk(mms_handle* h, const mms_zk_batch* b, float* logits, float* pro
         if (int rc = dedup_labels<int32_t>(h, st, b->label_ids, B * MMS_NBOX, &U)) return rc;
         uniq = h->dd_uniq32; index = h->dd_index;
     }
+    if (int rc = ln_begin_call(h, st)) return rc;
     if (int rc = zk_label_features(h, st, uniq, U)) return rc;
     for (int64_t p0 = 0; p0 < B; p0 += cs)
         if (int rc = zk_chunk(h, st, b, index, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
@@ -1171,6 +1249,7 @@ int mms_score_lds(mms_handle* h, const mms_lds_batch* b, float* logits, float* p
     hipStream_t st = (hipStream_t)stream;
     const int cs = chunk_size(h, B);
     if (int rc = ensure_workspace(h, cs)) return rc;
+    if (int rc = ln_begin_call(h, st)) return rc;
     for (int64_t p0 = 0; p0 < B; p0 += cs)
         if (int rc = lds_chunk(h, st, b, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
     return post_launch(h);
@@ -1196,6 +1275,7 @@ int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, fl
         if (int rc = dedup_labels<int64_t>(h, st, b->label_ids, B * MMS_NBOX, &U)) return rc;
         uniq = h->dd_uniq64; index = h->dd_index;
     }
+    if (int rc = ln_begin_call(h, st)) return rc;
     if (int rc = lx_label_features(h, st, uniq, U)) return rc;
     if (int rc = lx_query_stage(h, st, b, B, cs)) return rc;
     for (int64_t p0 = 0; p0 < B; p0 += cs)
@@ -1253,6 +1333,9 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
     if (int rc = ensure_workspace(l, cs)) return z->fail(rc, "lds handle: " + l->err);
     if (int rc = ensure_workspace(x, cs)) return z->fail(rc, "lxmert handle: " + x->err);
     if (int rc = ensure_ens_ws(z, B, T, TL)) return rc;
+    if (int rc = ln_begin_call(z, st)) return rc;
+    if (int rc = ln_begin_call(l, st)) return z->fail(rc, "lds handle: " + l->err);
+    if (int rc = ln_begin_call(x, st)) return z->fail(rc, "lxmert handle: " + x->err);
     // ---- feeds in each member's own dtypes ----
     launch_zk_segment_ids(z->ens_seg, B, T, st);                                   // load_data_v4.py:204
     launch_i32_to_i64(b->query_ids, z->ens_ids64, B * T, st);                      // lds reads the zk query as int64 (run_pretraining_predict_score.py:526-548)
@@ -1456,6 +1539,59 @@ int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32
     DBG_TRY(hipStreamSynchronize(st));
     DBG_TRY(hipGetLastError());
     (void)hipFree(a8); (void)hipFree(w8); (void)hipFree(ws); (void)hipFree(c8);
+    return MMS_OK;
+}
+
+#ifdef MMS_LAB
+unsigned long long* g_ln_dbg = nullptr;   // lab: device buffer for the per-tile phase stamps of the next mms_dbg_gemm_ln (tools/ln_trace.py)
+int mms_lab_ln_trace(unsigned long long* dev_buf) { g_ln_dbg = dev_buf; return MMS_OK; }
+#endif
+int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, const float* bias, const float* resid_f32,
+                    const float* gamma, const float* beta, int32_t f8, float* c_f32, int32_t* mode_out, void* stream) {
+    const int64_t N = H;
+    if (!a_f32 || !w_f32_nk || !resid_f32 || !gamma || !beta || !c_f32 || M <= 0 || K % 128) { g_err = "mms_dbg_gemm_ln: bad argument"; return MMS_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    bf16 *ap = nullptr, *wp = nullptr, *rp = nullptr, *cp = nullptr;
+    unsigned char *a8 = nullptr, *w8 = nullptr;
+    float *ws = nullptr, *t = nullptr, *stats = nullptr;
+    int* ctl = nullptr;
+    DBG_TRY(hipMalloc((void**)&ap, (size_t)M * K * 4)); DBG_TRY(hipMalloc((void**)&wp, (size_t)N * K * 4));
+    DBG_TRY(hipMalloc((void**)&rp, (size_t)M * N * 4)); DBG_TRY(hipMalloc((void**)&cp, (size_t)M * N * 4));
+    DBG_TRY(hipMalloc((void**)&t, (size_t)M * N * 4)); DBG_TRY(hipMalloc((void**)&stats, (size_t)(M + 256) * 48));
+    DBG_TRY(hipMalloc((void**)&ctl, 8));
+    DBG_TRY(hipMemsetAsync(stats, 0, (size_t)(M + 256) * 48, st)); DBG_TRY(hipMemsetAsync(ctl, 0, 8, st));
+    launch_split_f32(a_f32, ap, ap + M * K, M * K, st);
+    launch_split_f32(w_f32_nk, wp, wp + N * K, N * K, st);
+    launch_split_f32(resid_f32, rp, rp + M * N, M * N, st);
+    GemmParams p{};
+    if (f8) {
+        DBG_TRY(hipMalloc((void**)&a8, (size_t)M * K)); DBG_TRY(hipMalloc((void**)&w8, (size_t)N * K)); DBG_TRY(hipMalloc((void**)&ws, (size_t)N * 4));
+        launch_f32_to_f8(a_f32, a8, M * K, st);
+        launch_quant_rows_f8(w_f32_nk, w8, ws, (int)N, (int)K, st);
+        p.f8 = 1; p.a_hi = (const bf16*)a8; p.a_lo = p.a_hi; p.lda = (int)(K / 2); p.w = (const bf16*)w8; p.col_scale = ws; p.K = (int)(K / 2);
+    } else {
+        p.a_hi = ap; p.a_lo = ap + M * K; p.lda = (int)K; p.w = wp; p.K = (int)K;
+    }
+    p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
+    p.bias = bias; p.M = (int)M; p.N = (int)N; p.act = ACT_NONE;
+    p.r_hi = rp; p.r_lo = rp + M * N; p.ldr = (int)N;
+    p.c_hi = cp; p.c_lo = cp + M * N; p.ldp = (int)N;
+    p.out_kind = OUT_F32; p.c_f32 = t; p.ldc = (int)N;
+    p.ln_gamma = gamma; p.ln_beta = beta; p.ln_stats = stats; p.ln_tag = 0x5EED0001u; p.ln_ctl = ctl;
+#ifdef MMS_LAB
+    p.ln_dbg = g_ln_dbg;
+#endif
+    if (!launch_gemm_pp_ln(p, 2, st)) { g_err = "mms_dbg_gemm_ln: shape not supported"; return MMS_ERR_ARG; }
+    LnResid r;
+    r.hi = rp; r.lo = rp + M * N; r.ld = (int)N; r.skip = ctl + 1;
+    launch_ln_to_planes(t, (int)N, gamma, beta, cp, cp + M * N, (int)N, (int)M, st, nullptr, r);
+    launch_planes_to_f32(cp, cp + M * N, c_f32, M * N, st);
+    int ctl_h[2] = {0, 0};
+    DBG_TRY(hipMemcpyAsync(ctl_h, ctl, 8, hipMemcpyDeviceToHost, st));
+    DBG_TRY(hipStreamSynchronize(st));
+    DBG_TRY(hipGetLastError());
+    if (mode_out) *mode_out = ctl_h[1];
+    for (void* q : {(void*)ap, (void*)wp, (void*)rp, (void*)cp, (void*)a8, (void*)w8, (void*)ws, (void*)t, (void*)stats, (void*)ctl}) (void)hipFree(q);
     return MMS_OK;
 }
 

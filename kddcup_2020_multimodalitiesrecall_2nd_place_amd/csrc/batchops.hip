@@ -36,22 +36,49 @@ __device__ __forceinline__ bool tuple_eq(const T* a, const T* b) {
     return e;
 }
 
-// rep[r] = row index of the first claimant of r's tuple
+// rep[r] = row index of the first claimant of r's tuple.  Two levels: the 256 rows of a workgroup (25 pairs' boxes: about as many
+// distinct tuples as there are object classes) first agree on a representative through an LDS table, and only the representatives
+// probe the global table -- 8x fewer walks over the handful of hot global slots every workgroup of the grid converges on
+// (1.7 ms -> per 300 000-row call before, profiles/r02b_bench_ensemble_kernel_stats.csv).
 template <typename T>
 __global__ __launch_bounds__(256) void k_dedup_insert(const T* ids, int rows, int* slots, unsigned mask, int* rep) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const T* mine = ids + (long long)r * MMS_LABEL_LEN;
-    unsigned h = tuple_hash(mine) & mask;
-    for (;;) {
-        int s = slots[h];
-        if (s < 0) {
-            const int old = atomicCAS(&slots[h], -1, r);
-            s = old < 0 ? r : old;
+    __shared__ int tab[512];
+    __shared__ int grep[256];
+    const int tid = threadIdx.x, r = blockIdx.x * 256 + tid;
+    tab[tid] = -1; tab[tid + 256] = -1;
+    __syncthreads();
+    const bool live = r < rows;
+    const T* mine = ids + (long long)(live ? r : 0) * MMS_LABEL_LEN;
+    const unsigned hv = tuple_hash(mine);
+    int lrep = tid;                       // thread (of this workgroup) that represents my tuple
+    if (live) {
+        unsigned h = hv & 511u;
+        for (;;) {
+            int s = tab[h];
+            if (s < 0) {
+                const int old = atomicCAS(&tab[h], -1, tid);
+                s = old < 0 ? tid : old;
+            }
+            if (s == tid || tuple_eq(ids + (long long)(blockIdx.x * 256 + s) * MMS_LABEL_LEN, mine)) { lrep = s; break; }
+            h = (h + 1) & 511u;
         }
-        if (s == r || tuple_eq(ids + (long long)s * MMS_LABEL_LEN, mine)) { rep[r] = s; return; }
-        h = (h + 1) & mask;
     }
+    int g = r;
+    if (live && lrep == tid) {            // representatives only: global table
+        unsigned h = hv & mask;
+        for (;;) {
+            int s = slots[h];
+            if (s < 0) {
+                const int old = atomicCAS(&slots[h], -1, r);
+                s = old < 0 ? r : old;
+            }
+            if (s == r || tuple_eq(ids + (long long)s * MMS_LABEL_LEN, mine)) { g = s; break; }
+            h = (h + 1) & mask;
+        }
+    }
+    grep[tid] = g;
+    __syncthreads();
+    if (live) rep[r] = grep[lrep];
 }
 
 // claimants take consecutive numbers and write their tuple into the unique tables

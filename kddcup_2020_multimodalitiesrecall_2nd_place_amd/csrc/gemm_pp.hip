@@ -28,6 +28,7 @@
 
 #include "kernels.h"
 #include "gemm_pp_epilogue.h"
+#include "gemm_pp_ln.h"
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -58,9 +59,11 @@ __device__ __forceinline__ void pp_barrier() {
 // F8 (precision mode 4): the A and W planes hold e4m3 bytes -- a 64-byte stage row is 64 k-values instead of 32 -- and every
 // fragment pair feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (the low and the high 8 bytes of the ds_read_b128; the k order inside the
 // contraction is the same permutation in both operands).  Staging, ring, phases and epilogue are the bf16 engine's.
-template <int NSPLIT, int ACT, int DIAG, bool PERSIST, bool F8 = false>
+// LNF: N == 768 with the fused bias + residual + LayerNorm epilogue of gemm_pp_ln.h (persistent launches only).
+template <int NSPLIT, int ACT, int DIAG, bool PERSIST, bool F8 = false, bool LNF = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     static_assert(!F8 || NSPLIT == 1, "fp8 operands are single-plane");
+    static_assert(!LNF || (PERSIST && ACT == ACT_NONE && DIAG == 0), "the LayerNorm epilogue belongs to the persistent, activation-free kernel");
     constexpr int BM = 256, BN = 256, WAVES_N = 4, NW = 8, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int PLANE = 256 * 64;                 // one operand plane of a stage: 256 rows x 32 bf16
     constexpr int SLOT = (NSPLIT + 1) * PLANE;
@@ -79,9 +82,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
     if (!(DIAG & 32) && p.flop_counter && blockIdx.x == 0 && tid == 0)
         atomicAdd(p.flop_counter, (F8 ? 4ull : 2ull) * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
-    const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM, nblk = nbm * nbn;
+    if (LNF && tid == 0) atomicAdd(&p.ln_ctl[0], 1);     // check-in: "this workgroup is resident" (gemm_pp_ln.h)
+    const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM;
+    // LNF: whole row panels per XCD (the three tiles of a panel exchange row statistics), so the virtual index space is
+    // 8 XCDs x 3 tiles x (panels of the fullest XCD) and a few virtual indices name no tile
+    const int pan_q = nbm >> 3, pan_r = nbm & 7;
+    const int nblk = LNF ? 24 * (pan_q + (pan_r ? 1 : 0)) : nbm * nbn;
+    auto valid = [&](int v) { return !LNF || (v >> 3) < 3 * (pan_q + ((v & 7) < pan_r ? 1 : 0)); };
     int vb = blockIdx.x;                 // virtual block id; PERSIST: the workgroup walks vb, vb + gridDim.x, ... (gridDim.x % 8 == 0)
+    while (vb < nblk && !valid(vb)) vb += gridDim.x;
     if (vb >= nblk) return;
+    // fused or plain is settled BEFORE the first tile (the fused route preloads residual + bias into the accumulators): normally every
+    // workgroup has checked in within a few microseconds of the first one
+    int ln_decided = 0;
+    if constexpr (LNF) ln_decided = ln_decide(p.ln_ctl, (int)gridDim.x, lane);
     const long long lo_delta = p.a_lo - p.a_hi;
     // LDS-DMA sources: piece h (0/1) of an operand = rows h*128 + wave*16 + lane/4, 16-B chunk lane%4 (swizzled)
     const int gr_l = lane >> 2, gc = lane & 3;
@@ -90,10 +104,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     int bm, bn;
     auto setup = [&](int v) {
         // bijective XCD remap over the live tiles (virtual block v runs on XCD v % 8)
+        if constexpr (LNF) {
+            const int xcd = v & 7, loc = v >> 3;
+            bm = xcd * pan_q + (xcd < pan_r ? xcd : pan_r) + loc / 3;
+            bn = loc % 3;
+            if (p.reverse) bm = nbm - 1 - bm;
+        } else {
         const int q = nblk >> 3, r8 = nblk & 7, xcd = v & 7, loc = v >> 3;
         int bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
         if (p.reverse) bid = nblk - 1 - bid;
         bm = bid / nbn; bn = bid % nbn;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = h * 128 + wave * 16 + gr_l;
@@ -206,11 +227,67 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     const unsigned long long tr1 = (DIAG & 32) ? wall_clock64() : 0;
 
     if (DIAG & 4) { read_b(smem, 0, b0); read_b(smem, 1, b1); read_a(smem, 0); }
+    // LNF: the accumulators START at the residual tile (C = resid + A W^T), so the epilogue has no dependent global reads left:
+    // fetched as an 8-row hi burst and an 8-row lo burst per lane while the previous tile's stores drain / the first K stages
+    // are in flight (a residual read inside the epilogue was a serial latency chain of ~50 us per tile, measured).  fp8 operands:
+    // the accumulator is in units of the weight row's power-of-two scale, so the residual goes in divided by it (exact).
+    auto load_resid = [&]() {
+        const int mrow = lane & 15, nq = lane >> 4;
+        const int rbase = bm * BM + wm * TM, cbase = bn * BN + wn * TN + nq * 4;
+        // bias rides along (acc = (resid + bias) / scale): the epilogue then only scales.  Four bursts of 4 rows x 4 fragments
+        // (32 registers of bf16 in flight): with two bursts in flight the kernel spills, and ANY scratch use costs far more than it
+        // saves (ROCr hands out scratch of this size per dispatch: the first persistent round took 450 us instead of 66).  The read is
+        // bandwidth-bound anyway: all CUs reach the tile boundary together and pull 63 MB of residual per round.
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const bf16* src = pl ? p.r_lo : p.r_hi;
+#pragma unroll
+            for (int ih = 0; ih < FM; ih += 4) {
+                bf16x4 t[4][FN];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int row = rbase + 16 * (ih + i) + mrow;
+                    row = row < Meff ? row : Meff - 1;
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) t[i][j] = *reinterpret_cast<const bf16x4*>(src + (long long)row * p.ldr + cbase + 16 * j);
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    f32x4 add = f32x4{0.f, 0.f, 0.f, 0.f}, inv = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (pl == 0 && p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + cbase + 16 * j);
+                    if constexpr (F8) {
+                        const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.col_scale + cbase + 16 * j);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) inv[e] = __frcp_rn(s4[e]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = (float)t[i][j][e] + add[e];
+                            if constexpr (F8) v *= inv[e];
+                            acc[ih + i][j][e] = pl ? acc[ih + i][j][e] + v : v;
+                        }
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    };
+    if constexpr (LNF) {
+        if (ln_decided == 1) load_resid();
+    }
     for (;;) {
+#ifdef MMS_LAB
+        const unsigned long long tr_loop = (LNF && p.ln_dbg) ? wall_clock64() : 0;
+#else
+        const unsigned long long tr_loop = 0; (void)tr_loop;
+#endif
+        if (!LNF || ln_decided != 1) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         int slot = 0, s = 0;
         for (; s + 2 < ns; ++s) {
             stage(std::true_type{}, std::integral_constant<int, P>{}, s, slot);
@@ -235,15 +312,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         // their round trip -- the whole prologue of a fresh workgroup -- runs under the store drain; one full `vmcnt(0)` then covers
         // both, and neither a workgroup retirement nor a dispatch (~4.6 us) sits between two tiles.
         const int row0 = bm * BM + wm * TM, col0 = bn * BN + wn * TN;
-        const bool more = PERSIST && vb + (int)gridDim.x < nblk;
+        const int ebm = bm, ebn = bn, evb = vb;      // this tile (setup() below moves bm / bn / vb on to the next one)
+        int nvb = vb + (int)gridDim.x;
+        while (nvb < nblk && !valid(nvb)) nvb += gridDim.x;
+        const bool more = PERSIST && nvb < nblk;
         if (more) {
-            vb += gridDim.x;
+            vb = nvb;
             setup(vb);
 #pragma unroll
             for (int q = 0; q < P; ++q) issue(q, 0, 0);
 #pragma unroll
             for (int q = 0; q < P; ++q) issue(q, 1, 1);
         }
+        if constexpr (LNF) {
+#ifdef MMS_LAB
+            if (p.ln_dbg && tid == 0) p.ln_dbg[(long long)evb * 6] = tr_loop;
+#endif
+            if (ln_decided == 1) pp_epilogue_ln<FM, FN>(p, acc, ebm, ebn, wm, wn, lane, tid, Meff, smem + 2 * SLOT, evb);   // ring slot 2 is idle here
+            else pp_epilogue_plain_f32<FM, FN>(p, acc, row0, col0, lane, Meff);   // the LayerNorm kernel behind this launch finishes the job
+        } else
         pp_epilogue<ACT, FM, FN>(p, acc, row0, col0, lane, Meff);
         if ((DIAG & 32) && tid == 0 && p.flop_counter) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // epilogue stores acknowledged
@@ -251,6 +338,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
             t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = wall_clock64(); t[4] = ((unsigned long long)bm << 32) | (unsigned)bn;
         }
         if (!more) break;
+        if constexpr (LNF) { if (ln_decided == 1) load_resid(); }
         pp_wait_vmcnt<0>();
         pp_barrier();
         if (wm == 1) pp_barrier();     // stagger again
@@ -279,6 +367,24 @@ static void launch_pp_ns(const GemmParams& p, hipStream_t st) {
         case ACT_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_TANH, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
         default: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_NONE, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
     }
+}
+
+// N == 768 with the fused bias + residual + LayerNorm epilogue: nsplit 2 (bf16 planes) or e4m3 operands (p.f8)
+bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st) {
+    if (p.M <= 0) return true;
+    if (p.N != 768 || p.K % 64 || !p.ln_gamma || !p.ln_beta || !p.ln_stats || !p.ln_ctl || !p.r_hi || p.act != ACT_NONE) return false;
+    const int nbm = (p.M + 255) / 256;
+    const int nvirt = 24 * ((nbm >> 3) + ((nbm & 7) ? 1 : 0));
+    // workgroups per XCD: a multiple of 3, so that the three tiles of a row panel always fall into the SAME persistent round (with
+    // 32 per XCD every eleventh panel straddled two rounds: two workgroups idled a whole tile time waiting for the third tile, and
+    // the delay rippled through every later round -- measured -8 % end to end; 30 of 32 CUs per XCD costs 6 % of these launches)
+    const int per_xcd = (pp_cu_count() / 8) / 3 * 3;
+    const int full = per_xcd > 0 ? 8 * per_xcd : 24;
+    const dim3 grid(nvirt > full ? full : nvirt), block(512);
+    if (p.f8) hipLaunchKernelGGL((gemm_pp_kernel<1, ACT_NONE, 0, true, true, true>), grid, block, 0, st, p);
+    else if (nsplit == 2) hipLaunchKernelGGL((gemm_pp_kernel<2, ACT_NONE, 0, true, false, true>), grid, block, 0, st, p);
+    else return false;
+    return true;
 }
 
 // precision mode 4: e4m3 operands (p.f8 set; p.lda / p.K in byte PAIRS), any M, N % 256 == 0, K (in fp8 elements) % 128 == 0

@@ -8,6 +8,20 @@
 // activation / split run on float4.  (The strip-transposing epilogue of gemm_epilogue.h spent ~11 us per 256x256 tile, almost all of
 // it instruction issue -- 16 ds_write_b32 + 4 ds_read_b128 + per-store 64-bit address arithmetic and uniform branches -- while a CU
 // can write the tile in 2.2 us: tools/probes/store_probe.hip.)
+// Two column fragments (j, j + 1) of one output row as split planes, stored as ONE 16-byte access per plane and lane instead of two
+// 8-byte ones: lane group nq holds columns 4 nq .. 4 nq + 3 of every 16-column fragment; v_permlane16_swap exchanges the odd 16-lane
+// rows of the first operand with the even rows of the second, after which an even group owns 8 consecutive columns of fragment j and
+// the odd group next to it 8 consecutive columns of fragment j + 1.  The plane epilogues are store-ISSUE bound (64 8-byte stores per
+// lane and tile), so halving the store count is what shortens them (cdna_hip_programming.md T21).
+typedef __attribute__((ext_vector_type(2))) unsigned pp_u32x2;
+__device__ __forceinline__ void pp_store_plane_pair(bf16* plane_row, int col0, int nq, int j, bf16x4 f0, bf16x4 f1) {
+    const pp_u32x2 x = __builtin_bit_cast(pp_u32x2, f0), y = __builtin_bit_cast(pp_u32x2, f1);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
+    const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};      // {X'.lo, X'.hi, Y'.lo, Y'.hi} = 8 consecutive bf16
+    *reinterpret_cast<u32x4*>(plane_row + col0 + 16 * (j + (nq & 1)) + 4 * (nq & 2)) = v;
+}
+
 template <int ACT, int FM, int FN>
 __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int row0, int col0, int lane, int Meff) {
     const int mrow = lane & 15, nq = lane >> 4;
@@ -59,15 +73,20 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
                 *reinterpret_cast<unsigned*>(d8 + 16 * j) = pack4_f8(apply_act(acc[i][j][0], ACT), apply_act(acc[i][j][1], ACT),
                                                                      apply_act(acc[i][j][2], ACT), apply_act(acc[i][j][3], ACT));
         } else {
-            bf16* dh = p.c_hi + orow * p.ldp + col;
-            bf16* dl = p.c_lo + orow * p.ldp + col;
+            static_assert(FN % 2 == 0, "plane stores pair up column fragments");
+            bf16* dh = p.c_hi + orow * p.ldp;
+            bf16* dl = p.c_lo + orow * p.ldp;
+            // note: every lane of the wave takes part in the exchange; rows past the live count were skipped above as whole 16-lane
+            // groups of identical mrow across the four lane groups, so the partner lane (same mrow) is always present
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                bf16x4 h, l;
+            for (int j = 0; j < FN; j += 2) {
+                bf16x4 h[2], l[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { bf16 a, c2; split_bf16(apply_act(acc[i][j][e], ACT), a, c2); h[e] = a; l[e] = c2; }
-                *reinterpret_cast<bf16x4*>(dh + 16 * j) = h;
-                *reinterpret_cast<bf16x4*>(dl + 16 * j) = l;
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bf16 a, c2; split_bf16(apply_act(acc[i][j + jj][e], ACT), a, c2); h[jj][e] = a; l[jj][e] = c2; }
+                pp_store_plane_pair(dh, col0, nq, j, h[0], h[1]);
+                pp_store_plane_pair(dl, col0, nq, j, l[0], l[1]);
             }
         }
     }

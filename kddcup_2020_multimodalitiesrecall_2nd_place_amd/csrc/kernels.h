@@ -31,12 +31,21 @@ struct GemmParams {
     int f8;
     const float* col_scale;
     unsigned char* c_f8; int ldf8;
+    // fused bias + residual + LayerNorm epilogue (gemm_pp_ln.h; N == 768, rows of the residual = rows of the output): ln_gamma != nullptr
+    // selects it.  Outputs: planes c_hi / c_lo (+ c_f8) when the launch runs fused, plain fp32 c_f32 when it falls back (then the
+    // LayerNorm kernel queued behind the GEMM does the work; it skips itself when ln_ctl[1] == 1).
+    const float* ln_gamma; const float* ln_beta;
+    float* ln_stats;             // [rows][3 tiles][2] 8-byte {value, tag} granules
+    unsigned ln_tag;             // unique per launch
+    int* ln_ctl;                 // [0] workgroups checked in, [1] 0 undecided / 1 fused / 2 plain -- zeroed before the launch
+    unsigned long long* ln_dbg;  // lab build only: per-tile phase stamps [virtual tile][6] of wall_clock64 (tools/ln_trace.py); nullptr otherwise
 };
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
 void launch_gemm_v0(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm.hip (lab only)
 bool launch_gemm_ring(const GemmParams& p, int nsplit, int nslot, hipStream_t st);      // gemm_ring.hip (variants 11: 4 slots, 12: 2 slots)
 bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist = false);                     // gemm_pp.hip (variant 20: 256x256 ping-pong phases)
+bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm_pp.hip + gemm_pp_ln.h: N = 768 with the fused residual + LayerNorm epilogue (nsplit 2, or fp8 operands)
 bool launch_gemm_pp_f8(const GemmParams& p, hipStream_t st);                            // gemm_pp.hip with e4m3 operands (precision mode 4)
 bool launch_gemm_ppw(const GemmParams& p, hipStream_t st);                               // gemm_ppw.hip: precision mode 3 (A and W split), 256x128 ping-pong phases
 void set_gemm_variant(int v);   // test hook, see gemm_dispatch.hip
@@ -68,7 +77,8 @@ bool launch_attention(const AttnParams& p, hipStream_t st);   // false: (Sq, Sk)
 // ---------------------------------------------------------------------------------------------
 // optional residual of the LayerNorm input: row r adds planes row (r_index ? r_index[r] : rmap(r)) before normalising
 struct LnResid { const bf16* hi = nullptr; const bf16* lo = nullptr; int ld = 0; RowMap rmap{0, 0, 0}; const int* r_index = nullptr; int reverse = 0;
-                 unsigned char* o_f8 = nullptr; };   // o_f8: additionally write the row as e4m3 bytes (row stride ldo; precision mode 4)
+                 unsigned char* o_f8 = nullptr;
+                 const int* skip = nullptr; };   // skip: the kernel returns at once when *skip == 1 (the producing GEMM already normalised: gemm_pp_ln.h)   // o_f8: additionally write the row as e4m3 bytes (row stride ldo; precision mode 4)
 void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta,
                          bf16* o_hi, bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev = nullptr, LnResid res = LnResid());
 void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipStream_t st);

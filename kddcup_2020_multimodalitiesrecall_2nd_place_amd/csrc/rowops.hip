@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void k_ln_to_planes(const float* in, int ld, c
                                                       const float* beta, bf16* o_hi, bf16* o_lo, int ldo, int M,
                                                       const int* m_dev, LnResid res) {
     int row = wave_row();
+    if (res.skip && *res.skip == 1) return;       // the producing GEMM ran its fused LayerNorm epilogue
     const int lim = m_dev ? min(M, *m_dev) : M;
     if (row >= lim) return;
     if (res.reverse) row = lim - 1 - row;

@@ -29,7 +29,7 @@ class MmsError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "model", "layers", "r_layers", "x_layers", "vocab", "inter", "max_pos", "type_vocab", "text_len",
-        "precision", "chunk_pairs", "stop_after", "device", "pack_tokens")]
+        "precision", "chunk_pairs", "stop_after", "device", "pack_tokens", "fuse_layernorm")]
 
 
 class ZkBatch(C.Structure):
@@ -60,7 +60,7 @@ class EnsembleBatch(C.Structure):
 
 EXPORTS = ("mms_version", "mms_global_error", "mms_create", "mms_destroy", "mms_last_error", "mms_load_weight",
            "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_score_ensemble", "mms_gemm_timing",
-           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_attention", "mms_dbg_layernorm", "mms_set_gemm_variant",
+           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_ln", "mms_dbg_attention", "mms_dbg_layernorm", "mms_set_gemm_variant",
            "mms_dbg_gemm_bench")
 
 _lib = None
@@ -93,6 +93,7 @@ def load(path=None):
     lib.mms_score_lxmert.argtypes = [vp, C.POINTER(LxmertBatch), vp, vp, vp]
     lib.mms_score_ensemble.argtypes = [vp, vp, vp, C.POINTER(EnsembleBatch), C.POINTER(C.c_float), vp, vp, vp]
     lib.mms_dbg_gemm_f8.argtypes = [vp, i64, i64, vp, i64, vp, i32, i32, vp, vp]
+    lib.mms_dbg_gemm_ln.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, i32, vp, C.POINTER(i32), vp]
     lib.mms_gemm_timing.argtypes = [vp, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.mms_debug_read_x.argtypes = [vp, vp, i64, vp]
     lib.mms_dbg_gemm.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, i32, i32, i32, vp, vp]
@@ -108,7 +109,7 @@ class Handle:
     """Owns one ``mms_handle`` (one model on one GPU)."""
 
     def __init__(self, cfg, precision: int = 2, device: int = 0, chunk_pairs: int = 0, stop_after: int = -1,
-                 pack_tokens: bool = True):
+                 pack_tokens: bool = True, fuse_layernorm: bool = False):
         self.lib = load()
         self.cfg = cfg
         c = Config()
@@ -120,6 +121,7 @@ class Handle:
         c.vocab, c.inter, c.max_pos, c.type_vocab, c.text_len = cfg.vocab, cfg.inter, cfg.max_pos, cfg.type_vocab, cfg.text_len
         c.precision, c.chunk_pairs, c.stop_after, c.device = precision, chunk_pairs, stop_after, device
         c.pack_tokens = int(bool(pack_tokens) and cfg.name != "lds")
+        c.fuse_layernorm = int(bool(fuse_layernorm))
         self._h = C.c_void_p()
         rc = self.lib.mms_create(C.byref(c), C.byref(self._h))
         if rc != 0:
