@@ -288,8 +288,12 @@ def main():
                 live_frac = round(float(live) / (ps.n * cfgs["zk"].seq), 4)
             else:
                 live_frac = round(float(b0["input_mask"].sum() + b0["visual_attention_mask"].sum()) / (ps.n * (cfgs["lxmert"].text_len + N_BOX)), 4)
-        elif a.model == "lds":
-            live_frac = 1.0
+        elif a.model == "lds":        # rows kept after merging a pair's identical feature / label tokens (rowops.hip k_lds_plan_*)
+            b0 = synth.batch_for(cfgs["lds"], ps)
+            lab = b0["labelfeat"]
+            nb = np.minimum(ps.num_boxes, N_BOX)
+            distinct = np.array([len({tuple(t) for t in lab[i]}) for i in range(ps.n)])
+            live_frac = 1.0 if a.dense else round(float((cfgs["lds"].text_len + nb + (nb < N_BOX) + distinct).sum()) / (ps.n * cfgs["lds"].seq), 4)
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % a.model)
         if os.path.exists(tp) and not a.dense and a.precision == 2 and a.workload == "bench":   # tools/pmc_traffic.sh on this workload
@@ -308,7 +312,7 @@ def main():
                                    + wl + " (<=10 boxes x 2048-d), seeded weights%s, inputs HBM-resident" % (" (fp32, not bf16-rounded)" if a.fp32_weights else ""),
                        "pairs_per_gpu": ps.n, "pairs_total": total_pairs, "precision_mode": a.precision,
                        "parallelism": "query-sharded dp%d" % world,
-                       "token_packing": (not a.dense) and a.model != "lds", "live_token_fraction": live_frac},
+                       "token_packing": not a.dense, "live_token_fraction": live_frac},
             # pairs/s x the reference graph's padded-shape FLOPs/pair.  With token packing the
             # kernels EXECUTE fewer FLOPs than that (padded tokens are skipped), so this is an equivalent rate, not
             # a utilisation; roofline.achieved below counts executed FLOPs only.

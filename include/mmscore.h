@@ -66,12 +66,15 @@ typedef struct mms_config {
     int32_t chunk_pairs;      /* max pairs per internal launch wave (0 = default 32768); a batch is cut into equal chunks */
     int32_t stop_after;       /* debug: run only the first n encoder layers (-1 = all) and skip nothing else */
     int32_t device;           /* HIP device ordinal */
-    int32_t pack_tokens;      /* zk/lxmert: 1 = drop padded tokens whose keys are masked (identical logits: a masked
-                                 key's softmax weight is exactly 0 in fp32); 0 = dense padded rows like the reference.
-                                 lds has no mask (pixelmodel.py:189-190) and must use 0 */
+    int32_t pack_tokens;      /* 1 = skip token rows that cannot change a logit; 0 = the reference's padded rows.
+                                 zk / lxmert: padded tokens whose keys are masked are dropped (a masked key's softmax weight is
+                                 exactly 0 in fp32).  lds has no mask (pixelmodel.py:189-190), but its feature and label tokens carry
+                                 no position embedding, so identical rows of a pair (the zero-padded boxes, boxes of one class) stay
+                                 identical through every layer: one representative is kept and its key carries log(multiplicity) --
+                                 the same softmax and the same P V up to fp32 round-off */
     int32_t fuse_layernorm;   /* 1: the N = 768 projections (attention output, FFN down) of launches with >= 16384 rows add the
                                  residual and apply the LayerNorm in their GEMM epilogue (gemm_pp_ln.h: the three column tiles of
-                                 a row panel exchange row statistics across workgroups; precision modes 2 and 4), instead of
+                                 a row panel exchange row statistics across workgroups; precision mode 2 only), instead of
                                  writing the fp32 sum for a separate LayerNorm kernel.  Same results to fp32 round-off; 12 -> 6 KB
                                  of HBM traffic per row and LayerNorm, but measured NOT faster on MI355X, so the
                                  default is 0 */

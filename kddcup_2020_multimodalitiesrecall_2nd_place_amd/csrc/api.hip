@@ -592,7 +592,7 @@ int gemm_ln(mms_handle* h, hipStream_t st, bool f8, const Planes& a, int lda, co
             const float* bias, int64_t M, int K, const Planes& resid, const float* g, const float* b, const Planes& out, float* t,
             const int* m_dev, bool* fused) {
     *fused = false;
-    if (!h->fuse_ln || M < 16384 || !(f8 || h->nsplit == 2) || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
+    if (!h->fuse_ln || f8 || M < 16384 || h->nsplit != 2 || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
     if (f8 ? (K % 128 != 0) : (K % 64 != 0)) return MMS_OK;
     GemmParams p{};
     if (f8) {
@@ -897,27 +897,40 @@ int lds_chunk(mms_handle* h, hipStream_t st, const mms_lds_batch* b, int64_t p0,
     const mms_config& c = h->cfg;
     const int T = c.text_len, S = T + 2 * MMS_NBOX;
     const int64_t NB = n * MMS_NBOX;
+    // embedding stage in the dense [n, 40] layout; packed mode builds it in the idle y buffer and then keeps one representative of
+    // every group of identical feature / label token rows (rowops.hip k_lds_plan_*: duplicates ride as log(multiplicity) on the key)
+    Planes emb = c.pack_tokens ? h->y : h->x;
     launch_lds_embed_text(h->E, h->type_tab, h->pos_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, b->segment_ids + p0 * T, T, S,
-                          c.vocab, h->x.hi, h->x.lo, (int)n, st);
+                          c.vocab, emb.hi, emb.lo, (int)n, st);
     Planes featp = h->mid;
     if (featp_shared) featp = *featp_shared;
     else launch_split_f32(b->features + p0 * MMS_NBOX * MMS_FEAT, featp.hi, featp.lo, NB * MMS_FEAT, st);
     // featureemb (linear) written straight into rows b*S + T + n of the hidden state (pixelmodel.py:600-601)
     if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_feat, h->b_feat, NB, H, MMS_FEAT, ACT_NONE,
-                      to_planes(h->x, H, RowMap{MMS_NBOX, S, T}))) return rc;
-    launch_lds_label(h->E, h->w_lab8, b->labelfeat + p0 * MMS_NBOX * MMS_LABEL_LEN, c.vocab, S, T + MMS_NBOX, h->x.hi, h->x.lo, (int)n, st);
+                      to_planes(emb, H, RowMap{MMS_NBOX, S, T}))) return rc;
+    launch_lds_label(h->E, h->w_lab8, b->labelfeat + p0 * MMS_NBOX * MMS_LABEL_LEN, c.vocab, S, T + MMS_NBOX, emb.hi, emb.lo, (int)n, st);
+    Pack pk;
+    const float* key_add = nullptr;
+    if (c.pack_tokens) {
+        launch_lds_pack_plan(b->features + p0 * MMS_NBOX * MMS_FEAT, b->labelfeat + p0 * MMS_NBOX * MMS_LABEL_LEN, T, (int)n, h->pk_src[1],
+                             h->pk_off[0], h->pk_cnt[0], h->pk_src[0], h->key_add, h->pk_rows, st);
+        launch_rows_pick(emb.hi, emb.lo, h->pk_src[0], h->pk_rows, (int)(n * S), h->x.hi, h->x.lo, st);
+        pk.off = h->pk_off[0]; pk.cnt = h->pk_cnt[0]; pk.rows = h->pk_rows;
+        key_add = h->key_add;
+    }
     if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, n * S * H, st);
     const int nl = (c.stop_after >= 0 && c.stop_after < c.layers) ? c.stop_after : c.layers;
     const bool cls_only = c.stop_after < 0 && c.layers > 0;
     for (int i = 0; i < nl; ++i) {
         if (cls_only && i == nl - 1) {
-            if (int rc = last_block_cls(h, st, h->layers[i].att, h->layers[i].ffn, ACT_GELU_TANH, h->x, h->y, S, n, nullptr, Pack())) return rc;
+            if (int rc = last_block_cls(h, st, h->layers[i].att, h->layers[i].ffn, ACT_GELU_TANH, h->x, h->y, S, n, key_add, pk)) return rc;
             break;
         }
-        if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, n, nullptr)) return rc;
-        if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * S, ACT_GELU_TANH)) return rc;
+        if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, S, n, key_add, pk)) return rc;
+        if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * S, ACT_GELU_TANH, pk)) return rc;
     }
-    if (int rc = gemm(h, st, h->x, H, cls_only ? ID : RowMap{1, S, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H))) return rc;
+    if (int rc = gemm(h, st, h->x, H, cls_only ? ID : RowMap{1, S, 0}, h->w_pool, h->b_pool, n, H, H, ACT_TANH, to_f32(h->pooled, H), nullptr,
+                      nullptr, cls_only ? nullptr : pk.off)) return rc;
     launch_lds_head(h->pooled, h->w_cls, h->b_cls, logits + p0 * 2, probs ? probs + p0 * 2 : nullptr, (int)n, st);
     return MMS_OK;
 }
@@ -1149,7 +1162,6 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
         const int seq = cfg->text_len + (cfg->model == MMS_MODEL_ZK ? MMS_NBOX : cfg->model == MMS_MODEL_LDS ? 2 * MMS_NBOX : 0);
         if (seq > 48) { g_err = "text_len too long: the sequence (" + std::to_string(seq) + " tokens) exceeds the 48-token attention kernels"; return MMS_ERR_ARG; }
     }
-    if (cfg->pack_tokens && cfg->model == MMS_MODEL_LDS) { g_err = "lds has no attention mask: every token is live, pack_tokens must be 0"; return MMS_ERR_ARG; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) { g_err = std::string("no HIP device: ") + hipGetErrorString(e); return MMS_ERR_HIP; }

@@ -169,6 +169,17 @@ __global__ __launch_bounds__(256) void k_rows_scatter(const bf16* s_hi, const bf
         *reinterpret_cast<bf16x4*>(d_lo + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_lo + so + t * 256 + lane * 4);
     }
 }
+__global__ __launch_bounds__(256) void k_rows_pick(const bf16* s_hi, const bf16* s_lo, const int* map, const int* rows_dev, int max_rows,
+                                                   bf16* d_hi, bf16* d_lo) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= max_rows || row >= *rows_dev) return;
+    const long long so = (long long)map[row] * MMS_HIDDEN, d = (long long)row * MMS_HIDDEN;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        *reinterpret_cast<bf16x4*>(d_hi + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_hi + so + t * 256 + lane * 4);
+        *reinterpret_cast<bf16x4*>(d_lo + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_lo + so + t * 256 + lane * 4);
+    }
+}
 __global__ __launch_bounds__(256) void k_rows_gather(const bf16* s_hi, const bf16* s_lo, const int* map, const int* idx, int T, const int* rows_dev,
                                                      int max_rows, bf16* d_hi, bf16* d_lo) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -286,6 +297,10 @@ void launch_gather_i64_rows(const int64_t* in, const int* rows_of, int T, long l
 void launch_rows_scatter(const bf16* s_hi, const bf16* s_lo, const int* map, const int* rows_dev, int max_rows, bf16* d_hi, bf16* d_lo,
                          hipStream_t st) {
     if (max_rows > 0) hipLaunchKernelGGL(k_rows_scatter, dim3((max_rows + 3) / 4), dim3(256), 0, st, s_hi, s_lo, map, rows_dev, max_rows, d_hi, d_lo);
+}
+void launch_rows_pick(const bf16* s_hi, const bf16* s_lo, const int* map, const int* rows_dev, int max_rows, bf16* d_hi, bf16* d_lo,
+                      hipStream_t st) {
+    if (max_rows > 0) hipLaunchKernelGGL(k_rows_pick, dim3((max_rows + 3) / 4), dim3(256), 0, st, s_hi, s_lo, map, rows_dev, max_rows, d_hi, d_lo);
 }
 void launch_rows_gather(const bf16* s_hi, const bf16* s_lo, const int* map, const int* idx, int T, const int* rows_dev, int max_rows,
                         bf16* d_hi, bf16* d_lo, hipStream_t st) {

@@ -45,7 +45,7 @@ bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t 
 void launch_gemm_v0(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm.hip (lab only)
 bool launch_gemm_ring(const GemmParams& p, int nsplit, int nslot, hipStream_t st);      // gemm_ring.hip (variants 11: 4 slots, 12: 2 slots)
 bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist = false);                     // gemm_pp.hip (variant 20: 256x256 ping-pong phases)
-bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm_pp.hip + gemm_pp_ln.h: N = 768 with the fused residual + LayerNorm epilogue (nsplit 2, or fp8 operands)
+bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm_pp.hip + gemm_pp_ln.h: N = 768 with the fused residual + LayerNorm epilogue (nsplit 2)
 bool launch_gemm_pp_f8(const GemmParams& p, hipStream_t st);                            // gemm_pp.hip with e4m3 operands (precision mode 4)
 bool launch_gemm_ppw(const GemmParams& p, hipStream_t st);                               // gemm_ppw.hip: precision mode 3 (A and W split), 256x128 ping-pong phases
 void set_gemm_variant(int v);   // test hook, see gemm_dispatch.hip
@@ -100,6 +100,9 @@ void launch_zk_embed_packed(const float* E, const float* type_tab, const float* 
                             const float* beta, const int* query_ids, const int* segment_ids, const float* tok,
                             int T, int vocab, const int* tok_src, const int* rows_dev, int max_rows,
                             bf16* o_hi, bf16* o_lo, hipStream_t st);
+// lds: identical feature / label token rows of a pair merged, multiplicity as an additive log on the key (rowops.hip)
+void launch_lds_pack_plan(const float* feats, const int64_t* labelfeat, int T, int n, int* nz_flags, int* off, int* cnt, int* tok_src,
+                          float* key_add, int* rows_dev, hipStream_t st);
 void launch_lx_pack_plan(const int64_t* input_mask, const float* visual_mask, int T, int n, int* l_off, int* l_cnt,
                          int* l_src, float* l_add, int* l_rows, int* v_off, int* v_cnt, int* v_src, float* v_add,
                          int* v_rows, hipStream_t st);
@@ -152,6 +155,8 @@ void launch_gather_i64_rows(const int64_t* in, const int* rows_of, int T, long l
 // packed plane rows r < *rows_dev:  scatter: d[map[r]] = s[r];  gather: d[r] = s[idx[map[r] / T] * T + map[r] % T]
 void launch_rows_scatter(const bf16* s_hi, const bf16* s_lo, const int* map, const int* rows_dev, int max_rows, bf16* d_hi, bf16* d_lo,
                          hipStream_t st);
+void launch_rows_pick(const bf16* s_hi, const bf16* s_lo, const int* map, const int* rows_dev, int max_rows, bf16* d_hi, bf16* d_lo,
+                      hipStream_t st);   // d[r] = s[map[r]]
 void launch_rows_gather(const bf16* s_hi, const bf16* s_lo, const int* map, const int* idx, int T, const int* rows_dev, int max_rows,
                         bf16* d_hi, bf16* d_lo, hipStream_t st);
 // ensemble, second zk member: diff[b] = the rewritten query of pair b differs from the original; compact list of those pairs; row gathers;

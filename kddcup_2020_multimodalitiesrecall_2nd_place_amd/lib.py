@@ -120,7 +120,7 @@ class Handle:
             c.layers, c.r_layers, c.x_layers = cfg.layers, 0, 0
         c.vocab, c.inter, c.max_pos, c.type_vocab, c.text_len = cfg.vocab, cfg.inter, cfg.max_pos, cfg.type_vocab, cfg.text_len
         c.precision, c.chunk_pairs, c.stop_after, c.device = precision, chunk_pairs, stop_after, device
-        c.pack_tokens = int(bool(pack_tokens) and cfg.name != "lds")
+        c.pack_tokens = int(bool(pack_tokens))
         c.fuse_layernorm = int(bool(fuse_layernorm))
         self._h = C.c_void_p()
         rc = self.lib.mms_create(C.byref(c), C.byref(self._h))

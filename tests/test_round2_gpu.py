@@ -391,10 +391,10 @@ def test_ensemble_second_zk_member_with_no_and_all_queries_changed():
 # ---------------------------------------------------------------------------------------------------------------------
 # GEMM with the fused bias + residual + LayerNorm epilogue (gemm_pp_ln.h)
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("case", [(16400, 768, 0), (20000 + 37, 3072, 0), (66000, 768, 0), (16640, 768, 1), (300, 768, 0)])
+@pytest.mark.parametrize("case", [(16400, 768, 0), (20000 + 37, 3072, 0), (66000, 768, 0), (300, 768, 0)])
 def test_gemm_with_fused_layernorm_epilogue(case):
     """Ragged M (last row panel partly live), both K of the model, more tiles than CUs (66000 rows = 774 tiles: several persistent
-    rounds and the round-boundary partner wait), the fp8 variant, and a launch smaller than one round."""
+    rounds), and a launch smaller than one round."""
     M, K, f8 = case
     l = lib.load()
     a = weights.normal("ln/a/%d/%d" % (M, K), (M, K), 1)
@@ -424,7 +424,7 @@ def test_gemm_with_fused_layernorm_epilogue(case):
     assert err < (2e-4 if f8 else 3e-5), err
 
 
-@pytest.mark.parametrize("name,precision", [("zk", 2), ("lxmert", 2), ("lds", 4)])
+@pytest.mark.parametrize("name,precision", [("zk", 2), ("lxmert", 2), ("lds", 2), ("lds", 4)])
 def test_fused_layernorm_forward_matches_the_two_kernel_route(name, precision):
     """mms_config.fuse_layernorm at a size where the big launches really take the fused epilogue (>= 16384 rows): logits against
     the default route of the same handle configuration and, in mode 2, against the oracle on a subset."""
@@ -460,5 +460,30 @@ def test_fused_layernorm_forward_matches_the_two_kernel_route(name, precision):
         err = np.linalg.norm(l1[idx] - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 0.1)
         assert err.max() < TOL_P2, err
     else:
-        # fp8: a round-off-level change before an e4m3 rounding can flip that rounding, so only a loose agreement is meaningful
-        assert np.median(vecrel(l1, l0)) < 5e-2
+        assert np.array_equal(l1, l0)      # precision 4 keeps the two-kernel route (the option applies to mode 2 only)
+
+
+def test_lds_merged_identical_tokens_equal_dense_rows():
+    """lds has no mask, but identical feature / label token rows of a pair (zero-padded boxes, boxes of one class) can share one
+    representative with log(multiplicity) on its key.  Packed == dense == oracle, incl. the cases where nothing may be merged."""
+    cfg = small_cfg("lds", layers=3)
+    w = weights.make_weights(cfg)
+    ps = synth.make_pairs(6, (3, 5), vocab=cfg.vocab, tag="/ldsmerge")
+    b = synth.lds_batch(ps, cfg.text_len)
+    b["features"][0] = np.abs(weights.normal("ldsmerge/f0", (10, 2048), 3)) + 0.1      # pair 0: ten live boxes ...
+    b["labelfeat"][0] = np.arange(80).reshape(10, 8) % cfg.vocab + 200                     # ... of ten different classes: nothing merges
+    b["features"][1] = 0.0; b["labelfeat"][1] = 0                                          # pair 1: no box at all: two representatives
+    b["labelfeat"][2, :] = b["labelfeat"][2, 0]                                            # pair 2: every box of the same class
+    b["features"][3, 9, 5] = 1e-3                                                          # pair 3: a "padded" box that is not quite zero
+    b["labelfeat"][4, 1] = b["labelfeat"][4, 0]; b["labelfeat"][4, 3] = b["labelfeat"][4, 0]   # pair 4: classes repeat non-adjacently
+    ref, _ = O.forward(cfg, w, b, np.float64)
+    outs = {}
+    for pack in (True, False):
+        s = scorers.LdsScorer(cfg, w, pack_tokens=pack, chunk_pairs=7)
+        outs[pack] = scorers.score_batch(s, b)[0].cpu().numpy()
+        s.close()
+    assert vecrel(outs[False], ref).max() < TOL_P2 and vecrel(outs[True], ref).max() < TOL_P2, (vecrel(outs[True], ref).max())
+    assert np.abs(outs[True] - outs[False]).max() < 2e-4
+    s = scorers.LdsScorer(cfg, w, precision=4)
+    assert np.isfinite(scorers.score_batch(s, b)[0].cpu().numpy()).all()
+    s.close()
