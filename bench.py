@@ -11,8 +11,9 @@ building, on-device label-tuple de-duplication), every kernel of the forward -- 
 
 --gpus N > 1 without WORLD_SIZE in the environment: this process spawns the N ranks itself (one process per GPU, RCCL);
 under torchrun / torch.distributed.run it uses the ranks it is given (and refuses a --gpus that contradicts WORLD_SIZE).
---workload testB: the reference's testB shape -- 994 queries x 8..30 candidates = ONE job cut into contiguous query blocks
-(ragged shards, strong scaling; run_pretraining_predict_score.py:566, prediction_result/*.txt).
+--workload testB | valid: the reference's file shapes -- 994 queries x 8..30 candidates (testB) / 496 x 9..30 (valid; zk then gets
+the ground-truth label fed to its AM-softmax head, load_data_v4.py:259-263) = ONE job cut into contiguous query blocks (ragged
+shards, strong scaling; run_pretraining_predict_score.py:566, prediction_result/*.txt).
 --model ensemble: BASELINE.json config 5 -- zk, zk on the sen2forest rewrite, lds and lxmert on the same pairs through the
 fused entry point (mms_score_ensemble); a "pair scored" then means scored by all four members and merged.
 """
@@ -52,7 +53,7 @@ def device_feats(ps, device, seed):
     return f * live[:, :, None]
 
 
-def device_feed(cfg_name, cfgs, ps, feats, dev):
+def device_feed(cfg_name, cfgs, ps, feats, dev, valid=False):
     """The rank's feed, every array already on the device in the dtype the library reads (so a step's prepare() is struct
     building only -- what a caller that keeps its candidate store in HBM pays per call)."""
     ps.feats = feats
@@ -60,8 +61,9 @@ def device_feed(cfg_name, cfgs, ps, feats, dev):
     def dv(b):
         return {k: (torch.as_tensor(v).to(dev) if isinstance(v, np.ndarray) and v.dtype.kind in "fiu" else v) for k, v in b.items()}
     if cfg_name == "ensemble":
-        zb = synth.zk_batch(ps, cfgs["zk"].text_len)
-        zb2 = synth.zk_batch(synth.sen2forest_variant(ps), cfgs["zk"].text_len)
+        lab = "valid" if valid else "testB"
+        zb = synth.zk_batch(ps, cfgs["zk"].text_len, lab)
+        zb2 = synth.zk_batch(synth.sen2forest_variant(ps), cfgs["zk"].text_len, lab)
         xb = synth.lxmert_batch(ps, cfgs["lxmert"].text_len)
         from kddcup_2020_multimodalitiesrecall_2nd_place_amd.pipeline import ensemble_feed
         f = ensemble_feed(zb, zb2, xb)
@@ -69,7 +71,7 @@ def device_feed(cfg_name, cfgs, ps, feats, dev):
         for k in ("num_boxes", "label_ids", "query_ids", "len_query", "s2f_query_ids", "s2f_len_query", "lx_input_ids", "lx_input_mask"):
             f[k] = f[k].to(torch.int32)
         return f
-    b = dv(synth.batch_for(cfgs[cfg_name], ps))
+    b = dv(synth.batch_for(cfgs[cfg_name], ps, labels="valid") if (cfg_name == "zk" and valid) else synth.batch_for(cfgs[cfg_name], ps))
     key = {"zk": "np_images_features", "lds": "features", "lxmert": "feats"}[cfg_name]
     b[key] = feats
     return b
@@ -191,7 +193,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="zk", choices=["zk", "lds", "lxmert", "ensemble"])
     ap.add_argument("--precision", type=int, default=2)
-    ap.add_argument("--workload", default="bench", choices=["bench", "testB"])
+    ap.add_argument("--workload", default="bench", choices=["bench", "testB", "valid"])
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--cands", type=int, default=30)
     ap.add_argument("--chunk", type=int, default=0)
@@ -233,17 +235,19 @@ def main():
     scorer, members = make_members(a.model, a, local)
     cfgs = {n: m[0] for n, m in members.items()}
     handles = [m[2].handle for m in members.values()]
-    if a.workload == "testB":
-        # ONE 994-query job, candidate sets of 8..30, contiguous query blocks per rank (strong scaling, ragged shards)
-        whole = synth.make_pairs(994, (8, 30), tag="/testB", with_feats=False, all_boxes=a.all_boxes)
+    if a.workload in ("testB", "valid"):
+        # ONE job (testB: 994 queries x 8..30 candidates; valid: 496 x 9..30, prediction_result/*.txt / validscore_imagebert.txt),
+        # contiguous query blocks per rank (strong scaling, ragged shards)
+        NQ, cr = (994, (8, 30)) if a.workload == "testB" else (496, (9, 30))
+        whole = synth.make_pairs(NQ, cr, tag="/" + a.workload, with_feats=False, all_boxes=a.all_boxes)
         qop = whole.query_id - whole.query_id.min()
-        counts = sharding.shard_sizes(qop, 994, world)
-        lo, hi = sharding.query_block(994, world, rank)
+        counts = sharding.shard_sizes(qop, NQ, world)
+        lo, hi = sharding.query_block(NQ, world, rank)
         s, e = sharding.pair_slice_for_queries(qop, lo, hi)
         ps = whole.take(slice(s, e))
         total_pairs = whole.n
         scaling = "strong"
-        wl = "testB-like: 994 queries x 8..30 candidates (%d pairs) cut into %d contiguous query blocks" % (whole.n, world)
+        wl = "%s-like: %d queries x %d..%d candidates (%d pairs) cut into %d contiguous query blocks" % (a.workload, NQ, cr[0], cr[1], whole.n, world)
     else:
         # rank r owns queries [r*Q, (r+1)*Q) of the logical N*Q-query job (weak scaling)
         ps = synth.make_pairs(a.queries, a.cands, tag="/bench%d" % rank, with_feats=False, query_offset=rank * a.queries,
@@ -253,7 +257,7 @@ def main():
         scaling = "weak"
         wl = "%d queries x %d candidates per GPU" % (a.queries, a.cands)
     feats = device_feats(ps, dev, 20200823 + rank)
-    feed = device_feed(a.model, cfgs, ps, feats, dev)
+    feed = device_feed(a.model, cfgs, ps, feats, dev, valid=a.workload == "valid")
     qid = torch.as_tensor(ps.query_id, device=gather_dev)
     pid = torch.as_tensor(ps.product_id, device=gather_dev)
 
