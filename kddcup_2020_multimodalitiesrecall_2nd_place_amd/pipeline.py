@@ -154,20 +154,45 @@ class EnsembleScorer:
         return qid, pid, cat(merged, np.float64), tuple(cat(x, np.float32) for x in parts)
 
     def score_tsv_native(self, tsv_path, vocab_path, label_table, batch_pairs: int = 16384, threads: int = 0):
-        """``score_lines`` on a TSV file through libmmfeat: every span batch is decoded three times (zk flavour, zk with the
-        sen2forest rewrite, lxmert flavour) and scored by one fused call."""
+        """``score_lines`` on a TSV file through libmmfeat, decode and scoring overlapped: a producer thread decodes span batch i+1
+        three times (zk flavour, zk with the sen2forest rewrite, lxmert flavour; ctypes releases the GIL, each featurizer rotates
+        three pinned buffer sets) while the main thread copies batch i to the device and runs the ONE fused call on it."""
+        import queue
+        import threading
+
         from .featurizer_native import NativeFeaturizer
-        mk = lambda m: NativeFeaturizer(vocab_path, label_table, m, threads=threads, pinned=True, reuse_buffers=True)
+        mk = lambda m: NativeFeaturizer(vocab_path, label_table, m, threads=threads, pinned=True, reuse_buffers=True, pools=3)
         nf_zk, nf_s2f, nf_lx = mk("zk"), mk("zk"), mk("lxmert")
+        q = queue.Queue(maxsize=1)          # one decoded batch waiting + one being decoded + one being scored = 3 buffer sets
+
+        def produce():
+            try:
+                for base, getbytes, starts, ends in nf_zk.iter_spans(tsv_path, batch_pairs):
+                    a = nf_zk._run(base, getbytes, starts, ends, False)
+                    item = (a["query_id"].copy(), a["product_id"].copy(), nf_zk._layout(a),
+                            nf_s2f._layout(nf_s2f._run(base, getbytes, starts, ends, True)),
+                            nf_lx._layout(nf_lx._run(base, getbytes, starts, ends, False)))
+                    q.put(item)
+                q.put(None)
+            except BaseException as e:      # surfaced in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
         qids, pids, merged, parts = [], [], [], [[], [], [], []]
-        for base, getbytes, starts, ends in nf_zk.iter_spans(tsv_path, batch_pairs):
-            a = nf_zk._run(base, getbytes, starts, ends, False)
-            qids.append(a["query_id"].copy())
-            pids.append(a["product_id"].copy())
-            m, p4 = self._score(nf_zk._layout(a), nf_s2f._layout(nf_s2f._run(base, getbytes, starts, ends, True)),
-                                nf_lx._layout(nf_lx._run(base, getbytes, starts, ends, False)))
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            qi, pi, zf, sf, lf = item
+            qids.append(qi)
+            pids.append(pi)
+            m, p4 = self._score(zf, sf, lf)     # H2D from the pinned set + fused call; returns after the device is done with it
             merged.append(m)
             for k in range(4):
                 parts[k].append(p4[k])
+        th.join()
         cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
         return cat(qids, np.int64), cat(pids, np.int64), cat(merged, np.float64), tuple(cat(x, np.float32) for x in parts)

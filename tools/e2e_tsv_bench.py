@@ -38,7 +38,7 @@ if name == "ensemble":      # BASELINE.json config 5: TSV -> four score tables -
     from kddcup_2020_multimodalitiesrecall_2nd_place_amd import ensemble as E
     sc = {m: scorers.make_scorer(c, weights.make_weights(c), device=0) for m, c in (("zk", ZkConfig()), ("lds", LdsConfig()), ("lxmert", LxmertConfig()))}
     ens = pipeline.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
-    for _ in range(2):
+    for _ in range(3):
         torch.cuda.synchronize(); t0 = time.time()
         qid, pid, merged, parts = ens.score_tsv_native(path, VOCAB, TABLE, batch_pairs=16384)
         t1 = time.time()
