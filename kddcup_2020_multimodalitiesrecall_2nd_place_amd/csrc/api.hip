@@ -507,6 +507,7 @@ int ensure_label_ws(mms_handle* h, int64_t U) {
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 struct GemmOut {
+    int hm_rows = 0, hm_col0 = 0;                       // head-major [Q | K | V] blocks (kernels.h GemmParams::hm_rows)
     float* f32 = nullptr; int ldc = 0;
     Planes pl; int ldp = 0;
     RowMap cmap{0, 0, 0};
@@ -528,7 +529,7 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     }
     p.act = act;
     p.out_kind = out.f32 ? OUT_F32 : OUT_PLANES;
-    p.c_f32 = out.f32; p.ldc = out.ldc;
+    p.c_f32 = out.f32; p.ldc = out.ldc; p.hm_rows = out.hm_rows; p.hm_col0 = out.hm_col0;
     p.c_hi = out.pl.hi; p.c_lo = out.pl.lo; p.ldp = out.ldp; p.cmap = out.cmap;
     if (resid && !h->resid_in_ln) { p.r_hi = resid->hi; p.r_lo = resid->lo; p.ldr = H; }
     p.m_dev = m_dev; p.a_index = a_index; p.rmap = rmap; p.r_index = r_index;
@@ -561,7 +562,7 @@ int gemm_f8(mms_handle* h, hipStream_t st, const unsigned char* a8, int lda, con
     p.a_hi = (const bf16*)a8; p.a_lo = p.a_hi; p.lda = lda / 2; p.amap = RowMap{0, 0, 0};
     p.w = (const bf16*)w8; p.bias = bias; p.col_scale = wscale; p.M = (int)M; p.N = N; p.K = K / 2;
     p.act = act;
-    if (out.f32) { p.out_kind = OUT_F32; p.c_f32 = out.f32; p.ldc = out.ldc; }
+    if (out.f32) { p.out_kind = OUT_F32; p.c_f32 = out.f32; p.ldc = out.ldc; p.hm_rows = out.hm_rows; p.hm_col0 = out.hm_col0; }
     else { p.out_kind = OUT_F8; p.c_f8 = out.pl.f8; p.ldf8 = out.ldp; }
     p.cmap = out.cmap; p.rmap = RowMap{0, 0, 0};
     p.m_dev = m_dev;
@@ -638,6 +639,18 @@ int ln_begin_call(mms_handle* h, hipStream_t st) {
 }
 
 GemmOut to_f32(float* p, int ldc) { GemmOut o; o.f32 = p; o.ldc = ldc; return o; }
+// The [Q | K | V] projection of a token stream (first row row0, at most `rows` rows) in its own region of the qkv buffer, head-major:
+// 36 blocks [rows][64] (Q heads, K heads, V heads).  The GEMM's 64-column wave tiles write whole blocks row after row, the attention
+// kernel's per-(pair, head) wave reads S consecutive 256-byte rows -- contiguous on both sides instead of 256 bytes every 9216.
+float* qkv_region(mms_handle* h, int64_t row0) { return h->qkv + row0 * 3 * H; }
+GemmOut to_qkv(mms_handle* h, int64_t row0, int64_t rows, int col0 = 0) {
+    GemmOut o; o.f32 = qkv_region(h, row0); o.ldc = 3 * H; o.hm_rows = (int)rows; o.hm_col0 = col0; return o;
+}
+void attn_q(AttnParams& a, mms_handle* h, int64_t row0, int64_t rows) { a.q = qkv_region(h, row0); a.ldq = MMS_HEAD_DIM; a.hs_q = rows * MMS_HEAD_DIM; }
+void attn_kv(AttnParams& a, mms_handle* h, int64_t row0, int64_t rows) {
+    a.k = qkv_region(h, row0) + 12 * rows * MMS_HEAD_DIM; a.v = qkv_region(h, row0) + 24 * rows * MMS_HEAD_DIM;
+    a.ldkv = MMS_HEAD_DIM; a.hs_kv = rows * MMS_HEAD_DIM;
+}
 GemmOut to_planes(Planes p, int ldp, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.pl = p; o.ldp = ldp; o.cmap = m; return o; }
 const RowMap ID{0, 0, 0};
 
@@ -671,12 +684,11 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     const int64_t M = B * S;
     const bool f8 = h->f8 && in.f8;
     if (f8) {
-        if (int rc = gemm_f8(h, st, in.f8 + row0 * H, H, w.wqkv8, w.wqkvs, w.bqkv, M, 3 * H, H, ACT_NONE, to_f32(h->qkv + row0 * 3 * H, 3 * H), pk.rows)) return rc;
+        if (int rc = gemm_f8(h, st, in.f8 + row0 * H, H, w.wqkv8, w.wqkvs, w.bqkv, M, 3 * H, H, ACT_NONE, to_qkv(h, row0, M), pk.rows)) return rc;
     } else if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wqkv, w.bqkv, M, 3 * H, H, ACT_NONE,
-                             to_f32(h->qkv + row0 * 3 * H, 3 * H), nullptr, pk.rows, nullptr, ID, nullptr, 1)) return rc;
+                             to_qkv(h, row0, M), nullptr, pk.rows, nullptr, ID, nullptr, 1)) return rc;
     AttnParams a{};
-    a.q = h->qkv + row0 * 3 * H; a.ldq = 3 * H;
-    a.k = a.q + H; a.v = a.q + 2 * H; a.ldkv = 3 * H;
+    attn_q(a, h, row0, M); attn_kv(a, h, row0, M);
     a.q_base = 0; a.Sq = S; a.kv_base = 0; a.Sk = S;
     a.key_add = key_add;
     a.o_hi = h->ctx.hi + row0 * H; a.o_lo = h->ctx.lo + row0 * H; a.ldo = H;
@@ -729,12 +741,12 @@ int last_block_cls(mms_handle* h, hipStream_t st, const AttW& att, const FfnW& f
     const RowMap cls = RowMap{1, S, 0};                 // dense: CLS of pair b is row b*S; packed: row pk.off[b]
     // K,V for every live row -> columns [768, 2304) of the qkv buffer
     if (int rc = gemm(h, st, in, H, ID, att.wqkv + (long long)H * H, att.bqkv + H, M, 2 * H, H, ACT_NONE,
-                      to_f32(h->qkv + H, 3 * H), nullptr, pk.rows)) return rc;
+                      to_qkv(h, 0, M, H), nullptr, pk.rows)) return rc;
     // Q for the CLS rows only -> compact fp32 [n,768] (the pooled buffer is idle until the pooler)
     if (int rc = gemm(h, st, in, H, cls, att.wqkv, att.bqkv, n, H, H, ACT_NONE, to_f32(h->pooled, H), nullptr, nullptr, pk.off)) return rc;
     AttnParams a{};
-    a.q = h->pooled; a.ldq = H; a.q_stride = 1; a.Sq = 1; a.o_compact = 1;
-    a.k = h->qkv + H; a.v = h->qkv + 2 * H; a.ldkv = 3 * H; a.Sk = S;
+    a.q = h->pooled; a.ldq = H; a.hs_q = MMS_HEAD_DIM; a.q_stride = 1; a.Sq = 1; a.o_compact = 1;      // compact fp32 [n,768] CLS queries
+    attn_kv(a, h, 0, M); a.Sk = S;
     a.key_add = key_add; a.kv_off = pk.off; a.kv_cnt = pk.cnt;
     a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo; a.ldo = H; a.B = (int)n;
     if (int rc = attend(h, a, st)) return rc;
@@ -1068,13 +1080,13 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
             // Last cross layer: only the language CLS row is read afterwards (pooler).  The vision stream's outputs
             // (visn<-lang attention, vision self-attention, vision FFN) are dead; the language stream needs the
             // lang<-visn cross attention on all its rows (they are the keys of its self-attention), then a CLS-only block.
-            if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, ML, H, H, ACT_NONE, to_f32(h->qkv, 3 * H), nullptr, pl.rows)) return rc;
+            if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, ML, H, H, ACT_NONE, to_qkv(h, 0, ML), nullptr, pl.rows)) return rc;
             if (int rc = gemm(h, st, h->x.at(ML * H), H, ID, w.cross.wqkv + (long long)H * H, w.cross.bqkv + H, MV, 2 * H, H, ACT_NONE,
-                              to_f32(h->qkv + ML * 3 * H + H, 3 * H), nullptr, pv.rows)) return rc;
+                              to_qkv(h, ML, MV, H), nullptr, pv.rows)) return rc;
             AttnParams a{};
-            a.ldq = a.ldkv = 3 * H; a.ldo = H; a.B = (int)n; a.q_base = a.kv_base = 0;
-            a.q = h->qkv; a.Sq = T;
-            a.k = h->qkv + ML * 3 * H + H; a.v = h->qkv + ML * 3 * H + 2 * H; a.Sk = V; a.key_add = visn_add;
+            a.ldo = H; a.B = (int)n; a.q_base = a.kv_base = 0;
+            attn_q(a, h, 0, ML); a.Sq = T;
+            attn_kv(a, h, ML, MV); a.Sk = V; a.key_add = visn_add;
             a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo;
             a.q_off = pl.off; a.q_cnt = pl.cnt; a.kv_off = pv.off; a.kv_cnt = pv.cnt;
             if (int rc = attend(h, a, st)) return rc;
@@ -1086,21 +1098,23 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
         // cross attention, both directions with the SAME weights (modeling.py:460-464): the QKV projection and
         // the output dense + LN run over both streams (one launch when dense, one per stream when packed)
         if (c.pack_tokens) {
-            if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, ML, 3 * H, H, ACT_NONE, to_f32(h->qkv, 3 * H), nullptr, pl.rows)) return rc;
+            if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, ML, 3 * H, H, ACT_NONE, to_qkv(h, 0, ML), nullptr, pl.rows)) return rc;
             if (int rc = gemm(h, st, h->x.at(ML * H), H, ID, w.cross.wqkv, w.cross.bqkv, MV, 3 * H, H, ACT_NONE,
-                              to_f32(h->qkv + ML * 3 * H, 3 * H), nullptr, pv.rows)) return rc;
+                              to_qkv(h, ML, MV), nullptr, pv.rows)) return rc;
         } else {
-            if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, R, 3 * H, H, ACT_NONE, to_f32(h->qkv, 3 * H))) return rc;
+            // dense rows: one projection over both streams, written as the two streams' own regions would be (rows [0, ML) and [ML, R))
+            if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, ML, 3 * H, H, ACT_NONE, to_qkv(h, 0, ML))) return rc;
+            if (int rc = gemm(h, st, h->x.at(ML * H), H, ID, w.cross.wqkv, w.cross.bqkv, MV, 3 * H, H, ACT_NONE, to_qkv(h, ML, MV))) return rc;
         }
         AttnParams a{};
-        a.ldq = a.ldkv = 3 * H; a.ldo = H; a.B = (int)n; a.q_base = a.kv_base = 0;
-        a.q = h->qkv; a.Sq = T;                                   // lang <- visn
-        a.k = h->qkv + ML * 3 * H + H; a.v = h->qkv + ML * 3 * H + 2 * H; a.Sk = V; a.key_add = visn_add;
+        a.ldo = H; a.B = (int)n; a.q_base = a.kv_base = 0;
+        attn_q(a, h, 0, ML); a.Sq = T;                            // lang <- visn
+        attn_kv(a, h, ML, MV); a.Sk = V; a.key_add = visn_add;
         a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo;
         a.q_off = pl.off; a.q_cnt = pl.cnt; a.kv_off = pv.off; a.kv_cnt = pv.cnt;
         if (int rc = attend(h, a, st)) return rc;
-        a.q = h->qkv + ML * 3 * H; a.Sq = V;                      // visn <- lang
-        a.k = h->qkv + H; a.v = h->qkv + 2 * H; a.Sk = T; a.key_add = lang_add;
+        attn_q(a, h, ML, MV); a.Sq = V;                           // visn <- lang
+        attn_kv(a, h, 0, ML); a.Sk = T; a.key_add = lang_add;
         a.o_hi = h->ctx.hi + ML * H; a.o_lo = h->ctx.lo + ML * H;
         a.q_off = pv.off; a.q_cnt = pv.cnt; a.kv_off = pl.off; a.kv_cnt = pl.cnt;
         if (int rc = attend(h, a, st)) return rc;
@@ -1684,7 +1698,7 @@ int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B,
     const int64_t n = B * Sq * H;
     DBG_TRY(hipMalloc((void**)&op, (size_t)n * 4));
     AttnParams a{};
-    a.q = q; a.ldq = H; a.k = k; a.v = v; a.ldkv = H; a.q_base = 0; a.Sq = Sq; a.kv_base = 0; a.Sk = Sk;
+    a.q = q; a.ldq = H; a.k = k; a.v = v; a.ldkv = H; a.hs_q = a.hs_kv = MMS_HEAD_DIM; a.q_base = 0; a.Sq = Sq; a.kv_base = 0; a.Sk = Sk;
     a.key_add = key_add; a.o_hi = op; a.o_lo = op + n; a.ldo = H; a.B = (int)B;
     if (!launch_attention(a, st)) { (void)hipFree(op); g_err = "mms_dbg_attention: no kernel for this (Sq, Sk)"; return MMS_ERR_ARG; }
     launch_planes_to_f32(op, op + n, out_f32, n, st);

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         if (jt * 16 >= Sk) continue;   // wave-uniform: this key tile holds no live key (ragged pairs)
         int j = jt * 16 + fr;
         j = j < Sk ? j : Sk - 1;
-        const float* kr = p.k + (long long)(kv0 + j) * p.ldkv + h * MMS_HEAD_DIM + fk * 4;
+        const float* kr = p.k + (long long)(kv0 + j) * p.ldkv + h * p.hs_kv + fk * 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) kf[jt][s] = *reinterpret_cast<const float4*>(kr + s * 16);
     }
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         if (qt * 16 >= Sq) continue;
         int i = qt * 16 + fr;
         i = i < Sq ? i : Sq - 1;
-        const float* qr = p.q + (long long)(q0 + i) * p.ldq + h * MMS_HEAD_DIM + fk * 4;
+        const float* qr = p.q + (long long)(q0 + i) * p.ldq + h * p.hs_q + fk * 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[qt][s] = *reinterpret_cast<const float4*>(qr + s * 16);
     }
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         for (int r = 0; r < 4; ++r) {
             int j = jt * 16 + fk * 4 + r;
             j = j < Sk ? j : Sk - 1;  // P is exactly 0 there; keep the load in bounds and finite
-            vfr[jt][r] = *reinterpret_cast<const float4*>(p.v + (long long)(kv0 + j) * p.ldkv + h * MMS_HEAD_DIM + fr * 4);
+            vfr[jt][r] = *reinterpret_cast<const float4*>(p.v + (long long)(kv0 + j) * p.ldkv + h * p.hs_kv + fr * 4);
         }
     }
     f32x4 sc[KT][QT];

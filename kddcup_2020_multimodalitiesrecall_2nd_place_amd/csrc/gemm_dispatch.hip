@@ -41,7 +41,7 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         if (diag_ok && variant >= 101 && variant <= 103 && launch_gemm_ring(p, nsplit, variant, st)) return;
         variant = 99;
     }
-    if (variant == 0 && !(p.m_dev || p.flop_counter)) { launch_gemm_v0(p, nsplit, st); return; }
+    if (variant == 0 && !(p.m_dev || p.flop_counter || p.hm_rows)) { launch_gemm_v0(p, nsplit, st); return; }
     if (variant == 11 && launch_gemm_ring(p, nsplit, 4, st)) return;
     if (variant == 12 && launch_gemm_ring(p, nsplit, 2, st)) return;
 #endif

@@ -60,7 +60,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT);
                 const long long orow = p.cmap(row);
                 if (p.out_kind == OUT_F32) {
-                    *reinterpret_cast<f32x4*>(p.c_f32 + orow * p.ldc + col) = v;
+                    float* dst = p.hm_rows ? p.c_f32 + ((long long)((p.hm_col0 + col) >> 6) * p.hm_rows + orow) * 64 + ((p.hm_col0 + col) & 63)
+                                           : p.c_f32 + orow * p.ldc + col;
+                    *reinterpret_cast<f32x4*>(dst) = v;
                 } else {
                     bf16x4 h, l;
 #pragma unroll

@@ -58,7 +58,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
             for (int j = 0; j < FN; ++j) acc[i][j] += bias4[j];
         }
         if (f32_out) {
-            float* dst = p.c_f32 + orow * p.ldc + col;
+            float* dst = p.hm_rows ? p.c_f32 + ((long long)((p.hm_col0 + col0) >> 6) * p.hm_rows + orow) * 64 + nq * 4   // the wave's 64 columns = one head
+                                   : p.c_f32 + orow * p.ldc + col;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 f32x4 v = acc[i][j];

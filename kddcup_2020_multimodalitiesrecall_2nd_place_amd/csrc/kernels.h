@@ -28,6 +28,9 @@ struct GemmParams {
     // precision mode 4 (fp8 operands, gemm_pp.hip only): a_hi / w point at e4m3 bytes and lda / K count PAIRS of them (= the same
     // 2-byte units as the bf16 planes, so every address in the tile engine is unchanged); col_scale[n] = the weight row's
     // quantisation scale, applied to the accumulator before the bias; OUT_F8 stores e4m3 bytes at c_f8[row * ldf8 + col]
+    // OUT_F32, head-major (hm_rows > 0): the 64-column group G = (hm_col0 + col) / 64 of row r goes to c_f32[(G * hm_rows + r) * 64 + ...]
+    // -- the [Q | K | V] projection laid out as 36 contiguous [rows][64] blocks (12 heads each), which is how the attention kernel reads it
+    int hm_rows, hm_col0;
     int f8;
     const float* col_scale;
     unsigned char* c_f8; int ldf8;
@@ -58,6 +61,7 @@ int get_gemm_variant();
 struct AttnParams {
     const float* q; int ldq;
     const float* k; const float* v; int ldkv;
+    long long hs_q, hs_kv;       // element stride between heads: 64 inside a [rows][768+] row, rows * 64 for head-major blocks
     int q_base, Sq, kv_base, Sk;
     const float* key_add;        // additive mask indexed by kv row (relative to kv_base) or nullptr
     bf16* o_hi; bf16* o_lo; int ldo;
