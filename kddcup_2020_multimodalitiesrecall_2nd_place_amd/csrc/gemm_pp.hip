@@ -23,6 +23,7 @@
 // RAW: the wait sits before phase 4's first barrier and the first read of that data is in the next phase (one
 // barrier later for the staggered wave row).  WAR: a slot is refilled >= 2 phases after its last ds_read.
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -353,6 +354,9 @@ static int pp_cu_count() {
         hipDeviceProp_t prop;
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
                    ? prop.multiProcessorCount / 8 * 8 : 8;
+#ifdef MMS_LAB
+        if (const char* e = getenv("MMS_PP_GRID")) n_cu = atoi(e) / 8 * 8;   // lab: persistent GEMMs on part of the chip (tools/dual_stream.py)
+#endif
     }
     return n_cu;
 }

@@ -1,6 +1,7 @@
-"""Experiment: do two scorer handles on two HIP streams of ONE process overlap usefully (GEMM epilogue bursts and the
-HBM-bound LN / attention kernels of one stream under the MFMA-bound GEMMs of the other)?
-usage (GPU box): python tools/dual_stream.py [model]"""
+"""Experiment: two scorer handles on two HIP streams of ONE process, each on half of the pairs -- do the HBM-bound kernels (LayerNorm,
+attention, tile-boundary stores) of one stream hide under the MFMA-bound GEMMs of the other?  With MMS_PP_GRID=128 (lab build) the
+persistent GEMMs of each stream take half of the CUs, so both streams are resident at once.
+usage (GPU box): [MMS_PP_GRID=128] python tools/dual_stream.py [model] [streams]"""
 import os
 import sys
 import time
@@ -8,22 +9,23 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kddcup_2020_multimodalitiesrecall_2nd_place_amd import lib
+lib.load(lib.LAB_LIB_PATH)
 import bench  # noqa: E402
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd import scorers, synth, weights  # noqa: E402
-from kddcup_2020_multimodalitiesrecall_2nd_place_amd.config import LdsConfig, LxmertConfig, ZkConfig  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "zk"
-cfg = {"zk": ZkConfig(), "lds": LdsConfig(), "lxmert": LxmertConfig()}[name]
+NS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+cfg = bench.CFGS[name]()
 dev = torch.device("cuda", 0)
 w = weights.make_weights(cfg)
-NS = int(os.environ.get("DS_STREAMS", 2))
-sc, prep, streams = [], [], []
+sc, feed, streams = [], [], []
 for i in range(NS):
     s = scorers.make_scorer(cfg, w, device=0)
     ps = synth.make_pairs(1000 // NS, 30, tag="/ds%d" % i, with_feats=False)
     feats = bench.device_feats(ps, dev, 7 + i)
-    sc.append(s); prep.append(bench.prepare(s, cfg, ps, feats)); streams.append(torch.cuda.Stream(dev))
-n_pairs = sum(p_.n if hasattr(p_, "n") else 0 for p_ in prep) or (1000 // NS) * 30 * NS
+    sc.append(s); feed.append(bench.device_feed(name, {name: cfg}, ps, feats, dev)); streams.append(torch.cuda.Stream(dev))
+total = (1000 // NS) * 30 * NS
 
 
 def run(concurrent, steps=6):
@@ -33,13 +35,13 @@ def run(concurrent, steps=6):
         for i in range(NS):
             if concurrent:
                 with torch.cuda.stream(streams[i]):
-                    sc[i].score_prepared(prep[i])
+                    sc[i].score_prepared(bench.prepare(sc[i], name, feed[i]))
             else:
-                sc[i].score_prepared(prep[i])
+                sc[i].score_prepared(bench.prepare(sc[i], name, feed[i]))
     torch.cuda.synchronize()
-    return steps * (1000 // NS) * 30 * NS / (time.perf_counter() - t0)
+    return steps * total / (time.perf_counter() - t0)
 
 
 run(False, 2); run(True, 2)
 for _ in range(2):
-    print("%s: sequential %.0f pairs/s | %d streams %.0f pairs/s" % (name, run(False), NS, run(True)), flush=True)
+    print("%s grid %s: sequential %.0f pairs/s | %d streams %.0f pairs/s" % (name, os.environ.get("MMS_PP_GRID", "all"), run(False), NS, run(True)), flush=True)
