@@ -59,3 +59,41 @@ def test_missing_library_is_an_error(monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libmmscore.so")
     with pytest.raises(lib.MmsError):
         lib.load()
+
+
+def test_ctypes_structs_match_the_c_header_layout(tmp_path):
+    """include/mmscore.h is plain C: compile it with gcc, print sizeof / offsetof of every struct the binding mirrors, and compare
+    with the ctypes Structures of lib.py -- a drifted field order or type would otherwise only show up as garbage on a GPU."""
+    import re
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = open(os.path.join(ROOT, "include", "mmscore.h")).read()
+    src_nc = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    pairs = {"mms_config": lib.Config, "mms_zk_batch": lib.ZkBatch, "mms_lds_batch": lib.LdsBatch, "mms_lxmert_batch": lib.LxmertBatch,
+             "mms_ensemble_batch": lib.EnsembleBatch}
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "mmscore.h"', 'int main(void) {']
+    fields = {}
+    for cname in pairs:
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src_nc, flags=re.S).group(1)
+        names = re.findall(r"([A-Za-z_0-9]+)\s*;", body)
+        fields[cname] = names
+        prog.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for n in names:
+            prog.append('printf(" %s:%%zu", offsetof(%s, %s));' % (n, cname, n))
+        prog.append('printf("\\n");')
+    prog += ["return 0; }"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).splitlines()
+    for line in out:
+        toks = line.split()
+        cname, size = toks[0], int(toks[1])
+        st = pairs[cname]
+        assert ctypes.sizeof(st) == size, (cname, ctypes.sizeof(st), size)
+        py = [(n, getattr(st, n).offset) for n, _ in st._fields_]
+        cc = [(t.split(":")[0], int(t.split(":")[1])) for t in toks[2:]]
+        assert py == cc, (cname, py, cc)
