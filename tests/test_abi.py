@@ -97,3 +97,42 @@ def test_ctypes_structs_match_the_c_header_layout(tmp_path):
         py = [(n, getattr(st, n).offset) for n, _ in st._fields_]
         cc = [(t.split(":")[0], int(t.split(":")[1])) for t in toks[2:]]
         assert py == cc, (cname, py, cc)
+
+
+def test_c_host_links_and_calls_the_library(tmp_path):
+    """The C / C++ host of INTEGRATION.md: compiles against include/mmscore.h with plain gcc, links libmmscore.so, and gets the
+    documented error behaviour (status code + message, nothing thrown across the ABI) without a GPU."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    csrc = os.path.dirname(lib.LIB_PATH)
+    c = tmp_path / "host.c"
+    c.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "mmscore.h"
+int main(void) {
+    mms_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.model = 9; cfg.layers = 12; cfg.vocab = 21128; cfg.inter = 3072; cfg.max_pos = 512; cfg.type_vocab = 2; cfg.text_len = 20; cfg.precision = 2;
+    mms_handle* h = 0;
+    int rc = mms_create(&cfg, &h);
+    printf("version %d rc %d msg %s\n", mms_version(), rc, mms_global_error());
+    cfg.model = MMS_MODEL_LDS; cfg.text_len = 31;                 /* 51-token sequences: beyond the attention kernels */
+    rc = mms_create(&cfg, &h);
+    printf("rc %d msg %s\n", rc, mms_global_error());
+    mms_ensemble_batch b; memset(&b, 0, sizeof b);
+    printf("ensemble(null handles) rc %d\n", mms_score_ensemble(0, 0, 0, &b, 0, 0, 0, 0));
+    return 0;
+}
+''')
+    exe = tmp_path / "host"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe), "-L", csrc,
+                           "-lmmscore", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[0].startswith("version 1 rc 1") and "model" in lines[0]
+    assert lines[1].startswith("rc 1") and "48-token" in lines[1]
+    assert lines[2].endswith("rc 1")
