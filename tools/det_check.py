@@ -1,5 +1,6 @@
+"""Lab book: are repeated runs bit-identical in every precision / packing / LayerNorm-fusion combination?  (lds, GPU box)"""
 import sys, os, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd import scorers, synth, weights
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd.config import LdsConfig
 cfg = LdsConfig(layers=2)

@@ -1,5 +1,6 @@
-import ctypes as C, sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+"""Lab book: error of the LayerNorm-fused GEMM (mms_dbg_gemm_ln) and of the two-kernel route against an fp64 LayerNorm (GPU box)."""
+import ctypes as C, os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd import lib, weights
 l = lib.load()
 def run(M, K, rscale, rmean, seed=1):
