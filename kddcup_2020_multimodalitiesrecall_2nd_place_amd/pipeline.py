@@ -38,6 +38,25 @@ def predict_tsv(scorer, tsv_lines, label_table, tokenizer, out_path, sen2forest:
     return qid, pid, score
 
 
+def kdd_predict(scorer, tsv_lines, label_table, tokenizer, save_path=None, batch_pairs: int = 8192):
+    """``KDD.predict(mod, save)`` of the lxmert sub-model (code/lxmert/src/tasks/kdd_model.py:46-129) over already-read TSV lines:
+    returns ``(match_pred, match_label, rank_score_pred)`` -- the arg-max class per pair (``:112``), the fed target (1 for every
+    row, kdd_data.py:74) and ``{query_id: [(product_id, softmax(logit)[-1]), ...]}`` (``:107-110``) -- and with ``save_path``
+    writes the ``query-id,product-id,score`` CSV of ``:114-128`` grouped by query in first-seen order like the reference's dict walk."""
+    import collections
+    records = [F.read_line(l, label_table, tokenizer) for l in tsv_lines if l.strip() and "product_id" not in l]
+    qid, pid, score = score_records(scorer, records, batch_pairs)
+    match_pred = [int(s > 0.5) for s in score]           # argmax of a two-class softmax
+    match_label = [1] * len(records)
+    rank_score_pred = collections.defaultdict(list)
+    for q, p, s in zip(qid, pid, score):
+        rank_score_pred[int(q)].append((int(p), float(s)))
+    if save_path is not None:
+        rows = [(q, p, s) for q, items in rank_score_pred.items() for p, s in items]
+        scorefile.write_score_csv(save_path, [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows])
+    return match_pred, match_label, rank_score_pred
+
+
 def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: bool = False, batch_pairs: int = 32768, threads: int = 0):
     """TSV file -> (query_id, product_id, score) with the three stages overlapped:
 

@@ -242,6 +242,15 @@ def test_tsv_to_score_file_pipeline(tmp_path):
         s = scorers.make_scorer(cfg, w)
         out = tmp_path / ("scores_%s" % name + (".csv" if name == "lxmert" else ".txt"))
         qid, pid, score = pipeline.predict_tsv(s, ["product_id\tfoo"] + lines, table, tok, str(out), batch_pairs=3)
+        if name == "lxmert":     # the KDD.predict-shaped driver: same scores, grouped by query, CSV in the reference's dict order
+            mp, ml, rsp = pipeline.kdd_predict(s, ["product_id\tfoo"] + lines, table, tok, str(tmp_path / "kdd.csv"), batch_pairs=4)
+            assert ml == [1] * len(lines) and mp == [int(x > 0.5) for x in score]
+            assert sum(len(v) for v in rsp.values()) == len(lines)
+            for q, p_, sc in zip(qid, pid, score):
+                assert abs(dict(rsp[int(q)])[int(p_)] - sc) < 1e-6
+            a_, b_ = scorefile.read_scores(str(tmp_path / "kdd.csv")), scorefile.read_scores(str(out))
+            assert {q: set(v) for q, v in a_.items()} == {q: set(v) for q, v in b_.items()}
+            assert all(abs(a_[q][p_] - b_[q][p_]) < 1e-6 for q in a_ for p_ in a_[q])
         s.close()
         recs = [F.read_line(l, table, tok) for l in lines]
         b = (F.zk_batch if name == "zk" else F.lxmert_batch)(recs, cfg.text_len)
