@@ -709,6 +709,16 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     return MMS_OK;
 }
 
+#ifdef MMS_LAB
+// lab experiment (MMS_FFN_BLOCK=rows): FFN-up / FFN-down in row blocks that reuse ONE intermediate buffer of `rows` x inter, so the
+// 12 KB / row intermediate could stay inside the 256 MB Infinity Cache instead of streaming through HBM
+__global__ void k_block_counts(const int* rows, int blk, int nb, int* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) { const long long r = (long long)*rows - (long long)i * blk; out[i] = r < 0 ? 0 : r > blk ? blk : (int)r; }
+}
+static int* g_blk_counts = nullptr;
+#endif
+
 // feed-forward sub-layer: out = LN(dense(act(dense(in))) + in)      (pixelbert.py:969-985, modeling.py:395-420)
 int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes out, int64_t row0, int64_t M, int act,
               const Pack& pk = Pack()) {
@@ -723,6 +733,25 @@ int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes ou
         ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
         return MMS_OK;
     }
+#ifdef MMS_LAB
+    static const long blk = getenv("MMS_FFN_BLOCK") ? atol(getenv("MMS_FFN_BLOCK")) : 0;
+    static const long blk_live = getenv("MMS_FFN_LIVE") ? atol(getenv("MMS_FFN_LIVE")) : 0;     // host-side hint: skip blocks past this row
+    if (blk > 0 && M > blk && !h->fuse_ln) {
+        const int nb = (int)((M + blk - 1) / blk);
+        if (!g_blk_counts) HIP_TRY(h, hipMalloc((void**)&g_blk_counts, 4096 * 4));
+        if (pk.rows) k_block_counts<<<(nb + 255) / 256, 256, 0, st>>>(pk.rows, (int)blk, nb, g_blk_counts);
+        for (int i = 0; i < nb; ++i) {
+            const int64_t r0 = (int64_t)i * blk, Mi = std::min<int64_t>(blk, M - r0);
+            if (blk_live && r0 >= blk_live) break;
+            const int* md = pk.rows ? g_blk_counts + i : nullptr;
+            const Planes rs = in.at((row0 + r0) * H);
+            if (int rc = gemm(h, st, in.at((row0 + r0) * H), H, ID, w.wi, w.bi, Mi, I, H, act, to_planes(h->mid, I), nullptr, md, nullptr, ID, nullptr, 4)) return rc;
+            if (int rc = gemm(h, st, h->mid, I, ID, w.wd, w.bd, Mi, H, I, ACT_NONE, to_f32(h->t + (row0 + r0) * H, H), &rs, md, nullptr, ID, nullptr, 8)) return rc;
+        }
+        ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
+        return MMS_OK;
+    }
+#endif
     if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I), nullptr, pk.rows, nullptr, ID, nullptr, 4)) return rc;
     if (int rc = gemm_ln(h, st, false, h->mid, I, w.wd, w.wd8, w.wds, w.bd, M, I, resid, w.g, w.b, out.at(row0 * H), h->t + row0 * H, pk.rows, &fused)) return rc;
     if (fused) return MMS_OK;
