@@ -39,11 +39,14 @@ namespace {
 __device__ __forceinline__ int pp_swz(int r) { return (4 - ((r >> 2) & 3)) & 3; }
 
 template <int N> __device__ __forceinline__ void pp_wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else static_assert(N == 0, "unsupported count");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+
+// ring depth of the single-plane instantiations (mode 1, fp8): their 32 KiB stages leave room for more than three slots
+#ifndef MMS_PP_NSLOT1
+#define MMS_PP_NSLOT1 3
+#endif
 
 __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
@@ -68,8 +71,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 256, WAVES_N = 4, NW = 8, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int PLANE = 256 * 64;                 // one operand plane of a stage: 256 rows x 32 bf16
     constexpr int SLOT = (NSPLIT + 1) * PLANE;
-    constexpr int NSLOT = 3;
+    constexpr int NSLOT = (NSPLIT == 1 && !LNF) ? MMS_PP_NSLOT1 : 3;
+    constexpr int D = NSLOT - 1;                    // stages in flight ahead of the one being consumed
     constexpr int P = 2 * (NSPLIT + 1);             // LDS-DMA pieces per wave per stage (8 KiB = 128 rows per piece)
+    static_assert(NSLOT >= 3 && NSLOT * SLOT <= 160 * 1024 && (D - 1) * P < 64, "ring must fit the LDS and the vmcnt counter");
     constexpr int EPI_BYTES = NW * 16 * (TN + 4) * 4;
     static_assert(NSLOT * SLOT >= EPI_BYTES, "epilogue strip must fit in the ring");
     __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * SLOT];
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     };
 
     f32x4 acc[FM][FN];
+    const int ns = p.K / 32;   // >= 2 (K % 64 == 0)
 
     // fragment read offsets inside a slot (lane part; the rest are immediates)
     const int fr = lane & 15, fk = lane >> 4;
@@ -175,21 +181,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         __builtin_amdgcn_s_setprio(0);
     };
 
-    const int ns = p.K / 32;   // >= 2 (K % 64 == 0)
     // PRE: stage s+2 exists and is issued during this stage; WAITN: outstanding pieces allowed at the phase-4 wait
     auto stage = [&](auto pre_tag, auto wait_tag, int s, int slot) {
         constexpr bool PRE = decltype(pre_tag)::value;
         constexpr int WAITN = decltype(wait_tag)::value;
         const unsigned char* sb = smem + slot * SLOT;
-        const int nslot = slot == 0 ? 2 : slot - 1;     // (slot + 2) % 3
+        const int nslot = slot == 0 ? NSLOT - 1 : slot - 1;     // (slot + D) % NSLOT: the slot stage s-1 just left
         constexpr bool DMA = PRE && !(DIAG & 2), RD = !(DIAG & 4);
         auto bar = [&]() { if (DIAG & 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } else pp_barrier(); };
-        // LDS-DMA pieces of stage s+2: two per phase in phases 1-3 (other placements measured no better, profiles/r01c_gemm_variants.txt)
+        // LDS-DMA pieces of stage s+D: two per phase in phases 1-3 (other placements measured no better, profiles/r01c_gemm_variants.txt)
         auto dma = [&](int ph) {
             if (!DMA) return;
 #pragma unroll
             for (int q = 0; q < P; ++q)
-                if (q / 2 == ph) issue(q, s + 2, nslot);
+                if (q / 2 == ph) issue(q, s + D, nslot);
         };
         // phase 1: (A0, B0)
         if (RD) { read_b(sb, 0, b0); read_a(sb, 0); }
@@ -217,12 +222,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         bar();
     };
 
-    // prologue: stages 0 and 1 in flight, stage 0 landed
+    // prologue: stages 0 .. D-1 in flight (fewer when K is that short), stage 0 landed
+    const int pre = ns < D ? ns : D;
+    auto first_stages = [&]() {
 #pragma unroll
-    for (int q = 0; q < P; ++q) issue(q, 0, 0);
+        for (int d = 0; d < D; ++d)
+            if (d < pre) {
 #pragma unroll
-    for (int q = 0; q < P; ++q) issue(q, 1, 1);
-    pp_wait_vmcnt<P>();
+                for (int q = 0; q < P; ++q) issue(q, d, d);
+            }
+    };
+    first_stages();
+    if constexpr (D == 2) pp_wait_vmcnt<P>();
+    else {
+        if (pre == D) pp_wait_vmcnt<(D - 1) * P>();
+        else if (pre == 3) pp_wait_vmcnt<2 * P>();
+        else pp_wait_vmcnt<P>();               // pre == 2 (K % 64 == 0: never fewer than two stages)
+    }
     pp_barrier();
     if (wm == 1) pp_barrier();     // stagger the second wave row by one barrier
     const unsigned long long tr1 = (DIAG & 32) ? wall_clock64() : 0;
@@ -291,13 +307,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         int slot = 0, s = 0;
-        for (; s + 2 < ns; ++s) {
-            stage(std::true_type{}, std::integral_constant<int, P>{}, s, slot);
-            slot = slot == 2 ? 0 : slot + 1;
+        for (; s + D < ns; ++s) {
+            stage(std::true_type{}, std::integral_constant<int, (D - 1) * P>{}, s, slot);
+            slot = slot == NSLOT - 1 ? 0 : slot + 1;
         }
-        stage(std::false_type{}, std::integral_constant<int, 0>{}, s, slot);          // stage ns-2: wait for everything
-        slot = slot == 2 ? 0 : slot + 1;
-        stage(std::false_type{}, std::integral_constant<int, -1>{}, s + 1, slot);     // stage ns-1: nothing in flight
+        // tail: R stages still to come after this one -> R-1 of them may stay in flight; the last stage waits for nothing
+        auto tail = [&](auto r_tag) {
+            constexpr int R = decltype(r_tag)::value;
+            if (ns - 1 - s == R) {
+                stage(std::false_type{}, std::integral_constant<int, R >= 1 ? (R - 1) * P : -1>{}, s, slot);
+                slot = slot == NSLOT - 1 ? 0 : slot + 1;
+                ++s;
+            }
+        };
+        if constexpr (D >= 4) tail(std::integral_constant<int, 3>{});
+        if constexpr (D >= 3) tail(std::integral_constant<int, 2>{});
+        tail(std::integral_constant<int, 1>{});
+        tail(std::integral_constant<int, 0>{});
         if (wm == 0) pp_barrier();     // re-align the wave rows: nobody reads the ring any more
         const unsigned long long tr2 = (DIAG & 32) ? wall_clock64() : 0;
 
@@ -321,10 +347,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         if (more) {
             vb = nvb;
             setup(vb);
-#pragma unroll
-            for (int q = 0; q < P; ++q) issue(q, 0, 0);
-#pragma unroll
-            for (int q = 0; q < P; ++q) issue(q, 1, 1);
+            first_stages();
         }
         if constexpr (LNF) {
 #ifdef MMS_LAB
