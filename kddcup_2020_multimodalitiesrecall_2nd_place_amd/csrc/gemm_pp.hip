@@ -47,6 +47,11 @@ template <int N> __device__ __forceinline__ void pp_wait_vmcnt() {
 #ifndef MMS_PP_NSLOT1
 #define MMS_PP_NSLOT1 3
 #endif
+// wave grid: 8 waves as (8 / WN)(M) x WN(N).  WN = 4: 128 x 64 outputs per wave; WN = 2: 64 x 128 (with two A planes the A fragments
+// are the expensive ones: 4 x 2 + 8 = 16 ds_read_b128 per stage and wave instead of 8 x 2 + 4 = 20)
+#ifndef MMS_PP_WN
+#define MMS_PP_WN 4
+#endif
 
 __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
@@ -68,7 +73,8 @@ template <int NSPLIT, int ACT, int DIAG, bool PERSIST, bool F8 = false, bool LNF
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     static_assert(!F8 || NSPLIT == 1, "fp8 operands are single-plane");
     static_assert(!LNF || (PERSIST && ACT == ACT_NONE && DIAG == 0), "the LayerNorm epilogue belongs to the persistent, activation-free kernel");
-    constexpr int BM = 256, BN = 256, WAVES_N = 4, NW = 8, TM = 128, TN = 64, FM = 8, FN = 4;
+    constexpr int BM = 256, BN = 256, NW = 8, WAVES_N = LNF ? 4 : MMS_PP_WN, WAVES_M = NW / WAVES_N;
+    constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, FM = TM / 16, FN = TN / 16, HM = FM / 2, HN = FN / 2;     // HM x HN fragments per phase
     constexpr int PLANE = 256 * 64;                 // one operand plane of a stage: 256 rows x 32 bf16
     constexpr int SLOT = (NSPLIT + 1) * PLANE;
     constexpr int NSLOT = (NSPLIT == 1 && !LNF) ? MMS_PP_NSLOT1 : 3;
@@ -147,36 +153,36 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     const int laneA = (wm * TM + fr) * 64 + ((fk ^ pp_swz(fr)) << 4);
     const int laneB = NSPLIT * PLANE + (wn * TN + fr) * 64 + ((fk ^ pp_swz(fr)) << 4);
 
-    bf16x8 a[NSPLIT][4], b0[2], b1[2];
+    bf16x8 a[NSPLIT][HM], b0[HN], b1[HN];
     auto read_a = [&](const unsigned char* sb, int mh) {
 #pragma unroll
         for (int pl = 0; pl < NSPLIT; ++pl)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(sb + laneA + pl * PLANE + (mh * 64 + i * 16) * 64);
+            for (int i = 0; i < HM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(sb + laneA + pl * PLANE + (mh * (TM / 2) + i * 16) * 64);
     };
-    auto read_b = [&](const unsigned char* sb, int nh, bf16x8 (&b)[2]) {
+    auto read_b = [&](const unsigned char* sb, int nh, bf16x8 (&b)[HN]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + laneB + (nh * 32 + j * 16) * 64);
+        for (int j = 0; j < HN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + laneB + (nh * (TN / 2) + j * 16) * 64);
     };
     // M section: quadrant (mh, nh); hi-plane MFMAs first, then lo (dependent pairs 8 MFMAs apart).  The operands are SWAPPED
     // (W fragment first): each 16x16 result then sits transposed in the lane -- lane l holds row l&15, columns 4*(l>>4)..+3 --
     // so the epilogue stores float4s straight from the accumulators, no LDS transposition (pp_epilogue below).
-    auto mma = [&](int mh, int nh, const bf16x8 (&b)[2]) {
+    auto mma = [&](int mh, int nh, const bf16x8 (&b)[HN]) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int pl = 0; pl < NSPLIT; ++pl)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < HM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < HN; ++j) {
                     if constexpr (F8) {
                         typedef __attribute__((ext_vector_type(2))) long i64x2;
                         const i64x2 bw = __builtin_bit_cast(i64x2, b[j]), aw = __builtin_bit_cast(i64x2, a[pl][i]);
-                        acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bw[0], aw[0], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
-                        acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bw[1], aw[1], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+                        acc[mh * HM + i][nh * HN + j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bw[0], aw[0], acc[mh * HM + i][nh * HN + j], 0, 0, 0);
+                        acc[mh * HM + i][nh * HN + j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bw[1], aw[1], acc[mh * HM + i][nh * HN + j], 0, 0, 0);
                     } else
-                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[pl][i], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);   // swapped: C^T fragment
+                    acc[mh * HM + i][nh * HN + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[pl][i], acc[mh * HM + i][nh * HN + j], 0, 0, 0);   // swapped: C^T fragment
                 }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         else pp_wait_vmcnt<P>();               // pre == 2 (K % 64 == 0: never fewer than two stages)
     }
     pp_barrier();
-    if (wm == 1) pp_barrier();     // stagger the second wave row by one barrier
+    if (wave >= NW / 2) pp_barrier();     // stagger the second half of the waves (one of each half per SIMD) by one barrier
     const unsigned long long tr1 = (DIAG & 32) ? wall_clock64() : 0;
 
     if (DIAG & 4) { read_b(smem, 0, b0); read_b(smem, 1, b1); read_a(smem, 0); }
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         // (32 registers of bf16 in flight): with two bursts in flight the kernel spills, and ANY scratch use costs far more than it
         // saves (ROCr hands out scratch of this size per dispatch: the first persistent round took 450 us instead of 66).  The read is
         // bandwidth-bound anyway: all CUs reach the tile boundary together and pull 63 MB of residual per round.
-        constexpr int RB = 4;
+        constexpr int RB = 16 / FN;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
             const bf16* src = pl ? p.r_lo : p.r_hi;
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         if constexpr (D >= 3) tail(std::integral_constant<int, 2>{});
         tail(std::integral_constant<int, 1>{});
         tail(std::integral_constant<int, 0>{});
-        if (wm == 0) pp_barrier();     // re-align the wave rows: nobody reads the ring any more
+        if (wave < NW / 2) pp_barrier();     // re-align the two halves: nobody reads the ring any more
         const unsigned long long tr2 = (DIAG & 32) ? wall_clock64() : 0;
 
         if (DIAG & 16) {   // no epilogue (keep the accumulators live)
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         if constexpr (LNF) { if (ln_decided == 1) load_resid(); }
         pp_wait_vmcnt<0>();
         pp_barrier();
-        if (wm == 1) pp_barrier();     // stagger again
+        if (wave >= NW / 2) pp_barrier();     // stagger again
     }
 }
 

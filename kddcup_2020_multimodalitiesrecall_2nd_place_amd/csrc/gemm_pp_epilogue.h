@@ -58,14 +58,16 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
             for (int j = 0; j < FN; ++j) acc[i][j] += bias4[j];
         }
         if (f32_out) {
-            float* dst = p.hm_rows ? p.c_f32 + ((long long)((p.hm_col0 + col0) >> 6) * p.hm_rows + orow) * 64 + nq * 4   // the wave's 64 columns = one head
+            // head-major: every 64 columns (4 fragments) of the wave are one head's block [rows][64]
+            float* dst = p.hm_rows ? p.c_f32 + ((long long)((p.hm_col0 + col0) >> 6) * p.hm_rows + orow) * 64 + nq * 4
                                    : p.c_f32 + orow * p.ldc + col;
+            const long long head_step = p.hm_rows ? (long long)p.hm_rows * 64 - 64 : 0;     // on top of the 64 columns themselves
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 f32x4 v = acc[i][j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT);
-                *reinterpret_cast<f32x4*>(dst + 16 * j) = v;
+                *reinterpret_cast<f32x4*>(dst + 16 * j + (j >> 2) * head_step) = v;
             }
         } else if (p.out_kind == OUT_F8) {
             unsigned char* d8 = p.c_f8 + orow * p.ldf8 + col;
