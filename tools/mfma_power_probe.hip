@@ -12,7 +12,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int SHAPE>
+template <int SHAPE, int SLEEP = 0>
 __global__ __launch_bounds__(512) void k_probe(const bf16x8* __restrict__ src, float* __restrict__ sink, int iters) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bf16x8 a[8], b[4];
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(512) void k_probe(const bf16x8* __restrict__ src, f
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            if constexpr (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);      // duty-cycle probe: 64 x SLEEP idle cycles per 32 MFMAs
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -102,6 +103,32 @@ int main() {
                 printf("%-58s grid %3d  mfma %dx%d  %8.2f ms  %7.1f TFLOP/s\n", names[data], grid, shape, shape, ms, fl / (ms * 1e-3) / 1e12);
             }
         }
+    }
+    // duty cycle: the same random operands, every wave sleeping 64 x SLEEP cycles after each burst of 32 MFMAs (2 waves per SIMD:
+    // a burst pair keeps the pipe busy for 1024 cycles).  rate / 2049 against the duty tells whether the clock comes back up.
+    {
+        unsigned s2 = 12345u;
+        for (size_t i = 0; i < n; ++i) {
+            s2 = s2 * 1664525u + 1013904223u;
+            h[i] = (unsigned short)(((s2 >> 31) << 15) | ((125 + ((s2 >> 20) & 3)) << 7) | ((s2 >> 9) & 0x7f));
+        }
+        (void)hipMemcpy(src, h.data(), n * 2, hipMemcpyHostToDevice);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        const int it2 = 100000;
+        auto go = [&](auto kern, int sleep) {
+            float ms = 0.f;
+            for (int rep = 0; rep < 2; ++rep) {
+                (void)hipEventRecord(e0, 0);
+                hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, src, sink, it2);
+                (void)hipEventRecord(e1, 0);
+                (void)hipEventSynchronize(e1);
+                (void)hipEventElapsedTime(&ms, e0, e1);
+            }
+            const double fl = 524288.0 * it2 * 8.0 * 256;
+            printf("random bf16, grid 256, 16x16x32, s_sleep %2d after every 32 MFMAs: %8.2f ms  %7.1f TFLOP/s\n", sleep, ms, fl / (ms * 1e-3) / 1e12);
+        };
+        go(k_probe<16, 0>, 0); go(k_probe<16, 2>, 2); go(k_probe<16, 4>, 4); go(k_probe<16, 8>, 8); go(k_probe<16, 16>, 16); go(k_probe<16, 32>, 32);
     }
     return 0;
 }
