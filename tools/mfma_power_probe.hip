@@ -86,14 +86,17 @@ int main() {
     bf16x8* src; float* sink;
     (void)hipMalloc((void**)&src, n * 2); (void)hipMalloc((void**)&sink, 4096);
     const int iters = 400000;              // ~0.2 s per launch at full rate
-    const char* names[3] = {"zeros", "gaussian-like bf16 (|x| ~ 1, random mantissas)", "hi/lo mix: even fragments O(1), odd fragments O(2^-9)"};
-    for (int data = 0; data < 3; ++data) {
+    const char* names[5] = {"zeros", "gaussian-like bf16 (|x| ~ 1, random mantissas)", "hi/lo mix: even fragments O(1), odd fragments O(2^-9)",
+                            "hi/lo mix, lo mantissas cut to their top 3 bits", "hi/lo mix, lo fragments zero"};
+    for (int data = 0; data < 5; ++data) {
         unsigned s = 12345u;
         for (size_t i = 0; i < n; ++i) {
             s = s * 1664525u + 1013904223u;
             const unsigned m = (s >> 9) & 0x7f, sg = (s >> 31) << 15, e = 125 + ((s >> 20) & 3);       // exponents 2^-2 .. 2^1
-            const bool lo = data == 2 && ((i / (64 * 8)) & 1);
+            const bool lo = data >= 2 && ((i / (64 * 8)) & 1);
             h[i] = data == 0 ? 0 : (unsigned short)(sg | ((lo ? e - 9 : e) << 7) | m);
+            if (lo && data == 3) h[i] &= 0xfff0;
+            if (lo && data == 4) h[i] = 0;
         }
         (void)hipMemcpy(src, h.data(), n * 2, hipMemcpyHostToDevice);
         for (int grid : {256, 128}) {
