@@ -22,6 +22,10 @@
 // (= everything but the stage just issued), so one full stage stays in flight across every barrier.
 // RAW: the wait sits before phase 4's first barrier and the first read of that data is in the next phase (one
 // barrier later for the staggered wave row).  WAR: a slot is refilled >= 2 phases after its last ds_read.
+//
+// Two shape parameters are compile-time (both measured, profiles/r02f_*; the defaults are what ships): MMS_PP_NSLOT1, the ring depth
+// of the single-plane instantiations whose 32 KiB stages leave room for 4 or 5 slots (D = slots - 1 stages in flight; not faster),
+// and MMS_PP_WN, the wave grid (4: as above; 2: 4(M) x 2(N), 64x128 outputs per wave, 16 instead of 20 ds_read_b128 per stage; equal).
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
