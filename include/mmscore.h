@@ -146,6 +146,11 @@ typedef struct mms_ensemble_batch {
     const int32_t* lx_input_mask;  /* [B,lxmert.text_len] */
 } mms_ensemble_batch;
 
+/* ABI revision of the structs and entry points declared in this header.  It changes whenever a struct gains a field or an entry
+ * point changes its signature (r1: 1; r2 added mms_config.fuse_layernorm, mms_zk_batch.label_ids, mms_lxmert_batch.label_ids / x_norm
+ * without bumping it; r3: 3).  A caller built against another revision would make the library read past its structs, so compare
+ * BEFORE the first mms_create:  if (mms_version() != MMS_ABI_VERSION) abort();   (lib.py's load() does) */
+#define MMS_ABI_VERSION 3
 int mms_version(void);
 const char* mms_global_error(void);              /* message of the last failing mms_create */
 

@@ -26,7 +26,9 @@ struct Planes {
     bf16* hi = nullptr;
     bf16* lo = nullptr;
     unsigned char* f8 = nullptr;   // precision mode 4: the same activation as e4m3 bytes (the fp8 GEMMs' A operand)
-    Planes at(long long elem_off) const { Planes p; p.hi = hi + elem_off; p.lo = lo + elem_off; p.f8 = f8 ? f8 + elem_off : nullptr; return p; }
+    // hl32 layout (common.h): hi and lo are ONE buffer of alternating 32-element blocks (lo == hi + 32); a LOGICAL element offset that is
+    // a multiple of 32 (row offsets: every leading dimension is) is twice as far in the buffer
+    Planes at(long long elem_off) const { Planes p; p.hi = hi + 2 * elem_off; p.lo = lo + 2 * elem_off; p.f8 = f8 ? f8 + elem_off : nullptr; return p; }
 };
 
 // *8 / *s: e4m3 copy of the matrix and its per-output-channel scales (precision mode 4 only)
@@ -193,7 +195,11 @@ struct MatSrc { const float* p; int64_t n; bool in_out; };
 int upload_mat(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, bf16** out) {
     int64_t N = 0;
     for (auto& s : srcs) N += s.n;
-    // precision mode 3 keeps a second plane lo = bf16(w - bf16(w)) right behind the hi plane
+    // Stored as 16-row x 32-column tiles of 1 KiB (wtile_off, common.h): what one LDS-DMA piece of the GEMM engines fetches.  A row offset
+    // that is a multiple of 16 is n * K elements into the buffer, as in a row-major matrix, so sub-matrix pointers (the K | V rows of a
+    // fused [Q | K | V] matrix) are formed as before.
+    // precision mode 3 keeps a second (tiled) plane lo = bf16(w - bf16(w)) right behind the hi plane
+    if (N % 16 || K % 32) return h->fail(MMS_ERR_WEIGHT, "GEMM weight matrix must have N % 16 == 0 and K % 32 == 0");
     const bool with_lo = h->nsplit == 3;
     std::vector<uint16_t> buf((size_t)(N * K) * (with_lo ? 2 : 1));
     int64_t r0 = 0;
@@ -202,10 +208,11 @@ int upload_mat(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, bf16**
             for (int64_t k = 0; k < K; ++k) {
                 const float w = s.in_out ? s.p[k * s.n + n] : s.p[n * K + k];
                 const uint16_t hi = f2bf(w);
-                buf[(size_t)((r0 + n) * K + k)] = hi;
+                const size_t at = (size_t)wtile_off(r0 + n, k, K);
+                buf[at] = hi;
                 if (with_lo) {
                     uint32_t u = (uint32_t)hi << 16; float hf; std::memcpy(&hf, &u, 4);
-                    buf[(size_t)(N * K + (r0 + n) * K + k)] = f2bf(w - hf);
+                    buf[(size_t)(N * K) + at] = f2bf(w - hf);
                 }
             }
         r0 += s.n;
@@ -415,7 +422,7 @@ int alloc_planes(mms_handle* h, std::vector<void*>& pool, Planes* p, int64_t ele
     void* q;
     if (int rc = dev_alloc(h, pool, &q, (size_t)elems * 2 * 2)) return rc;
     p->hi = (bf16*)q;
-    p->lo = p->hi + elems;
+    p->lo = p->hi + MMS_PLANE_LO;      // hl32: one buffer of 2 * elems, 32-element blocks of hi and lo alternating (common.h)
     return MMS_OK;
 }
 
@@ -691,7 +698,7 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     attn_q(a, h, row0, M); attn_kv(a, h, row0, M);
     a.q_base = 0; a.Sq = S; a.kv_base = 0; a.Sk = S;
     a.key_add = key_add;
-    a.o_hi = h->ctx.hi + row0 * H; a.o_lo = h->ctx.lo + row0 * H; a.ldo = H;
+    a.o_hi = h->ctx.at(row0 * H).hi; a.o_lo = h->ctx.at(row0 * H).lo; a.ldo = H;
     a.B = (int)B;
     a.q_off = a.kv_off = pk.off; a.q_cnt = a.kv_cnt = pk.cnt;
     if (f8) a.o_f8 = h->ctx.f8 + row0 * H;
@@ -1027,7 +1034,7 @@ int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int
         if (h->lq_store.hi) { (void)hipFree(h->lq_store.hi); h->lq_store.hi = nullptr; }
         void* p = nullptr;
         HIP_TRY(h, hipMalloc(&p, (size_t)Q * T * H * 4));
-        h->lq_store.hi = (bf16*)p; h->lq_store.lo = h->lq_store.hi + Q * T * H;
+        h->lq_store.hi = (bf16*)p; h->lq_store.lo = h->lq_store.hi + MMS_PLANE_LO;
         h->lq_store_q = Q;
     }
     if (cs > h->lq_sub) {                               // gathered inputs of one sub-batch of distinct queries
@@ -1054,7 +1061,7 @@ int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int
             if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * T, ACT_GELU_ERF, pl)) return rc;
         }
         // packed row r holds token pk_src[r] = u_local * T + t  ->  store row (u0 + u_local) * T + t
-        launch_rows_scatter(h->x.hi, h->x.lo, h->pk_src[0], h->pk_rows, (int)(n * T), h->lq_store.hi + u0 * T * H, h->lq_store.lo + u0 * T * H, st);
+        launch_rows_scatter(h->x.hi, h->x.lo, h->pk_src[0], h->pk_rows, (int)(n * T), h->lq_store.at(u0 * T * H).hi, h->lq_store.at(u0 * T * H).lo, st);
     }
     h->lq_active = true;
     return MMS_OK;
@@ -1085,12 +1092,12 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
             launch_lx_embed_lang_packed(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->pk_src[0],
                                         h->pk_rows, (int)ML, h->x.hi, h->x.lo, st);
         launch_lx_visn(xf, h->g_visn, h->be_visn, b->boxes + p0 * V * 4, 4, h->w_box, h->b_box, h->g_box, h->be_box, h->lab_feat,
-                       label_index + p0 * V, (int)h->n_labels, h->x.hi + ML * H, h->x.lo + ML * H, (int)MV, st, h->pk_src[1], h->pk_rows + 1);
+                       label_index + p0 * V, (int)h->n_labels, h->x.at(ML * H).hi, h->x.at(ML * H).lo, (int)MV, st, h->pk_src[1], h->pk_rows + 1);
     } else {
         launch_lx_masks(b->input_mask + p0 * T, b->visual_attention_mask + p0 * V, T, lang_add, visn_add, (int)n, st);
         launch_lx_embed_lang(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->x.hi, h->x.lo, (int)n, st);
         launch_lx_visn(xf, h->g_visn, h->be_visn, b->boxes + p0 * V * 4, 4, h->w_box, h->b_box, h->g_box, h->be_box, h->lab_feat,
-                       label_index + p0 * V, (int)h->n_labels, h->x.hi + ML * H, h->x.lo + ML * H, (int)MV, st);
+                       label_index + p0 * V, (int)h->n_labels, h->x.at(ML * H).hi, h->x.at(ML * H).lo, (int)MV, st);
     }
     if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, R * H, st);
     int budget = c.stop_after >= 0 ? c.stop_after : (1 << 30);
@@ -1144,7 +1151,7 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
         if (int rc = attend(h, a, st)) return rc;
         attn_q(a, h, ML, MV); a.Sq = V;                           // visn <- lang
         attn_kv(a, h, 0, ML); a.Sk = T; a.key_add = lang_add;
-        a.o_hi = h->ctx.hi + ML * H; a.o_lo = h->ctx.lo + ML * H;
+        a.o_hi = h->ctx.at(ML * H).hi; a.o_lo = h->ctx.at(ML * H).lo;
         a.q_off = pv.off; a.q_cnt = pv.cnt; a.kv_off = pl.off; a.kv_cnt = pl.cnt;
         if (int rc = attend(h, a, st)) return rc;
         if (c.pack_tokens) {
@@ -1189,7 +1196,7 @@ int chunk_size(const mms_handle* h, int64_t B) {
 // ================================================================================================
 extern "C" {
 
-int mms_version(void) { return 1; }
+int mms_version(void) { return MMS_ABI_VERSION; }
 const char* mms_global_error(void) { return g_err.c_str(); }
 const char* mms_last_error(const mms_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -1540,30 +1547,30 @@ static int dbg_fail(const char* m) { g_err = m; return MMS_ERR_HIP; }
 
 int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const float* w_f32_nk, int64_t N, const float* bias,
                  const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes, float* c_f32, void* stream) {
-    if (!a_f32 || !w_f32_nk || !c_f32 || M <= 0 || N % 128 || K % 64 || lda < K || lda % 8) { g_err = "mms_dbg_gemm: bad argument"; return MMS_ERR_ARG; }
+    if (!a_f32 || !w_f32_nk || !c_f32 || M <= 0 || N % 128 || K % 64 || lda < K || lda % 32) { g_err = "mms_dbg_gemm: bad argument"; return MMS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     bf16 *ap = nullptr, *wp = nullptr, *rp = nullptr, *cp = nullptr;
     float* wtmp = nullptr;
     DBG_TRY(hipMalloc((void**)&ap, (size_t)M * lda * 4));
     DBG_TRY(hipMalloc((void**)&wp, (size_t)N * K * 4));
-    launch_split_f32(a_f32, ap, ap + M * lda, M * lda, st);
-    launch_split_f32(w_f32_nk, wp, wp + N * K, N * K, st);  // hi plane == RNE bf16 of the weights
+    launch_split_f32(a_f32, ap, ap + MMS_PLANE_LO, M * lda, st);
+    launch_tile_weights(w_f32_nk, wp, wp + N * K, N, K, st);  // hi plane == RNE bf16 of the weights (tiled), lo plane behind it
     GemmParams p{};
-    p.a_hi = ap; p.a_lo = ap + M * lda; p.lda = (int)lda; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
+    p.a_hi = ap; p.a_lo = ap + MMS_PLANE_LO; p.lda = (int)lda; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
     p.w = wp; p.w_lo = wp + N * K; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
     if (resid_f32) {
         DBG_TRY(hipMalloc((void**)&rp, (size_t)M * N * 4));
-        launch_split_f32(resid_f32, rp, rp + M * N, M * N, st);
-        p.r_hi = rp; p.r_lo = rp + M * N; p.ldr = (int)N;
+        launch_split_f32(resid_f32, rp, rp + MMS_PLANE_LO, M * N, st);
+        p.r_hi = rp; p.r_lo = rp + MMS_PLANE_LO; p.ldr = (int)N;
     }
     if (out_planes) {
         DBG_TRY(hipMalloc((void**)&cp, (size_t)M * N * 4));
-        p.out_kind = OUT_PLANES; p.c_hi = cp; p.c_lo = cp + M * N; p.ldp = (int)N;
+        p.out_kind = OUT_PLANES; p.c_hi = cp; p.c_lo = cp + MMS_PLANE_LO; p.ldp = (int)N;
     } else {
         p.out_kind = OUT_F32; p.c_f32 = c_f32; p.ldc = (int)N;
     }
     launch_gemm(p, nsplit, st);
-    if (out_planes) launch_planes_to_f32(cp, cp + M * N, c_f32, M * N, st);
+    if (out_planes) launch_planes_to_f32(cp, cp + MMS_PLANE_LO, c_f32, M * N, st);
     DBG_TRY(hipStreamSynchronize(st));
     DBG_TRY(hipGetLastError());
     (void)hipFree(ap); (void)hipFree(wp); (void)hipFree(rp); (void)hipFree(cp); (void)wtmp;
@@ -1615,9 +1622,9 @@ int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32
     DBG_TRY(hipMalloc((void**)&t, (size_t)M * N * 4)); DBG_TRY(hipMalloc((void**)&stats, (size_t)(M + 256) * 48));
     DBG_TRY(hipMalloc((void**)&ctl, 8));
     DBG_TRY(hipMemsetAsync(stats, 0, (size_t)(M + 256) * 48, st)); DBG_TRY(hipMemsetAsync(ctl, 0, 8, st));
-    launch_split_f32(a_f32, ap, ap + M * K, M * K, st);
-    launch_split_f32(w_f32_nk, wp, wp + N * K, N * K, st);
-    launch_split_f32(resid_f32, rp, rp + M * N, M * N, st);
+    launch_split_f32(a_f32, ap, ap + MMS_PLANE_LO, M * K, st);
+    launch_tile_weights(w_f32_nk, wp, wp + N * K, N, K, st);
+    launch_split_f32(resid_f32, rp, rp + MMS_PLANE_LO, M * N, st);
     GemmParams p{};
     if (f8) {
         DBG_TRY(hipMalloc((void**)&a8, (size_t)M * K)); DBG_TRY(hipMalloc((void**)&w8, (size_t)N * K)); DBG_TRY(hipMalloc((void**)&ws, (size_t)N * 4));
@@ -1625,12 +1632,12 @@ int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32
         launch_quant_rows_f8(w_f32_nk, w8, ws, (int)N, (int)K, st);
         p.f8 = 1; p.a_hi = (const bf16*)a8; p.a_lo = p.a_hi; p.lda = (int)(K / 2); p.w = (const bf16*)w8; p.col_scale = ws; p.K = (int)(K / 2);
     } else {
-        p.a_hi = ap; p.a_lo = ap + M * K; p.lda = (int)K; p.w = wp; p.K = (int)K;
+        p.a_hi = ap; p.a_lo = ap + MMS_PLANE_LO; p.lda = (int)K; p.w = wp; p.K = (int)K;
     }
     p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
     p.bias = bias; p.M = (int)M; p.N = (int)N; p.act = ACT_NONE;
-    p.r_hi = rp; p.r_lo = rp + M * N; p.ldr = (int)N;
-    p.c_hi = cp; p.c_lo = cp + M * N; p.ldp = (int)N;
+    p.r_hi = rp; p.r_lo = rp + MMS_PLANE_LO; p.ldr = (int)N;
+    p.c_hi = cp; p.c_lo = cp + MMS_PLANE_LO; p.ldp = (int)N;
     p.out_kind = OUT_F32; p.c_f32 = t; p.ldc = (int)N;
     p.ln_gamma = gamma; p.ln_beta = beta; p.ln_stats = stats; p.ln_tag = 0x5EED0001u; p.ln_ctl = ctl;
 #ifdef MMS_LAB
@@ -1638,9 +1645,9 @@ int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32
 #endif
     if (!launch_gemm_pp_ln(p, 2, st)) { g_err = "mms_dbg_gemm_ln: shape not supported"; return MMS_ERR_ARG; }
     LnResid r;
-    r.hi = rp; r.lo = rp + M * N; r.ld = (int)N; r.skip = ctl + 1;
-    launch_ln_to_planes(t, (int)N, gamma, beta, cp, cp + M * N, (int)N, (int)M, st, nullptr, r);
-    launch_planes_to_f32(cp, cp + M * N, c_f32, M * N, st);
+    r.hi = rp; r.lo = rp + MMS_PLANE_LO; r.ld = (int)N; r.skip = ctl + 1;
+    launch_ln_to_planes(t, (int)N, gamma, beta, cp, cp + MMS_PLANE_LO, (int)N, (int)M, st, nullptr, r);
+    launch_planes_to_f32(cp, cp + MMS_PLANE_LO, c_f32, M * N, st);
     int ctl_h[2] = {0, 0};
     DBG_TRY(hipMemcpyAsync(ctl_h, ctl, 8, hipMemcpyDeviceToHost, st));
     DBG_TRY(hipStreamSynchronize(st));
@@ -1648,10 +1655,6 @@ int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32
     if (mode_out) *mode_out = ctl_h[1];
     for (void* q : {(void*)ap, (void*)wp, (void*)rp, (void*)cp, (void*)a8, (void*)w8, (void*)ws, (void*)t, (void*)stats, (void*)ctl}) (void)hipFree(q);
     return MMS_OK;
-}
-
-__global__ void k_mask_u16(unsigned short* p, long long n, unsigned short mask) {
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] &= mask;
 }
 
 __global__ void k_fill_random(float* p, long long n, unsigned seed) {
@@ -1686,18 +1689,14 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     if (!zero_fill) hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, wf, N * K, 2u);
     hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, rf, M * N, 3u);
     hipLaunchKernelGGL(k_fill_random, dim3(64), dim3(256), 0, 0, bias, N, 4u);
-    launch_split_f32(af, ap, ap + M * K, M * K, 0);
-    launch_split_f32(wf, wp, wp + N * K, N * K, 0);
-    launch_split_f32(rf, rp, rp + M * N, M * N, 0);
-#ifdef MMS_LAB
-    if (const char* e = getenv("MMS_GB_LOMASK"))   // power probe: zero the low mantissa bits of the A lo plane
-        hipLaunchKernelGGL(k_mask_u16, dim3(4096), dim3(256), 0, 0, (unsigned short*)(ap + M * K), M * K, (unsigned short)strtol(e, nullptr, 16));
-#endif
+    launch_split_f32(af, ap, ap + MMS_PLANE_LO, M * K, 0);
+    launch_tile_weights(wf, wp, wp + N * K, N, K, 0);
+    launch_split_f32(rf, rp, rp + MMS_PLANE_LO, M * N, 0);
     GemmParams p{};
-    p.a_hi = ap; p.a_lo = ap + M * K; p.lda = (int)K; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
+    p.a_hi = ap; p.a_lo = ap + MMS_PLANE_LO; p.lda = (int)K; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
     p.w = wp; p.w_lo = wp + N * K; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
-    if (resid) { p.r_hi = rp; p.r_lo = rp + M * N; p.ldr = (int)N; }
-    if (out_planes) { p.out_kind = OUT_PLANES; p.c_hi = cp; p.c_lo = cp + M * N; p.ldp = (int)N; }
+    if (resid) { p.r_hi = rp; p.r_lo = rp + MMS_PLANE_LO; p.ldr = (int)N; }
+    if (out_planes) { p.out_kind = OUT_PLANES; p.c_hi = cp; p.c_lo = cp + MMS_PLANE_LO; p.ldp = (int)N; }
     else { p.out_kind = OUT_F32; p.c_f32 = cf; p.ldc = (int)N; }
     const int saved = get_gemm_variant();
     set_gemm_variant(variant);
@@ -1728,9 +1727,9 @@ int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B,
     DBG_TRY(hipMalloc((void**)&op, (size_t)n * 4));
     AttnParams a{};
     a.q = q; a.ldq = H; a.k = k; a.v = v; a.ldkv = H; a.hs_q = a.hs_kv = MMS_HEAD_DIM; a.q_base = 0; a.Sq = Sq; a.kv_base = 0; a.Sk = Sk;
-    a.key_add = key_add; a.o_hi = op; a.o_lo = op + n; a.ldo = H; a.B = (int)B;
+    a.key_add = key_add; a.o_hi = op; a.o_lo = op + MMS_PLANE_LO; a.ldo = H; a.B = (int)B;
     if (!launch_attention(a, st)) { (void)hipFree(op); g_err = "mms_dbg_attention: no kernel for this (Sq, Sk)"; return MMS_ERR_ARG; }
-    launch_planes_to_f32(op, op + n, out_f32, n, st);
+    launch_planes_to_f32(op, op + MMS_PLANE_LO, out_f32, n, st);
     DBG_TRY(hipStreamSynchronize(st));
     DBG_TRY(hipGetLastError());
     (void)hipFree(op);
@@ -1743,8 +1742,8 @@ int mms_dbg_layernorm(const float* x, const float* gamma, const float* beta, int
     bf16* op = nullptr;
     const int64_t n = M * H;
     DBG_TRY(hipMalloc((void**)&op, (size_t)n * 4));
-    launch_ln_to_planes(x, H, gamma, beta, op, op + n, H, (int)M, st);
-    launch_planes_to_f32(op, op + n, out_f32, n, st);
+    launch_ln_to_planes(x, H, gamma, beta, op, op + MMS_PLANE_LO, H, (int)M, st);
+    launch_planes_to_f32(op, op + MMS_PLANE_LO, out_f32, n, st);
     DBG_TRY(hipStreamSynchronize(st));
     DBG_TRY(hipGetLastError());
     (void)hipFree(op);

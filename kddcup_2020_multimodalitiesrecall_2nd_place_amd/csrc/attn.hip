@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                 hi[dt] = a;
                 lo[dt] = c;
             }
-            *reinterpret_cast<bf16x4*>(p.o_hi + off) = hi;
-            *reinterpret_cast<bf16x4*>(p.o_lo + off) = lo;
+            *reinterpret_cast<bf16x4*>(plane_ptr(p.o_hi, off)) = hi;      // hl32 plane layout (common.h)
+            *reinterpret_cast<bf16x4*>(plane_ptr(p.o_lo, off)) = lo;
         }
 }
 

@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256) void k_rows_scatter(const bf16* s_hi, const bf
     const long long so = (long long)row * MMS_HIDDEN, d = (long long)map[row] * MMS_HIDDEN;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        *reinterpret_cast<bf16x4*>(d_hi + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_hi + so + t * 256 + lane * 4);
-        *reinterpret_cast<bf16x4*>(d_lo + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_lo + so + t * 256 + lane * 4);
+        *reinterpret_cast<bf16x4*>(plane_ptr(d_hi, d + t * 256 + lane * 4)) = *reinterpret_cast<const bf16x4*>(plane_ptr(s_hi, so + t * 256 + lane * 4));
+        *reinterpret_cast<bf16x4*>(plane_ptr(d_lo, d + t * 256 + lane * 4)) = *reinterpret_cast<const bf16x4*>(plane_ptr(s_lo, so + t * 256 + lane * 4));
     }
 }
 __global__ __launch_bounds__(256) void k_rows_pick(const bf16* s_hi, const bf16* s_lo, const int* map, const int* rows_dev, int max_rows,
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void k_rows_pick(const bf16* s_hi, const bf16*
     const long long so = (long long)map[row] * MMS_HIDDEN, d = (long long)row * MMS_HIDDEN;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        *reinterpret_cast<bf16x4*>(d_hi + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_hi + so + t * 256 + lane * 4);
-        *reinterpret_cast<bf16x4*>(d_lo + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_lo + so + t * 256 + lane * 4);
+        *reinterpret_cast<bf16x4*>(plane_ptr(d_hi, d + t * 256 + lane * 4)) = *reinterpret_cast<const bf16x4*>(plane_ptr(s_hi, so + t * 256 + lane * 4));
+        *reinterpret_cast<bf16x4*>(plane_ptr(d_lo, d + t * 256 + lane * 4)) = *reinterpret_cast<const bf16x4*>(plane_ptr(s_lo, so + t * 256 + lane * 4));
     }
 }
 __global__ __launch_bounds__(256) void k_rows_gather(const bf16* s_hi, const bf16* s_lo, const int* map, const int* idx, int T, const int* rows_dev,
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void k_rows_gather(const bf16* s_hi, const bf1
     const long long so = ((long long)idx[m / T] * T + m % T) * MMS_HIDDEN, d = (long long)row * MMS_HIDDEN;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        *reinterpret_cast<bf16x4*>(d_hi + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_hi + so + t * 256 + lane * 4);
-        *reinterpret_cast<bf16x4*>(d_lo + d + t * 256 + lane * 4) = *reinterpret_cast<const bf16x4*>(s_lo + so + t * 256 + lane * 4);
+        *reinterpret_cast<bf16x4*>(plane_ptr(d_hi, d + t * 256 + lane * 4)) = *reinterpret_cast<const bf16x4*>(plane_ptr(s_hi, so + t * 256 + lane * 4));
+        *reinterpret_cast<bf16x4*>(plane_ptr(d_lo, d + t * 256 + lane * 4)) = *reinterpret_cast<const bf16x4*>(plane_ptr(s_lo, so + t * 256 + lane * 4));
     }
 }
 
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256) void k_xnorm(const bf16* hi, const bf16* lo, f
     float v[12], ss = 0.f;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>(hi + (long long)row * MMS_HIDDEN + t * 256 + lane * 4);
-        const bf16x4 l = *reinterpret_cast<const bf16x4*>(lo + (long long)row * MMS_HIDDEN + t * 256 + lane * 4);
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(plane_ptr(hi, (long long)row * MMS_HIDDEN + t * 256 + lane * 4));
+        const bf16x4 l = *reinterpret_cast<const bf16x4*>(plane_ptr(lo, (long long)row * MMS_HIDDEN + t * 256 + lane * 4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[t * 4 + e] = join_bf16(h[e], l[e]); ss += v[t * 4 + e] * v[t * 4 + e]; }
     }

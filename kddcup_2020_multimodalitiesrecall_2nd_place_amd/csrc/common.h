@@ -5,6 +5,16 @@
 // 16-17 significant bits; GEMMs feed MFMA with hi (precision mode 1) or hi and lo as two MFMA
 // passes that share the weight fragment (mode 2, the parity mode: SURVEY.md Appendix C row
 // "split-bf16 activations").  Residual / LayerNorm / softmax / GELU always run in fp32.
+//
+// Memory layout of a plane pair ("hl32"): ONE buffer in which 32-element blocks of hi and lo alternate -- logical element i
+// (flat index over [M][K], K % 32 == 0) of the hi plane sits at (i >> 5) * 64 + (i & 31), the same element of the lo plane 32
+// further.  A 32-wide K stage of one row is then 128 contiguous, 128-byte-aligned bytes [hi 64 B | lo 64 B]: every LDS-DMA piece
+// of the GEMM engines (8 rows x 128 B) covers whole cache lines.  With two separate planes a piece was 16 rows x 64 B = sixteen
+// HALF lines, each line fetched twice (once per K stage): measured 6-10 % of the big GEMMs' time (profiles/r03a_gemm_layout.txt).
+// Every kernel addresses planes through plane_ptr(); `lo == hi + 32` always; leading dimensions and row maps stay LOGICAL.
+//
+// Weight matrices W[N][K] (bf16, K contiguous) are stored as 16-row x 32-column tiles of 1 KiB, tile (n / 16, k / 32) at
+// ((n / 16) * (K / 32) + k / 32) * 512, row-major inside (wtile_off): an LDS-DMA piece of W is one contiguous KiB.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,6 +42,16 @@ __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
 }
 
 __device__ __forceinline__ float join_bf16(bf16 hi, bf16 lo) { return (float)hi + (float)lo; }
+
+// hl32 plane addressing: `base` is the hi (or lo = hi + 32) pointer of a plane pair, `i` a logical flat element index.  Vector
+// accesses of 4 / 8 elements stay inside one 32-element block as long as i is 4- / 8-aligned.
+#define MMS_PLANE_LO 32
+__host__ __device__ __forceinline__ long long plane_off(long long i) { return ((i >> 5) << 6) + (i & 31); }
+template <typename T> __host__ __device__ __forceinline__ T* plane_ptr(T* base, long long i) { return base + plane_off(i); }
+// tiled weights: element (n, k) of W[N][K]
+__host__ __device__ __forceinline__ long long wtile_off(long long n, long long k, long long K) {
+    return (((n >> 4) * (K >> 5) + (k >> 5)) << 9) + ((n & 15) << 5) + (k & 31);
+}
 
 // fp32 -> OCP e4m3fn, round-to-nearest-even, saturating at +-448 (precision mode 4).  v_cvt_pk_fp8_f32 packs two values into
 // one 16-bit half of a dword; the clamp makes the result independent of the instruction's overflow convention.

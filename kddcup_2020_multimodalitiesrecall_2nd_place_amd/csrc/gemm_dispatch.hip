@@ -5,9 +5,10 @@
 // register-staged tiles of gemm_tile.hip for the small ones (CLS-only last block, poolers, heads, label text).  No environment
 // variable is read here.  `set_gemm_variant` is a TEST hook (mms_set_gemm_variant): it can only select among these product kernels.
 //
-// Lab library (libmmscore_lab.so, `make lab`, -DMMS_LAB): additionally honours MMS_GEMM_VARIANT and reaches the superseded A/B
-// kernels (gemm.hip v0, gemm_ring.hip, the LDS-DMA double-buffer tile) and -- with MMS_GEMM_DIAG -- the timing-only DIAG
-// instantiations of gemm_pp.hip, which compute WRONG results by design.  None of that code is in the product binary.
+// Lab library (libmmscore_lab.so, `make lab`, -DMMS_LAB): additionally honours MMS_GEMM_VARIANT, reaches the LDS-DMA double-buffer
+// tile of gemm_tile.hip and -- with MMS_GEMM_DIAG -- the timing-only DIAG instantiations of gemm_pp.hip, which compute WRONG results
+// by design.  None of that code is in the product binary.  (The round-1 A/B kernels gemm.hip / gemm_ring.hip were removed in round 3:
+// their measurements stay in profiles/r01c_gemm_variants.txt.)
 #include <cstdlib>
 
 #include "kernels.h"
@@ -35,15 +36,11 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         return;
     }
 #ifdef MMS_LAB
-    if (variant > 100) {   // timing diagnostics (101-103 ring, 201-232 ping-pong): WRONG results on purpose, only with MMS_GEMM_DIAG
+    if (variant > 100) {   // timing diagnostics (201-232 ping-pong): WRONG results on purpose, only with MMS_GEMM_DIAG
         static const bool diag_ok = getenv("MMS_GEMM_DIAG") != nullptr;
         if (diag_ok && variant > 200 && variant < 233 && launch_gemm_pp(p, nsplit, variant - 200, st)) return;
-        if (diag_ok && variant >= 101 && variant <= 103 && launch_gemm_ring(p, nsplit, variant, st)) return;
         variant = 99;
     }
-    if (variant == 0 && !(p.m_dev || p.flop_counter || p.hm_rows)) { launch_gemm_v0(p, nsplit, st); return; }
-    if (variant == 11 && launch_gemm_ring(p, nsplit, 4, st)) return;
-    if (variant == 12 && launch_gemm_ring(p, nsplit, 2, st)) return;
 #endif
     if (variant != 1 && variant != 4 && variant != 16 && variant != 20 && variant != 26
 #ifdef MMS_LAB

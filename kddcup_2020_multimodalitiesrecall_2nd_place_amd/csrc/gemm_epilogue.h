@@ -51,8 +51,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 v += bias4;
                 if (p.r_hi) {
                     const long long ro = (p.r_index ? (long long)p.r_index[row] : p.rmap(row)) * (long long)p.ldr + col;
-                    const bf16x4 rh = *reinterpret_cast<const bf16x4*>(p.r_hi + ro);
-                    const bf16x4 rl = *reinterpret_cast<const bf16x4*>(p.r_lo + ro);
+                    const bf16x4 rh = *reinterpret_cast<const bf16x4*>(plane_ptr(p.r_hi, ro));
+                    const bf16x4 rl = *reinterpret_cast<const bf16x4*>(plane_ptr(p.r_lo, ro));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += join_bf16(rh[e], rl[e]);
                 }
@@ -67,8 +67,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                     bf16x4 h, l;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { bf16 a, c2; split_bf16(v[e], a, c2); h[e] = a; l[e] = c2; }
-                    *reinterpret_cast<bf16x4*>(p.c_hi + orow * p.ldp + col) = h;
-                    *reinterpret_cast<bf16x4*>(p.c_lo + orow * p.ldp + col) = l;
+                    *reinterpret_cast<bf16x4*>(plane_ptr(p.c_hi, orow * p.ldp + col)) = h;
+                    *reinterpret_cast<bf16x4*>(plane_ptr(p.c_lo, orow * p.ldp + col)) = l;
                 }
             }
         }

@@ -3,9 +3,13 @@
 //
 // Same contract / epilogue as gemm_tile.hip (GemmParams: C = act(A W^T + bias (+ residual)), A in split planes).
 //
-// K is consumed in 32-wide STAGES.  A stage = A_hi [256][64 B] (+ A_lo) + W [256][64 B] (48 KiB at two passes), kept
-// in a 3-slot LDS ring filled by `global_load_lds_dwordx4` (LDS-DMA; the bank swizzle f(r) = {0,3,2,1}[(r>>2)&3] is
-// applied on the per-lane SOURCE address, fragment reads use the same involution: conflict-free ds_read_b128).
+// K is consumed in 32-wide STAGES.  A stage = A [256][hi 64 B | lo 64 B] + W [256][64 B] (48 KiB at two passes; one pass: A [256][64 B]),
+// kept in a 3-slot LDS ring filled by `global_load_lds_dwordx4` (LDS-DMA).  Every A piece of a wave is 8 rows x 128 B = eight whole
+// cache lines of the hl32 plane layout (common.h), every W piece one contiguous KiB of the tiled weights -- with separate row-major
+// planes a piece was sixteen half lines and each line was fetched twice (6-10 % of a launch, profiles/r03a_gemm_layout.txt).  Bank
+// swizzles are applied on the per-lane SOURCE address (LDS-DMA writes lane-linear) and undone by the fragment reads' addresses:
+// 128-byte A rows: 16-B chunk c of row r sits at chunk c ^ ((r >> 1) & 7); 64-byte rows (W, one-pass A): c ^ {0,3,2,1}[(r>>2)&3];
+// both make every ds_read_b128 lane group hit 16 distinct 16-B slots.
 // Each stage runs as 4 PHASES, one 64x32 quadrant of the wave's outputs per phase (16 MFMAs at two passes):
 //
 //     phase:   L: ds_read the fragments this phase needs (+ issue 2 LDS-DMA pieces of stage s+2)
@@ -112,10 +116,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     // workgroup has checked in within a few microseconds of the first one
     int ln_decided = 0;
     if constexpr (LNF) ln_decided = ln_decide(p.ln_ctl, (int)gridDim.x, lane);
-    const long long lo_delta = p.a_lo - p.a_hi;
-    // LDS-DMA sources: piece h (0/1) of an operand = rows h*128 + wave*16 + lane/4, 16-B chunk lane%4 (swizzled)
+    // LDS-DMA sources.  A2 (two planes): the A region of a slot is [256 rows][128 B]; piece q (0..3) = rows q*64 + wave*8 + lane/8, physical
+    // 16-B chunk lane%8 <- logical chunk (lane%8) ^ ((row>>1)&7) of the row's [hi 64 B | lo 64 B] stage line.  One plane (and W): [256][64 B];
+    // piece h (0/1) = rows h*128 + wave*16 + lane/4, physical chunk lane%4 <- logical chunk (lane%4) ^ pp_swz(row).
+    constexpr bool A2 = NSPLIT == 2;
+    constexpr int NAP = A2 ? 4 : 2;                 // A pieces per wave and stage
+    constexpr int ASTEP = F8 ? 32 : 64;             // 2-byte elements between two K stages of an A row (hl32: a hi and a lo block per stage)
+    constexpr int WSTEP = F8 ? 32 : 512;            // ... of a W row (bf16 weights: one 1-KiB tile per stage; e4m3 bytes: row-major)
     const int gr_l = lane >> 2, gc = lane & 3;
-    const bf16* a_src[2];
+    const bf16* a_src[NAP];
     const bf16* w_src[2];
     int bm, bn;
     auto setup = [&](int v) {
@@ -131,21 +140,45 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         if (p.reverse) bid = nblk - 1 - bid;
         bm = bid / nbn; bn = bid % nbn;
         }
+        auto a_row = [&](int r) {      // first element of tile row r's A row (clamped to the last live row), in 2-byte units
+            int gr = bm * BM + r;
+            gr = gr < Meff ? gr : Meff - 1;
+            const long long lrow = (p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda;
+            return p.a_hi + (F8 ? lrow : 2 * lrow);
+        };
+        if constexpr (A2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = q * 64 + wave * 8 + (lane >> 3);
+                a_src[q] = a_row(r) + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = h * 128 + wave * 16 + gr_l;
+                a_src[h] = a_row(r) + (gc ^ pp_swz(r)) * 8;
+            }
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = h * 128 + wave * 16 + gr_l;
-            int gr = bm * BM + r;
-            gr = gr < Meff ? gr : Meff - 1;
-            a_src[h] = p.a_hi + (p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda + (gc ^ pp_swz(r)) * 8;
-            w_src[h] = p.w + (long long)(bn * BN + r) * p.K + (gc ^ pp_swz(r)) * 8;
+            w_src[h] = p.w + (F8 ? (long long)(bn * BN + r) * p.K : wtile_off(bn * BN + r, 0, p.K)) + (gc ^ pp_swz(r)) * 8;
         }
     };
     setup(vb);
-    // piece q of stage `st` into ring slot `slot`: q>>1 = operand (A planes first, then W), q&1 = row half
+    // piece q of stage `st` into ring slot `slot`: the NAP A pieces first, then the two W halves; every piece is 1 KiB per wave
     auto issue = [&](int q, int st, int slot) {
-        const int o = q >> 1, h = q & 1;
-        unsigned char* d = smem + slot * SLOT + o * PLANE + h * 8192 + wave * 1024;
-        const bf16* s = (o < NSPLIT ? a_src[h] + (o ? lo_delta : 0) : w_src[h]) + ((DIAG & 8) ? (st & 1) : st) * 32;   // DIAG 8: L2-resident source
+        const int kst = (DIAG & 8) ? (st & 1) : st;       // DIAG 8: L2-resident source
+        unsigned char* d;
+        const bf16* s;
+        if (q < NAP) {
+            d = smem + slot * SLOT + q * 8192 + wave * 1024;        // A2: rows q*64 + wave*8 .. of 128 B; else rows q*128 + wave*16 .. of 64 B
+            s = a_src[q] + kst * ASTEP;
+        } else {
+            const int h = q - NAP;
+            d = smem + slot * SLOT + NSPLIT * PLANE + h * 8192 + wave * 1024;
+            s = w_src[h] + kst * WSTEP;
+        }
         __builtin_amdgcn_global_load_lds((glb_void*)s, (lds_void*)d, 16, 0, 0);
     };
 
@@ -154,7 +187,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
 
     // fragment read offsets inside a slot (lane part; the rest are immediates)
     const int fr = lane & 15, fk = lane >> 4;
-    const int laneA = (wm * TM + fr) * 64 + ((fk ^ pp_swz(fr)) << 4);
+    constexpr int AROW = A2 ? 128 : 64;               // bytes of an A row in a slot
+    const int laneA = (wm * TM + fr) * AROW + ((A2 ? (fk ^ ((fr >> 1) & 7)) : (fk ^ pp_swz(fr))) << 4);      // hi fragment; the lo one: chunk ^ 4
     const int laneB = NSPLIT * PLANE + (wn * TN + fr) * 64 + ((fk ^ pp_swz(fr)) << 4);
 
     bf16x8 a[NSPLIT][HM], b0[HN], b1[HN];
@@ -162,7 +196,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
         for (int pl = 0; pl < NSPLIT; ++pl)
 #pragma unroll
-            for (int i = 0; i < HM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(sb + laneA + pl * PLANE + (mh * (TM / 2) + i * 16) * 64);
+            for (int i = 0; i < HM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(sb + (laneA ^ (pl << 6)) + (mh * (TM / 2) + i * 16) * AROW);
     };
     auto read_b = [&](const unsigned char* sb, int nh, bf16x8 (&b)[HN]) {
 #pragma unroll
@@ -277,7 +311,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
                     int row = rbase + 16 * (ih + i) + mrow;
                     row = row < Meff ? row : Meff - 1;
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) t[i][j] = *reinterpret_cast<const bf16x4*>(src + (long long)row * p.ldr + cbase + 16 * j);
+                    for (int j = 0; j < FN; ++j)     // hl32 planes: the wave's 64 columns are two 32-blocks, fragment j in block j / 2
+                        t[i][j] = *reinterpret_cast<const bf16x4*>(src + 2 * ((long long)row * p.ldr + cbase - nq * 4) + 64 * (j >> 1) + 16 * (j & 1) + nq * 4);
                 }
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {

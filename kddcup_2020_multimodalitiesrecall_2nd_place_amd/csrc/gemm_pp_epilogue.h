@@ -14,12 +14,18 @@
 // the odd group next to it 8 consecutive columns of fragment j + 1.  The plane epilogues are store-ISSUE bound (64 8-byte stores per
 // lane and tile), so halving the store count is what shortens them (cdna_hip_programming.md T21).
 typedef __attribute__((ext_vector_type(2))) unsigned pp_u32x2;
-__device__ __forceinline__ void pp_store_plane_pair(bf16* plane_row, int col0, int nq, int j, bf16x4 f0, bf16x4 f1) {
+// `lane_row` = the lane's own pointer into the output row of an hl32 plane (common.h): physical address of logical column
+// col0 + 16 (nq & 1) + 4 (nq & 2) -- col0 a multiple of 32, so that is 2 * (row offset + col0) + 16 (nq & 1) + 4 (nq & 2), inside the first
+// 32-column block of the wave's columns; fragment pair j (even) then lies 32 (j / 2) logical = 64 (j / 2) physical elements further: an immediate.
+__device__ __forceinline__ bf16* pp_plane_lane_row(bf16* plane, long long row_off, int col0, int nq) {
+    return plane + 2 * (row_off + col0) + 16 * (nq & 1) + 4 * (nq & 2);
+}
+__device__ __forceinline__ void pp_store_plane_pair(bf16* lane_row, int j, bf16x4 f0, bf16x4 f1) {
     const pp_u32x2 x = __builtin_bit_cast(pp_u32x2, f0), y = __builtin_bit_cast(pp_u32x2, f1);
     const auto r0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
     const auto r1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
     const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};      // {X'.lo, X'.hi, Y'.lo, Y'.hi} = 8 consecutive bf16
-    *reinterpret_cast<u32x4*>(plane_row + col0 + 16 * (j + (nq & 1)) + 4 * (nq & 2)) = v;
+    *reinterpret_cast<u32x4*>(lane_row + 64 * (j >> 1)) = v;
 }
 
 template <int ACT, int FM, int FN>
@@ -47,8 +53,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
             const long long ro = (p.r_index ? (long long)p.r_index[row] : p.rmap(row)) * (long long)p.ldr + col;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const bf16x4 rh = *reinterpret_cast<const bf16x4*>(p.r_hi + ro + 16 * j);
-                const bf16x4 rl = *reinterpret_cast<const bf16x4*>(p.r_lo + ro + 16 * j);
+                const bf16x4 rh = *reinterpret_cast<const bf16x4*>(plane_ptr(p.r_hi, ro + 16 * j));
+                const bf16x4 rl = *reinterpret_cast<const bf16x4*>(plane_ptr(p.r_lo, ro + 16 * j));
                 acc[i][j] += bias4[j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][e] += join_bf16(rh[e], rl[e]);
@@ -58,10 +64,15 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
             for (int j = 0; j < FN; ++j) acc[i][j] += bias4[j];
         }
         if (f32_out) {
-            // head-major: every 64 columns (4 fragments) of the wave are one head's block [rows][64]
-            float* dst = p.hm_rows ? p.c_f32 + ((long long)((p.hm_col0 + col0) >> 6) * p.hm_rows + orow) * 64 + nq * 4
+            // head-major: every 64 output columns are one head's block [rows][64].  A wave's columns start on a multiple of its own width:
+            // 64 or 128 wide (gemm_pp.hip) they begin a head and fragment j lies (j >> 2) heads further; 32 wide (gemm_ppw.hip) they are
+            // the lower or the upper half of ONE head -- (hc & 63) places them (without it the odd waves of gemm_ppw overwrote the even
+            // ones' half).  Either way every fragment is an immediate offset from one pointer per row.
+            const int hc = p.hm_col0 + col0;
+            float* dst = p.hm_rows ? p.c_f32 + ((long long)(hc >> 6) * p.hm_rows + orow) * 64 + (hc & 63) + nq * 4
                                    : p.c_f32 + orow * p.ldc + col;
             const long long head_step = p.hm_rows ? (long long)p.hm_rows * 64 - 64 : 0;     // on top of the 64 columns themselves
+            static_assert(FN <= 2 || FN % 4 == 0, "a wave covers half a head, one head or whole heads");
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 f32x4 v = acc[i][j];
@@ -77,8 +88,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
                                                                      apply_act(acc[i][j][2], ACT), apply_act(acc[i][j][3], ACT));
         } else {
             static_assert(FN % 2 == 0, "plane stores pair up column fragments");
-            bf16* dh = p.c_hi + orow * p.ldp;
-            bf16* dl = p.c_lo + orow * p.ldp;
+            bf16* dh = pp_plane_lane_row(p.c_hi, orow * p.ldp, col0, nq);     // ldp % 32 == 0, col0 % 32 == 0
+            bf16* dl = dh + (p.c_lo - p.c_hi);
             // note: every lane of the wave takes part in the exchange; rows past the live count were skipped above as whole 16-lane
             // groups of identical mrow across the four lane groups, so the partner lane (same mrow) is always present
 #pragma unroll
@@ -88,8 +99,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
                 for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { bf16 a, c2; split_bf16(apply_act(acc[i][j + jj][e], ACT), a, c2); h[jj][e] = a; l[jj][e] = c2; }
-                pp_store_plane_pair(dh, col0, nq, j, h[0], h[1]);
-                pp_store_plane_pair(dl, col0, nq, j, l[0], l[1]);
+                pp_store_plane_pair(dh, j, h[0], h[1]);
+                pp_store_plane_pair(dl, j, l[0], l[1]);
             }
         }
     }

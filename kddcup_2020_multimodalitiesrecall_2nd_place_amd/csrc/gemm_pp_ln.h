@@ -179,8 +179,9 @@ __device__ __forceinline__ void pp_epilogue_ln(const GemmParams& p, f32x4 (&acc)
                 }
                 if (p.c_f8) *reinterpret_cast<unsigned*>(p.c_f8 + (long long)row * p.ldf8 + col + 16 * (j + jj)) = pack4_f8(y[0], y[1], y[2], y[3]);
             }
-            pp_store_plane_pair(p.c_hi + (long long)row * p.ldp, col0, nq, j, h[0], h[1]);
-            pp_store_plane_pair(p.c_lo + (long long)row * p.ldp, col0, nq, j, l[0], l[1]);
+            bf16* dh = pp_plane_lane_row(p.c_hi, (long long)row * p.ldp, col0, nq);
+            pp_store_plane_pair(dh, j, h[0], h[1]);
+            pp_store_plane_pair(dh + (p.c_lo - p.c_hi), j, l[0], l[1]);
         }
     }
 #ifdef MMS_LAB

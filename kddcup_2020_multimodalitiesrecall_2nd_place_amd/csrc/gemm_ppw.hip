@@ -1,7 +1,7 @@
 // Ping-pong phase GEMM for precision mode 3 (fp32-checkpoint-faithful): activations AND weights in split planes, three MFMA
 // passes per product  a_hi*w_hi + a_lo*w_hi + a_hi*w_lo  (the a_lo*w_lo term is below 2^-17 of the product).
 //
-// The gemm_pp.hip engine re-cut for four operand planes: 256x128 tile (a 32-wide K stage = A_hi, A_lo [256][64 B] + W_hi, W_lo
+// The gemm_pp.hip engine re-cut for four operand planes: 256x128 tile (a 32-wide K stage = A [256][hi 64 B | lo 64 B] + W_hi, W_lo
 // [128][64 B] = 48 KiB, so the 3-slot LDS-DMA ring still fits), 8 wavefronts as 2(M) x 4(N), 128x32 outputs per wave, TWO phases per
 // stage (rows 0-63 / 64-127 of the wave tile x both column fragments: 4 x 2 x 3 = 24 MFMAs each), wave rows staggered by one
 // barrier, swapped MFMA operands + LDS-free epilogue (gemm_pp_epilogue.h), persistent workgroups.
@@ -54,11 +54,14 @@ __global__ __launch_bounds__(512) void gemm_ppw_kernel(const GemmParams p) {
     const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM, nblk = nbm * nbn;
     int vb = blockIdx.x;                 // virtual block id: the workgroup walks vb, vb + gridDim.x, ...
     if (vb >= nblk) return;
-    const long long alo = p.a_lo - p.a_hi, wlo = p.w_lo - p.w;
+    const long long wlo = p.w_lo - p.w;
 
-    // LDS-DMA sources: one workgroup-wide instruction fills 128 rows (wave w: rows w*16 + lane/4, 16-B chunk lane%4, swizzled)
+    // LDS-DMA sources.  A region of a slot: [256 rows][hi 64 B | lo 64 B]; piece q (0..3) of a wave = rows q*64 + wave*8 + lane/8, physical
+    // 16-B chunk lane%8 <- logical chunk (lane%8) ^ ((row>>1)&7) of the row's stage line in the hl32 plane layout (common.h): eight whole
+    // cache lines per piece.  W_hi / W_lo regions: [128][64 B] each, one piece per wave = one contiguous KiB of the tiled weights
+    // (rows wave*16 + lane/4, physical chunk lane%4 <- logical chunk (lane%4) ^ pw_swz(row)).
     const int gr_l = lane >> 2, gc = lane & 3;
-    const bf16* a_src[2];
+    const bf16* a_src[4];
     const bf16* w_src;
     int bm, bn;
     auto setup = [&](int v) {
@@ -67,34 +70,34 @@ __global__ __launch_bounds__(512) void gemm_ppw_kernel(const GemmParams p) {
         if (p.reverse) bid = nblk - 1 - bid;
         bm = bid / nbn; bn = bid % nbn;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r = h * 128 + wave * 16 + gr_l;
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int r = q4 * 64 + wave * 8 + (lane >> 3);
             int gr = bm * BM + r;
             gr = gr < Meff ? gr : Meff - 1;
-            a_src[h] = p.a_hi + (p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda + (gc ^ pw_swz(r)) * 8;
+            a_src[q4] = p.a_hi + 2 * ((p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda) + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
         }
         const int rw = wave * 16 + gr_l;
-        w_src = p.w + (long long)(bn * BN + rw) * p.K + (gc ^ pw_swz(rw)) * 8;
+        w_src = p.w + wtile_off(bn * BN + rw, 0, p.K) + (gc ^ pw_swz(rw)) * 8;
     };
     setup(vb);
-    auto issue = [&](int q, int st, int slot) {     // q: 0,1 = A_hi halves, 2,3 = A_lo halves, 4 = W_hi, 5 = W_lo
+    auto issue = [&](int q, int st, int slot) {     // q: 0..3 = A row quarters (both planes), 4 = W_hi, 5 = W_lo
         unsigned char* d = smem + slot * SLOT + wave * 1024;
         const bf16* s;
-        if (q < 4) { d += (q >> 1) * APLANE + (q & 1) * 8192; s = a_src[q & 1] + ((q >> 1) ? alo : 0); }
-        else { d += WOFF + (q - 4) * WPLANE; s = w_src + (q == 5 ? wlo : 0); }
-        __builtin_amdgcn_global_load_lds((glb_void*)(s + st * 32), (lds_void*)d, 16, 0, 0);
+        if (q < 4) { d += q * 8192; s = a_src[q] + st * 64; }
+        else { d += WOFF + (q - 4) * WPLANE; s = w_src + (q == 5 ? wlo : 0) + st * 512; }
+        __builtin_amdgcn_global_load_lds((glb_void*)s, (lds_void*)d, 16, 0, 0);
     };
 
     f32x4 acc[FM][FN];
     const int fr = lane & 15, fk = lane >> 4;
-    const int laneA = (wm * TM + fr) * 64 + ((fk ^ pw_swz(fr)) << 4);
+    const int laneA = (wm * TM + fr) * 128 + ((fk ^ ((fr >> 1) & 7)) << 4);      // hi fragment; the lo one: chunk ^ 4
     const int laneB = WOFF + (wn * TN + fr) * 64 + ((fk ^ pw_swz(fr)) << 4);
     bf16x8 a[2][4], b[2][2];      // [plane][fragment]
     auto read_a = [&](const unsigned char* sb, int mh) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(sb + laneA + pl * APLANE + (mh * 64 + i * 16) * 64);
+            for (int i = 0; i < 4; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(sb + (laneA ^ (pl << 6)) + (mh * 64 + i * 16) * 128);
     };
     auto read_b = [&](const unsigned char* sb) {
 #pragma unroll

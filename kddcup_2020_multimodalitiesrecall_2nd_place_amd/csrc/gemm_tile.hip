@@ -115,26 +115,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
             const int c = (lane & 7) ^ ((r >> 1) & 7);
             int gr = bm * BM + r;
             gr = gr < Meff ? gr : Meff - 1;
-            a_src[s] = p.a_hi + (p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda + c * 8;
+            a_src[s] = p.a_hi + 2 * ((p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda) + plane_off(c * 8);   // hl32 planes
         }
 #pragma unroll
         for (int s = 0; s < GB; ++s) {
             const int r = (wave + NW * s) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((r >> 1) & 7);
-            w_src[s] = p.w + (long long)(bn * BN + r) * p.K + c * 8;
+            w_src[s] = p.w + wtile_off(bn * BN + r, c * 8, p.K);                                                                       // tiled weights
         }
         // piece q of a stage: q < GA*NSPLIT -> A planes, else B; one global_load_lds (1 KiB) per piece per wave
         constexpr int NPIECE = GA * NA + GB;
         auto issue_piece = [&](int q, int kt, unsigned char* sb) {
-            const int ko = kt * BK;
+            static_assert(BK == 64, "K tile = two 32-column blocks");
             if (q < GA * NA) {
                 const int s = q / NA, pl = q % NA;
                 unsigned char* d = sb + pl * A_BYTES + (wave + NW * s) * 1024;
-                __builtin_amdgcn_global_load_lds((glb_void*)(a_src[s] + (pl ? lo_delta : 0) + ko), (lds_void*)d, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(a_src[s] + (pl ? lo_delta : 0) + kt * (2 * BK)), (lds_void*)d, 16, 0, 0);
             } else {
                 const int s = q - GA * NA;
                 unsigned char* d = sb + NA * A_BYTES + (wave + NW * s) * 1024;
-                __builtin_amdgcn_global_load_lds((glb_void*)(w_src[s] + ko), (lds_void*)d, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(w_src[s] + kt * (16 * BK)), (lds_void*)d, 16, 0, 0);
             }
         };
 #pragma unroll
@@ -172,10 +172,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
         for (int s = 0; s < CA; ++s) {
             int r = bm * BM + lr + (NT / 8) * s;
             r = r < Meff ? r : Meff - 1;
-            a_row[s] = p.a_hi + (p.a_index ? (long long)p.a_index[r] : p.amap(r)) * (long long)p.lda + c * 8;
+            // hl32 planes (common.h): a row's K tile of 64 columns = [hi 32 | lo 32 | hi 32 | lo 32]; chunk c (8 columns) of the hi plane
+            a_row[s] = p.a_hi + 2 * ((p.a_index ? (long long)p.a_index[r] : p.amap(r)) * (long long)p.lda) + plane_off(c * 8);
         }
+        static_assert(BK == 64, "K tile = two 32-column blocks");
 #pragma unroll
-        for (int s = 0; s < CB; ++s) w_row[s] = p.w + (long long)(bn * BN + lr + (NT / 8) * s) * p.K + c * 8;
+        for (int s = 0; s < CB; ++s) w_row[s] = p.w + wtile_off(bn * BN + lr + (NT / 8) * s, c * 8, p.K);      // tiled weights: a K tile = 2 tiles of 512
         u32x4 ra0[CA], ra1[CA], rb[CB], rb1[CB];
 #pragma unroll
         for (int s = 0; s < CA; ++s) {
@@ -202,16 +204,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
                 if (NB == 2) *reinterpret_cast<u32x4*>(smem + B_BYTES + o) = rb1[s];
             }
             __syncthreads();
-            const int ko = (kt + 1 < nk ? kt + 1 : kt) * BK;
+            const int kn = kt + 1 < nk ? kt + 1 : kt, koA = kn * (2 * BK), koW = kn * (16 * BK);
 #pragma unroll
             for (int s = 0; s < CA; ++s) {
-                ra0[s] = *reinterpret_cast<const u32x4*>(a_row[s] + ko);
-                if (NA == 2) ra1[s] = *reinterpret_cast<const u32x4*>(a_row[s] + lo_delta + ko);
+                ra0[s] = *reinterpret_cast<const u32x4*>(a_row[s] + koA);
+                if (NA == 2) ra1[s] = *reinterpret_cast<const u32x4*>(a_row[s] + lo_delta + koA);
             }
 #pragma unroll
             for (int s = 0; s < CB; ++s) {
-                rb[s] = *reinterpret_cast<const u32x4*>(w_row[s] + ko);
-                if (NB == 2) rb1[s] = *reinterpret_cast<const u32x4*>(w_row[s] + wlo_delta + ko);
+                rb[s] = *reinterpret_cast<const u32x4*>(w_row[s] + koW);
+                if (NB == 2) rb1[s] = *reinterpret_cast<const u32x4*>(w_row[s] + wlo_delta + koW);
             }
             compute(smem, no_hook);
         }

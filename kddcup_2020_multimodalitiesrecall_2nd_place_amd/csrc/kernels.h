@@ -4,8 +4,8 @@
 
 // ---------------------------------------------------------------------------------------------
 // GEMM  C[M,N] = act(A[M,K] * W[N,K]^T + bias (+ residual))      (gemm.hip)
-// A is a split-plane activation (hi/lo bf16), W is bf16 [N][K] (K contiguous), N % 128 == 0,
-// K % 64 == 0.  nsplit 1: hi plane only (1 MFMA pass), 2: A hi+lo (2 passes, parity mode for bf16-exact
+// A is a split-plane activation (hi/lo bf16 in the hl32 layout of common.h: a_lo == a_hi + 32; lda, ldp, ldr are LOGICAL row lengths,
+// multiples of 32), W is bf16 [N][K] stored as 16 x 32 tiles (wtile_off), N % 128 == 0, K % 64 == 0.  nsplit 1: hi plane only (1 MFMA pass), 2: A hi+lo (2 passes, parity mode for bf16-exact
 // weights), 3: A hi+lo and W hi+lo (3 passes a_hi*w_hi + a_lo*w_hi + a_hi*w_lo: fp32-checkpoint-faithful).
 // ---------------------------------------------------------------------------------------------
 struct GemmParams {
@@ -45,8 +45,6 @@ struct GemmParams {
 };
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
-void launch_gemm_v0(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm.hip (lab only)
-bool launch_gemm_ring(const GemmParams& p, int nsplit, int nslot, hipStream_t st);      // gemm_ring.hip (variants 11: 4 slots, 12: 2 slots)
 bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist = false);                     // gemm_pp.hip (variant 20: 256x256 ping-pong phases)
 bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm_pp.hip + gemm_pp_ln.h: N = 768 with the fused residual + LayerNorm epilogue (nsplit 2)
 bool launch_gemm_pp_f8(const GemmParams& p, hipStream_t st);                            // gemm_pp.hip with e4m3 operands (precision mode 4)
@@ -87,6 +85,7 @@ void launch_ln_to_planes(const float* in, int ld, const float* gamma, const floa
                          bf16* o_hi, bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev = nullptr, LnResid res = LnResid());
 void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipStream_t st);
 void launch_planes_to_f32(const bf16* hi, const bf16* lo, float* out, long long n, hipStream_t st);
+void launch_tile_weights(const float* in, bf16* o_hi, bf16* o_lo, long long N, long long K, hipStream_t st);   // fp32 W[N][K] -> tiled bf16 (hi, optional lo)
 void launch_mean8(const float* in, float* out, int U, hipStream_t st);
 
 // zk (code/imagebert_zk/model_triple.py:162-214, pixelbert.py:541-621)

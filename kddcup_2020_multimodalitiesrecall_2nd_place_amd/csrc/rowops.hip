@@ -54,8 +54,8 @@ __device__ __forceinline__ void row_store_planes(const Row& x, bf16* hi, bf16* l
             split_bf16(x.v[t * 4 + e], a, c);
             h[e] = a; l[e] = c;
         }
-        *reinterpret_cast<bf16x4*>(hi + t * 256 + lane_id() * 4) = h;
-        *reinterpret_cast<bf16x4*>(lo + t * 256 + lane_id() * 4) = l;
+        *reinterpret_cast<bf16x4*>(plane_ptr(hi, t * 256 + lane_id() * 4)) = h;     // hi / lo: row pointers (plane_ptr of a 32-aligned index)
+        *reinterpret_cast<bf16x4*>(plane_ptr(lo, t * 256 + lane_id() * 4)) = l;
     }
 }
 __device__ __forceinline__ void row_ln(Row& x, const float* gamma, const float* beta) {
@@ -95,8 +95,8 @@ static inline dim3 row_grid(long long rows) { return dim3((unsigned)((rows + ROW
 __device__ __forceinline__ void row_add_planes(Row& x, const bf16* hi, const bf16* lo) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>(hi + t * 256 + lane_id() * 4);
-        const bf16x4 l = *reinterpret_cast<const bf16x4*>(lo + t * 256 + lane_id() * 4);
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(plane_ptr(hi, t * 256 + lane_id() * 4));
+        const bf16x4 l = *reinterpret_cast<const bf16x4*>(plane_ptr(lo, t * 256 + lane_id() * 4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) x.v[t * 4 + e] += join_bf16(h[e], l[e]);
     }
@@ -116,10 +116,10 @@ __global__ __launch_bounds__(256) void k_ln_to_planes(const float* in, int ld, c
     row_load(x, in + (long long)row * ld);
     if (res.hi) {
         const long long ro = (res.r_index ? (long long)res.r_index[row] : res.rmap(row)) * (long long)res.ld;
-        row_add_planes(x, res.hi + ro, res.lo + ro);
+        row_add_planes(x, plane_ptr(res.hi, ro), plane_ptr(res.lo, ro));
     }
     row_ln(x, gamma, beta);
-    row_store_planes(x, o_hi + (long long)row * ldo, o_lo + (long long)row * ldo);
+    row_store_planes(x, plane_ptr(o_hi, (long long)row * ldo), plane_ptr(o_lo, (long long)row * ldo));
     if (res.o_f8) row_store_f8(x, res.o_f8 + (long long)row * ldo);
 }
 void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta, bf16* o_hi,
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void k_split_f32(const float* in, bf16* o_hi, 
         bf16x4 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bf16 a, c; split_bf16(v[e], a, c); h[e] = a; l[e] = c; }
-        reinterpret_cast<bf16x4*>(o_hi)[i] = h;
-        reinterpret_cast<bf16x4*>(o_lo)[i] = l;
+        *reinterpret_cast<bf16x4*>(plane_ptr(o_hi, i * 4)) = h;
+        *reinterpret_cast<bf16x4*>(plane_ptr(o_lo, i * 4)) = l;
     }
 }
 void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipStream_t st) {
@@ -158,10 +158,31 @@ void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipS
     hipLaunchKernelGGL(k_split_f32, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, in, o_hi, o_lo, n4);
 }
 
+// fp32 W[N][K] -> bf16 tiles (wtile_off, common.h): hi = bf16(w) and, when o_lo != nullptr, lo = bf16(w - hi) as a second tiled matrix
+__global__ __launch_bounds__(256) void k_tile_weights(const float* in, bf16* o_hi, bf16* o_lo, long long N, long long K) {
+    const long long n4 = N * K / 4;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 f = reinterpret_cast<const float4*>(in)[i];
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bf16 a, c; split_bf16(v[e], a, c); h[e] = a; l[e] = c; }
+        const long long at = wtile_off(i * 4 / K, i * 4 % K, K);
+        *reinterpret_cast<bf16x4*>(o_hi + at) = h;
+        if (o_lo) *reinterpret_cast<bf16x4*>(o_lo + at) = l;
+    }
+}
+void launch_tile_weights(const float* in, bf16* o_hi, bf16* o_lo, long long N, long long K, hipStream_t st) {
+    const long long n4 = N * K / 4;
+    if (n4 <= 0) return;
+    const long long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(k_tile_weights, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, in, o_hi, o_lo, N, K);
+}
+
 __global__ __launch_bounds__(256) void k_planes_to_f32(const bf16* hi, const bf16* lo, float* out, long long n4) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const bf16x4 h = reinterpret_cast<const bf16x4*>(hi)[i];
-        const bf16x4 l = reinterpret_cast<const bf16x4*>(lo)[i];
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(plane_ptr(hi, i * 4));
+        const bf16x4 l = *reinterpret_cast<const bf16x4*>(plane_ptr(lo, i * 4));
         reinterpret_cast<float4*>(out)[i] = make_float4(join_bf16(h[0], l[0]), join_bf16(h[1], l[1]),
                                                         join_bf16(h[2], l[2]), join_bf16(h[3], l[3]));
     }
@@ -176,8 +197,8 @@ void launch_planes_to_f32(const bf16* hi, const bf16* lo, float* out, long long 
 // ---- precision mode 4: e4m3 operand bytes ----
 __global__ __launch_bounds__(256) void k_planes_to_f8(const bf16* hi, const bf16* lo, unsigned* out, long long n4) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const bf16x4 h = reinterpret_cast<const bf16x4*>(hi)[i];
-        const bf16x4 l = reinterpret_cast<const bf16x4*>(lo)[i];
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(plane_ptr(hi, i * 4));
+        const bf16x4 l = *reinterpret_cast<const bf16x4*>(plane_ptr(lo, i * 4));
         out[i] = pack4_f8(join_bf16(h[0], l[0]), join_bf16(h[1], l[1]), join_bf16(h[2], l[2]), join_bf16(h[3], l[3]));
     }
 }
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(256) void k_zk_im2col(const float* E, const int* un
     if (src >= 0 && src < MMS_LABEL_LEN)
         row_load(x, E + clamp_id(uniq_ids[u * MMS_LABEL_LEN + src], vocab) * MMS_HIDDEN);
     const long long off = ((long long)u * MMS_LABEL_LEN + p) * (MMS_LABEL_LEN * MMS_HIDDEN) + k * MMS_HIDDEN;
-    row_store_planes(x, o_hi + off, o_lo + off);
+    row_store_planes(x, plane_ptr(o_hi, off), plane_ptr(o_lo, off));
 }
 void launch_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab, bf16* o_hi, bf16* o_lo, hipStream_t st) {
     if (U > 0)
@@ -282,7 +303,7 @@ __global__ __launch_bounds__(256) void k_zk_tokpre(const float* labfeat, const i
 #pragma unroll
     for (int k = 0; k < 5; ++k) row_axpy(x, boxes5[(long long)row * 5 + k], Wd + k * MMS_HIDDEN);
     row_add(x, img + (long long)row * MMS_HIDDEN);
-    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+    row_store_planes(x, plane_ptr(o_hi, (long long)row * MMS_HIDDEN), plane_ptr(o_lo, (long long)row * MMS_HIDDEN));
 }
 void launch_zk_tokpre(const float* labfeat, const int* lab_index, int n_labels, const float* boxes5, const float* Wd,
                       const float* bd, const float* img, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st) {
@@ -306,7 +327,7 @@ __global__ __launch_bounds__(256) void k_zk_embed(const float* E, const float* t
     row_add(x, type_tab + clamp_id(segment_ids[row], 2) * MMS_HIDDEN);
     row_add(x, pos_tab + (s < T ? s : T) * MMS_HIDDEN);
     row_ln(x, gamma, beta);
-    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+    row_store_planes(x, plane_ptr(o_hi, (long long)row * MMS_HIDDEN), plane_ptr(o_lo, (long long)row * MMS_HIDDEN));
 }
 void launch_zk_embed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
                      const float* beta, const int* query_ids, const int* segment_ids, const float* tok,
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(256) void k_lds_embed_text(const float* E, const fl
     row_add(x, pos_tab + t * MMS_HIDDEN);
     row_ln(x, gamma, beta);
     const long long off = ((long long)b * S + t) * MMS_HIDDEN;
-    row_store_planes(x, o_hi + off, o_lo + off);
+    row_store_planes(x, plane_ptr(o_hi, off), plane_ptr(o_lo, off));
 }
 void launch_lds_embed_text(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
                            const float* beta, const int64_t* input_ids, const int64_t* segment_ids, int T, int S,
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(256) void k_lds_label(const float* E, const float* 
             x.v[t * 4 + e] = a;
         }
     const long long off = ((long long)b * S + row_off + n) * MMS_HIDDEN;
-    row_store_planes(x, o_hi + off, o_lo + off);
+    row_store_planes(x, plane_ptr(o_hi, off), plane_ptr(o_lo, off));
 }
 void launch_lds_label(const float* E, const float* wl, const int64_t* labelfeat, int vocab, int S, int row_off,
                       bf16* o_hi, bf16* o_lo, int B, hipStream_t st) {
@@ -465,7 +486,7 @@ __global__ __launch_bounds__(256) void k_lx_embed_lang(const float* E, const flo
     row_add(x, pos_tab + (row % T) * MMS_HIDDEN);
     row_add(x, type_tab);
     row_ln(x, gamma, beta);
-    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+    row_store_planes(x, plane_ptr(o_hi, (long long)row * MMS_HIDDEN), plane_ptr(o_lo, (long long)row * MMS_HIDDEN));
 }
 void launch_lx_embed_lang(const float* E, const float* pos_tab, const float* type_tab, const float* gamma,
                           const float* beta, const int64_t* input_ids, int T, int vocab, bf16* o_hi, bf16* o_lo,
@@ -498,7 +519,7 @@ __global__ __launch_bounds__(256) void k_lx_label_emb(const float* E, const floa
     const float cb = conv_b[0];
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc.v[i] += cb;
-    row_store_planes(acc, o_hi + (long long)u * MMS_HIDDEN, o_lo + (long long)u * MMS_HIDDEN);
+    row_store_planes(acc, plane_ptr(o_hi, (long long)u * MMS_HIDDEN), plane_ptr(o_lo, (long long)u * MMS_HIDDEN));
 }
 void launch_lx_label_emb(const float* E, const float* pos_tab, const float* type_tab, const float* gamma,
                          const float* beta, const float* conv_w, const float* conv_b, const int64_t* uniq_ids,
@@ -533,7 +554,7 @@ __global__ __launch_bounds__(256) void k_lx_visn(const float* xf, const float* g
     row_load(zz, z + clamp_id(lab_index[row], n_labels) * MMS_HIDDEN);
 #pragma unroll
     for (int i = 0; i < 12; ++i) x.v[i] = (x.v[i] + y.v[i] + zz.v[i]) / 3.0f;
-    row_store_planes(x, o_hi + (long long)orow * MMS_HIDDEN, o_lo + (long long)orow * MMS_HIDDEN);
+    row_store_planes(x, plane_ptr(o_hi, (long long)orow * MMS_HIDDEN), plane_ptr(o_lo, (long long)orow * MMS_HIDDEN));
 }
 void launch_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes, int box_dim,
                     const float* Wb, const float* bb, const float* g_y, const float* b_y, const float* z,
@@ -687,7 +708,7 @@ __global__ __launch_bounds__(256) void k_zk_embed_packed(const float* E, const f
     row_add(x, type_tab + clamp_id(segment_ids[src], 2) * MMS_HIDDEN);
     row_add(x, pos_tab + (s < T ? s : T) * MMS_HIDDEN);
     row_ln(x, gamma, beta);
-    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+    row_store_planes(x, plane_ptr(o_hi, (long long)row * MMS_HIDDEN), plane_ptr(o_lo, (long long)row * MMS_HIDDEN));
 }
 void launch_zk_embed_packed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
                             const float* beta, const int* query_ids, const int* segment_ids, const float* tok, int T,
@@ -837,7 +858,7 @@ __global__ __launch_bounds__(256) void k_lx_embed_lang_packed(const float* E, co
     row_add(x, pos_tab + (sp % T) * MMS_HIDDEN);
     row_add(x, type_tab);
     row_ln(x, gamma, beta);
-    row_store_planes(x, o_hi + (long long)row * MMS_HIDDEN, o_lo + (long long)row * MMS_HIDDEN);
+    row_store_planes(x, plane_ptr(o_hi, (long long)row * MMS_HIDDEN), plane_ptr(o_lo, (long long)row * MMS_HIDDEN));
 }
 void launch_lx_embed_lang_packed(const float* E, const float* pos_tab, const float* type_tab, const float* gamma,
                                  const float* beta, const int64_t* input_ids, int T, int vocab, const int* src,

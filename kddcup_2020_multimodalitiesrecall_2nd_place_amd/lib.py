@@ -58,6 +58,8 @@ class EnsembleBatch(C.Structure):
                 ("lx_input_ids", C.c_void_p), ("lx_input_mask", C.c_void_p)]
 
 
+ABI_VERSION = 3     # include/mmscore.h MMS_ABI_VERSION
+
 EXPORTS = ("mms_version", "mms_global_error", "mms_create", "mms_destroy", "mms_last_error", "mms_load_weight",
            "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_score_ensemble", "mms_gemm_timing",
            "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_ln", "mms_dbg_attention", "mms_dbg_layernorm", "mms_set_gemm_variant",
@@ -80,6 +82,9 @@ def load(path=None):
     lib = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.mms_version.restype = C.c_int
+    if lib.mms_version() != ABI_VERSION:     # the ctypes structs below mirror include/mmscore.h at exactly this revision
+        raise MmsError("%s has ABI revision %d, this package's ctypes structs are revision %d: rebuild (`make -C .../csrc`)"
+                       % (path, lib.mms_version(), ABI_VERSION))
     lib.mms_global_error.restype = C.c_char_p
     lib.mms_last_error.restype = C.c_char_p
     lib.mms_last_error.argtypes = [vp]

@@ -267,6 +267,14 @@ def from_tf_variables(cfg, reader, ema: bool = None) -> dict:
     return out
 
 
+def from_tf_checkpoint(cfg, prefix: str, ema: bool = None) -> dict:
+    """zk / lds weights straight from a TensorFlow checkpoint bundle (``<prefix>.index`` + ``<prefix>.data-*``), the files
+    ``saver.restore(sess, ckpt)`` reads in the reference (evaluate_normal.py:204-212, run_pretraining_predict_score.py:558-563).
+    No TensorFlow needed: ``tf_checkpoint.BundleReader`` parses the bundle.  ``ema`` as in ``from_tf_variables``."""
+    from .tf_checkpoint import BundleReader
+    return from_tf_variables(cfg, BundleReader(prefix), ema=ema)
+
+
 class DictReader:
     """Minimal ``get_tensor`` / ``has_tensor`` adapter over a {name: array} dict (e.g. an .npz export of a checkpoint)."""
 

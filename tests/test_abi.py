@@ -17,6 +17,10 @@ def _declared():
     return sorted(set(re.findall(r"\b(mms_[a-z_0-9]+)\s*\(", src)))
 
 
+def _header_abi_version():
+    return int(re.search(r"#define\s+MMS_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "mmscore.h")).read()).group(1))
+
+
 def test_header_declares_expected_surface():
     names = _declared()
     for n in ("mms_create", "mms_load_weight", "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert",
@@ -30,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for n in _declared():
         assert hasattr(so, n), n
     assert sorted(lib.EXPORTS) == _declared()
-    assert so.mms_version() == 1
+    assert so.mms_version() == lib.ABI_VERSION == _header_abi_version()
 
 
 def test_create_rejects_bad_config_without_touching_a_device():
@@ -133,6 +137,6 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.splitlines()
-    assert lines[0].startswith("version 1 rc 1") and "model" in lines[0]
+    assert lines[0].startswith("version %d rc 1" % lib.ABI_VERSION) and "model" in lines[0]
     assert lines[1].startswith("rc 1") and "48-token" in lines[1]
     assert lines[2].endswith("rc 1")

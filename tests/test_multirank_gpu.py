@@ -34,6 +34,39 @@ def test_sharded_hip_scoring_equals_single_rank_bitwise(world, tmp_path):
     assert res["ok"] is True and sum(res["counts"]) == res["pairs"]
 
 
+def test_eight_ranks_fused_ensemble_gather_and_rank0_post_processing(tmp_path):
+    """The N = 8 code path end to end on ONE device (no 8-GPU node is available to the builder; no RCCL run exists, DESIGN.md
+    section 7): 8 processes, contiguous query blocks of fewer than 3 queries each, the fused three-model scorer per rank, one
+    all-gather with static counts, then main.py's global uniqueness filter + top-5 on rank 0 -- identical to one rank doing it all."""
+    out = tmp_path / "res8.json"
+    port = _port()
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="8", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), str(out), "ensemble"], env=env, cwd=ROOT))
+    for p in procs:
+        assert p.wait(timeout=1500) == 0
+    res = json.load(open(out))
+    assert res["ok"] is True and sum(res["counts"]) == res["pairs"] and len(res["counts"]) == 8 and res["queries"] == 21
+
+
+def test_bench_gpus8_reports_weak_and_strong_in_one_line():
+    """`python bench.py --gpus 8` (self-spawned, 8 ranks sharing device 0 over gloo here; one GPU each over RCCL on the driver's node):
+    ONE JSON line carrying the weak-scaling value (N x Q queries) and, under "strong", the metric's own Q-query job cut over the 8 ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MMS_BENCH_SHARE_GPU="1", MMS_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--queries", "24",
+                          "--cands", "10"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=2400)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["pairs_total"] == 8 * 24 * 10 and d["value"] > 0
+    st = d["strong"]
+    assert st["scaling"] == "strong" and st["pairs_total"] == 24 * 10 and sum(st["pairs_per_gpu"]) == 240 and len(st["pairs_per_gpu"]) == 8
+    assert st["value"] > 0 and abs(st["value"] - 240 * d["steps"] / (st["ms_per_step"] * 1e-3 * d["steps"])) / st["value"] < 1e-3
+
+
 def test_bench_gpus2_spawns_two_ranks_itself():
     """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE: the bench starts its own ranks.  On this
     one-GPU box the ranks share device 0 and exchange over gloo; on the driver's node they get one GPU each and RCCL."""
