@@ -186,6 +186,10 @@ int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const fl
  * W: per-output-channel scale max|w|/448, e4m3 RNE of w/scale) */
 int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, int64_t N, const float* bias, int32_t act,
                     int32_t out_f8, float* c_f32, void* stream);
+/* precision-5 GEMM (gemm_mx.hip: fp16 high pass + MX-scaled e4m3 low pass) on fp32 operands, N % 256 == 0, K % 256 == 0; A is split into
+ * h3 planes and W prepared exactly as the forward does it; out_h3 != 0: the output leaves as h3 planes and is converted back */
+int mms_dbg_gemm_mx(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, int64_t N, const float* bias, int32_t act,
+                    int32_t out_h3, float* c_f32, void* stream);
 /* out = LayerNorm(A W^T + bias + resid) over N = 768 through the GEMM with the fused LayerNorm epilogue (gemm_pp_ln.h) and the
  * LayerNorm kernel queued behind it; *mode_out = 1 when the launch ran fused, 2 when it took the plain two-kernel route */
 int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, const float* bias, const float* resid_f32,

@@ -1604,6 +1604,38 @@ int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32
     return MMS_OK;
 }
 
+// precision mode 5 GEMM (gemm_mx.hip) on fp32 operands: A goes through the h3 split (fp16 + e4m3 residual), W through the weight
+// preparation of the forward (fp16 copy + e4m3 copy + per-channel scales); out_h3: the result leaves as h3 planes (and is converted back)
+int mms_dbg_gemm_mx(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, int64_t N, const float* bias, int32_t act,
+                    int32_t out_h3, float* c_f32, void* stream) {
+    if (!a_f32 || !w_f32_nk || !c_f32 || M <= 0 || N % 256 || K % 256) { g_err = "mms_dbg_gemm_mx: bad argument (N % 256, K % 256)"; return MMS_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t Mp = (M + 255) / 256 * 256;
+    f16 *a16 = nullptr, *w16 = nullptr, *c16 = nullptr;
+    unsigned char *a8 = nullptr, *w8 = nullptr, *c8 = nullptr;
+    unsigned* ws4 = nullptr;
+    float* cs = nullptr;
+    DBG_TRY(hipMalloc((void**)&a16, (size_t)Mp * K * 2)); DBG_TRY(hipMalloc((void**)&a8, (size_t)Mp * K));
+    DBG_TRY(hipMemsetAsync(a16, 0, (size_t)Mp * K * 2, st)); DBG_TRY(hipMemsetAsync(a8, 0, (size_t)Mp * K, st));
+    DBG_TRY(hipMalloc((void**)&w16, (size_t)N * K * 2)); DBG_TRY(hipMalloc((void**)&w8, (size_t)N * K));
+    DBG_TRY(hipMalloc((void**)&ws4, (size_t)N)); DBG_TRY(hipMalloc((void**)&cs, (size_t)N * 4));
+    launch_split_h3(a_f32, a16, a8, M * K, st);
+    launch_prep_w_mx(w_f32_nk, w16, w8, ws4, cs, (int)N, (int)K, st);
+    GemmParams p{};
+    p.a_hi = (const bf16*)a16; p.a8 = a8; p.lda = (int)K; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
+    p.w = (const bf16*)w16; p.w8 = w8; p.w8_scale4 = ws4; p.col_scale = cs; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
+    if (out_h3) {
+        DBG_TRY(hipMalloc((void**)&c16, (size_t)M * N * 2)); DBG_TRY(hipMalloc((void**)&c8, (size_t)M * N));
+        p.out_kind = OUT_H3; p.c_h16 = c16; p.c_l8 = c8; p.ldh = (int)N;
+    } else { p.out_kind = OUT_F32; p.c_f32 = c_f32; p.ldc = (int)N; }
+    if (!launch_gemm_mx(p, st)) { g_err = "mms_dbg_gemm_mx: shape not supported"; return MMS_ERR_ARG; }
+    if (out_h3) launch_h3_to_f32(c16, c8, c_f32, M * N, st);
+    DBG_TRY(hipStreamSynchronize(st));
+    DBG_TRY(hipGetLastError());
+    for (void* q : {(void*)a16, (void*)a8, (void*)w16, (void*)w8, (void*)ws4, (void*)cs, (void*)c16, (void*)c8}) (void)hipFree(q);
+    return MMS_OK;
+}
+
 #ifdef MMS_LAB
 unsigned long long* g_ln_dbg = nullptr;   // lab: device buffer for the per-tile phase stamps of the next mms_dbg_gemm_ln (tools/ln_trace.py)
 int mms_lab_ln_trace(unsigned long long* dev_buf) { g_ln_dbg = dev_buf; return MMS_OK; }
@@ -1702,10 +1734,38 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     set_gemm_variant(variant);
     hipEvent_t e0, e1;
     DBG_TRY(hipEventCreate(&e0)); DBG_TRY(hipEventCreate(&e1));
-    launch_gemm(p, nsplit, 0);
-    launch_gemm(p, nsplit, 0);
+    // variants 50 / 51: the precision-5 engine (gemm_mx.hip) / its high pass alone (lab) on the same random operands
+    f16 *a16 = nullptr, *w16 = nullptr, *c16 = nullptr;
+    unsigned char *a8 = nullptr, *w8 = nullptr, *c8 = nullptr;
+    unsigned* ws4 = nullptr;
+    float* cs = nullptr;
+    GemmParams pm{};
+    const bool mx = variant == 50 || variant == 51;
+    if (mx) {
+        if (N % 256 || K % 256 || resid) { g_err = "mms_dbg_gemm_bench: mx engine needs N % 256 == 0, K % 256 == 0, no residual"; return MMS_ERR_ARG; }
+        const int64_t Mp = (M + 255) / 256 * 256;
+        DBG_TRY(hipMalloc((void**)&a16, (size_t)Mp * K * 2)); DBG_TRY(hipMalloc((void**)&a8, (size_t)Mp * K));
+        DBG_TRY(hipMemset(a16, 0, (size_t)Mp * K * 2)); DBG_TRY(hipMemset(a8, 0, (size_t)Mp * K));
+        DBG_TRY(hipMalloc((void**)&w16, (size_t)N * K * 2)); DBG_TRY(hipMalloc((void**)&w8, (size_t)N * K));
+        DBG_TRY(hipMalloc((void**)&ws4, (size_t)N)); DBG_TRY(hipMalloc((void**)&cs, (size_t)N * 4));
+        DBG_TRY(hipMalloc((void**)&c16, (size_t)M * N * 2)); DBG_TRY(hipMalloc((void**)&c8, (size_t)M * N));
+        launch_split_h3(af, a16, a8, M * K, 0);
+        launch_prep_w_mx(wf, w16, w8, ws4, cs, (int)N, (int)K, 0);
+        pm = p;
+        pm.a_hi = (const bf16*)a16; pm.a8 = a8; pm.w = (const bf16*)w16; pm.w8 = w8; pm.w8_scale4 = ws4; pm.col_scale = cs; pm.w_lo = nullptr;
+        if (out_planes) { pm.out_kind = OUT_H3; pm.c_h16 = c16; pm.c_l8 = c8; pm.ldh = (int)N; }
+    }
+    auto run = [&]() {
+        if (!mx) { launch_gemm(p, nsplit, 0); return true; }
+#ifdef MMS_LAB
+        if (variant == 51) return launch_gemm_mx_hi_only(pm, 0);
+#endif
+        return launch_gemm_mx(pm, 0);
+    };
+    if (!run()) { g_err = "mms_dbg_gemm_bench: variant not available"; return MMS_ERR_ARG; }
+    run();
     DBG_TRY(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) launch_gemm(p, nsplit, 0);
+    for (int i = 0; i < iters; ++i) run();
     DBG_TRY(hipEventRecord(e1, 0));
     DBG_TRY(hipEventSynchronize(e1));
     float ms = 0;
@@ -1714,7 +1774,8 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     set_gemm_variant(saved);
     DBG_TRY(hipGetLastError());
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    for (void* q : {(void*)af, (void*)wf, (void*)rf, (void*)bias, (void*)cf, (void*)ap, (void*)wp, (void*)rp, (void*)cp}) (void)hipFree(q);
+    for (void* q : {(void*)af, (void*)wf, (void*)rf, (void*)bias, (void*)cf, (void*)ap, (void*)wp, (void*)rp, (void*)cp, (void*)a16, (void*)a8,
+                    (void*)w16, (void*)w8, (void*)ws4, (void*)cs, (void*)c16, (void*)c8}) (void)hipFree(q);
     return MMS_OK;
 }
 

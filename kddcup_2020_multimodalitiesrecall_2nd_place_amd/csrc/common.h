@@ -34,7 +34,18 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define MMS_LN_EPS 1e-12f
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU_TANH = 2, ACT_GELU_ERF = 3, ACT_TANH = 4 };
-enum { OUT_F32 = 0, OUT_PLANES = 1, OUT_F8 = 2 };
+enum { OUT_F32 = 0, OUT_PLANES = 1, OUT_F8 = 2, OUT_H3 = 3 };
+
+// "h3" operand format of precision mode 5 (gemm_mx.hip): an activation x as an fp16 high plane h = fp16(x) [rows][ld] and an e4m3 low
+// plane l = e4m3((x - h) * 2^MMS_H3_SA) [rows][ld] bytes, both row-major: 3 bytes per element, 11 + 4 significant bits.  The constant
+// exponent keeps the residual of |x| in [2^-8, 64] inside e4m3's normal range (|x - h| <= 2^-11 |x|); smaller values lose only bits
+// below 2^-24 of the row scale, larger ones saturate towards plain fp16 precision.
+#define MMS_H3_SA 13
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
     hi = (bf16)v;                 // v_cvt_pk_bf16_f32: round-to-nearest-even
@@ -42,7 +53,6 @@ __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
 }
 
 __device__ __forceinline__ float join_bf16(bf16 hi, bf16 lo) { return (float)hi + (float)lo; }
-
 // hl32 plane addressing: `base` is the hi (or lo = hi + 32) pointer of a plane pair, `i` a logical flat element index.  Vector
 // accesses of 4 / 8 elements stay inside one 32-element block as long as i is 4- / 8-aligned.
 #define MMS_PLANE_LO 32
@@ -62,6 +72,15 @@ __device__ __forceinline__ unsigned pack4_f8(float a, float b, float c, float d)
     w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
     return (unsigned)w;
 }
+
+// h3 split of four values: hi = fp16 (RNE), lo = the four e4m3 bytes of (v - hi) * 2^SA packed into one dword
+__device__ __forceinline__ void split_h3(const float (&v)[4], f16x4& hi, unsigned& lo) {
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hi[e] = (f16)v[e]; r[e] = (v[e] - (float)hi[e]) * (float)(1 << MMS_H3_SA); }
+    lo = pack4_f8(r[0], r[1], r[2], r[3]);
+}
+
 
 // Fast transcendental forms for the GEMM epilogues: v_exp_f32 / v_rcp_f32 directly (both ~1 ulp; `__fdividef` and `x / y` compile
 // to the full IEEE division sequence, 10 instructions per element).  Absolute error <= ~2e-7, entering GELU only through a factor

@@ -1,0 +1,315 @@
+// Precision mode 5 GEMM (gfx950): the second MFMA pass of the split-activation product made cheap.
+//
+//     C[M,N] = (A16 W16^T  +  2^-SA 2^(e16-e8) (A8 W8^T)) 2^-e16  + bias ...            ("1.5 passes")
+//
+//   A16 = fp16(a), A8 = e4m3((a - A16) 2^SA)           activation in the h3 operand format (common.h): 11 + 4 significant bits, 3 B / element
+//   W16 = fp16(w 2^e16[n]), W8 = e4m3(w 2^e8[n])        bf16-exact weights: an exact fp16 copy (per-channel power-of-two scale) + an e4m3 copy
+//
+// High pass: v_mfma_f32_16x16x32_f16 (the bf16 rate).  Low pass: v_mfma_scale_f32_16x16x128_f8f6f4 -- ONE instruction per 128 k at
+// twice the bf16 rate per flop -- with its hardware block scales used as plain per-row powers of two: the weight operand's lane scale
+// is 2^(e16-e8) of its output channel, the activation operand's the constant 2^-SA, so both passes accumulate in the same units and
+// the epilogue applies 2^-e16[n] (exact).  The low term is 2^-11 of the product and carries 4 bits of each operand: the sum is good to
+// ~2^-15 relative (two bf16 planes: 2^-17), measured per model in tests/test_round3_gpu.py.
+//
+// Engine = gemm_pp.hip's: 256x256 tile, 8 waves 2(M) x 4(N), 128x64 outputs per wave, wave rows staggered by one barrier (ping-pong),
+// persistent workgroups, swapped MFMA operands + LDS-free epilogue.  LDS (all 160 KiB):
+//   * 3-slot ring of 32-k HIGH stages: A16 [256][64 B] + W16 [256][64 B] = 32 KiB per slot; stage s+2 is issued while stage s is consumed
+//   * one LOW region per 128-k SUPER-STAGE: A8 [256][128 B] + W8 [256][128 B] = 64 KiB, single-buffered
+// A super-stage is 12 PHASES of equal MFMA length (256 cycles): 4 high stages x 2 phases (rows 0-63 / 64-127 of the wave tile x all 64
+// columns: 16 f16 MFMAs) and then 4 low phases (one 64x32 quadrant each: 8 MX MFMAs).  The low operands of a super-stage are
+// issued during its own second to fifth phase (>= 2 phases after the region's last reader, the previous super-stage's last low phase)
+// and are read from its ninth phase on; the counted wait at the end of every high stage covers them.
+// Low fragments: lane (row r, g) reads the 16-byte chunks g and 4 + g of its 128-byte row (k = 16 g .. and 64 + 16 g ..: the instruction's
+// own k order, tools/probes/mx_probe.hip); rows are swizzled chunk ^ ((r >> 1) & 7) on the LDS-DMA source address, conflict-free.
+//
+// Contract: M rows of A allocated up to a multiple of 256 (rows >= the live count are read and discarded, never clamped: one base
+// pointer per operand), identity row maps, N % 256 == 0, K % 128 == 0.
+#include <type_traits>
+
+#include "kernels.h"
+#include "gemm_pp_epilogue.h"
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+namespace {
+
+__device__ __forceinline__ int mx_swz(int r) { return (4 - ((r >> 2) & 3)) & 3; }
+
+template <int N> __device__ __forceinline__ void mx_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void mx_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+}  // namespace
+
+// LOW = false: the high pass alone (timing reference of the lab bench; results are those of a single fp16 pass)
+template <int ACT, bool LOW = true>
+__global__ __launch_bounds__(512) void gemm_mx_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 256, NW = 8, WAVES_N = 4, TM = 128, TN = 64, FM = 8, FN = 4;
+    constexpr int HPLANE = 256 * 64;                 // one high operand of a stage
+    constexpr int HSLOT = 2 * HPLANE;                // A16 + W16
+    constexpr int RING = 3 * HSLOT;                  // 96 KiB
+    constexpr int LPLANE = 256 * 128;                // one low operand of a super-stage
+    constexpr int LOA = RING, LOW_W = RING + LPLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING + 2 * LPLANE];
+    static_assert(RING + 2 * LPLANE == 160 * 1024, "the whole LDS");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    int Meff = p.M;
+    if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
+    if (p.flop_counter && blockIdx.x == 0 && tid == 0)
+        atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
+    const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM, nblk = nbm * nbn;
+    int vb = blockIdx.x;                 // virtual block id; the workgroup walks vb, vb + gridDim.x, ... (gridDim.x % 8 == 0)
+    if (vb >= nblk) return;
+
+    const f16* a16 = reinterpret_cast<const f16*>(p.a_hi);
+    const f16* w16 = reinterpret_cast<const f16*>(p.w);
+    const long long lda = p.lda, K = p.K;
+    // per-lane LDS-DMA sources (one base per operand; the pieces of an operand differ by workgroup-uniform strides)
+    const f16* a16_src; const f16* w16_src; const unsigned char* a8_src; const unsigned char* w8_src;
+    unsigned wscale = 0;                 // e8m0 bytes of the wave's four 16-channel column fragments (lane: channel 16 j + lane % 16)
+    int bm, bn;
+    const int rh = wave * 16 + (lane >> 2), ch = ((lane & 3) ^ mx_swz(rh)) * 8;           // high pieces: 16 rows x 64 B
+    const int rl = wave * 8 + (lane >> 3), cl = ((lane & 7) ^ ((rl >> 1) & 7)) * 16;      // low pieces: 8 rows x 128 B
+    auto setup = [&](int v) {
+        const int q = nblk >> 3, r8 = nblk & 7, xcd = v & 7, loc = v >> 3;                 // bijective XCD remap over the live tiles
+        int bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+        if (p.reverse) bid = nblk - 1 - bid;
+        bm = bid / nbn; bn = bid % nbn;
+        a16_src = a16 + (long long)(bm * BM + rh) * lda + ch;
+        w16_src = w16 + wtile_off(bn * BN + rh, 0, K) + ch;
+        if constexpr (LOW) {
+            a8_src = p.a8 + (long long)(bm * BM + rl) * lda + cl;
+            const int n = bn * BN + rl;                                                    // W8: [N/8][K/128][8][128 B]
+            w8_src = p.w8 + ((long long)(n >> 3) * (K >> 7)) * 1024 + (n & 7) * 128 + cl;
+            wscale = p.w8_scale4[(bn * BN + wn * TN) / 4 + (lane & 15)];
+        }
+    };
+    setup(vb);
+    auto issue_hi = [&](int q, int st, int slot) {        // q: 0, 1 = A16 row halves; 2, 3 = W16 row halves
+        const int h = q & 1;
+        unsigned char* d = smem + slot * HSLOT + (q >> 1) * HPLANE + h * 8192 + wave * 1024;
+        const f16* s = q < 2 ? a16_src + (long long)h * 128 * lda + st * 32 : w16_src + (long long)h * 128 * K + st * 512;
+        __builtin_amdgcn_global_load_lds((glb_void*)s, (lds_void*)d, 16, 0, 0);
+    };
+    auto issue_lo = [&](int q, int ss) {                  // q: 0..3 = A8 row quarters; 4..7 = W8 row quarters
+        const int h = q & 3;
+        unsigned char* d = smem + (q < 4 ? LOA : LOW_W) + h * 8192 + wave * 1024;
+        const unsigned char* s = q < 4 ? a8_src + (long long)h * 64 * lda + ss * 128 : w8_src + (long long)h * 64 * K + ss * 1024;
+        __builtin_amdgcn_global_load_lds((glb_void*)s, (lds_void*)d, 16, 0, 0);
+    };
+
+    f32x4 acc[FM][FN];
+    const int ns = p.K / 32, nss = p.K / 128;
+
+    const int fr = lane & 15, fk = lane >> 4;
+    const int laneA = (wm * TM + fr) * 64 + ((fk ^ mx_swz(fr)) << 4);
+    const int laneB = HPLANE + (wn * TN + fr) * 64 + ((fk ^ mx_swz(fr)) << 4);
+    const int c0 = (fk ^ ((fr >> 1) & 7)) << 4;                        // low chunk g; chunk 4 + g = c0 ^ 64
+    // two addresses per operand (chunks g and 4 + g); every fragment row offset is a multiple of 128 and rides as an immediate
+    const int loA0 = LOA + (wm * TM + fr) * 128 + c0, loA1 = loA0 ^ 64, loB0 = LOW_W + (wn * TN + fr) * 128 + c0, loB1 = loB0 ^ 64;
+
+    // fragment registers: the high set (a, b) and the low set (la, lb) are never live together
+    f16x8 a[4], b[4];
+    i32x8 la[4], lb[2];
+    auto read_a = [&](const unsigned char* sb, int mh, f16x8 (&dst)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const f16x8*>(sb + laneA + (mh * 64 + i * 16) * 64);
+    };
+    auto read_b = [&](const unsigned char* sb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f16x8*>(sb + laneB + j * 16 * 64);
+    };
+    auto read_lo = [&](int off0, int off1, int imm, i32x8& dst) {
+        const i32x4 x = *reinterpret_cast<const i32x4*>(smem + off0 + imm);
+        const i32x4 y = *reinterpret_cast<const i32x4*>(smem + off1 + imm);
+        dst = i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    };
+    auto read_la = [&](int mh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) read_lo(loA0, loA1, (mh * 64 + i * 16) * 128, la[i]);
+    };
+    auto read_lb = [&](int nh) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) read_lo(loB0, loB1, (nh * 32 + jj * 16) * 128, lb[jj]);
+    };
+    // swapped operands (W fragment first): every 16x16 result sits transposed in the lane (gemm_pp_epilogue.h).
+    // The MFMAs are inline asm with the accumulators constrained to the ACCUMULATOR half of the register file ("+a"): hipcc otherwise
+    // keeps all 128 accumulator registers in arch VGPRs next to two fragment sets whose 8-register tuples it cannot overlay and
+    // spills 35-45 registers to scratch (any scratch use costs a persistent kernel far more than it saves).  What the asm
+    // hides from the compiler is harmless here: the operands are ordinary compiler-loaded VGPRs (it waits for the ds_reads), every
+    // accumulator is used once per phase (dependent MFMAs are >= 8 instructions and a barrier apart), and the first reader of an
+    // accumulator outside the chain (the epilogue) sits behind a barrier and the next tile's set-up.
+    auto mfma_f16 = [](f32x4& c, const f16x8& x, const f16x8& y) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(x), "v"(y));
+    };
+    auto mma_hi = [&](int mh, const f16x8 (&af)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mfma_f16(acc[mh * 4 + i][j], b[j], af[i]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    const int sa_byte = 127 - MMS_H3_SA;
+    // the weight operand's scale byte J of `wscale` (op_sel / op_sel_hi bit 0 = low / high bit of the byte index), the activation operand's byte 0
+#define MX_MFMA(J, SEL) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " SEL : "+a"(acc[mh * 4 + i][nh * 2 + (J & 1)]) : "v"(lb[J & 1]), "v"(la[i]), "v"(wscale), "v"(sa_byte))
+    auto mma_lo = [&](auto mh_tag, auto nh_tag) {
+        constexpr int mh = decltype(mh_tag)::value, nh = decltype(nh_tag)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (nh == 0) { MX_MFMA(0, "op_sel_hi:[0,0,0]"); MX_MFMA(1, "op_sel:[1,0,0] op_sel_hi:[0,0,0]"); }
+            else { MX_MFMA(2, "op_sel_hi:[1,0,0]"); MX_MFMA(3, "op_sel:[1,0,0] op_sel_hi:[1,0,0]"); }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+#undef MX_MFMA
+
+    // one 32-k high stage = 2 phases of 16 MFMAs (rows 0-63 / 64-127 of the wave tile).  T = s % 4; PRE: stage s+2 exists and is issued here.
+    // ALL fragment reads of a stage sit in its first phase, so a slot's last read is >= 2 phases older than the first LDS-DMA piece that
+    // refills it (stage s+2 goes into the slot stage s-1 left) -- for the lagging wave row as well.  The super-stage's 8 low pieces ride in
+    // the phases (T0, B), (T1, A), (T1, B), (T2, A): the first one two phases after the low region's last reader (the first low-block
+    // phase of the previous super-stage that still reads is two barriers back for either row).  Issue order per phase: low pair, then
+    // high pair -- the last operation of every stage is a high piece, so the stage-end wait may leave exactly this stage's own issues
+    // in flight: 4 high pieces + 2 / 4 / 2 / 0 low ones.
+    auto hi_stage = [&](auto t_tag, int s, int slot) {
+        constexpr int T = decltype(t_tag)::value;
+        const bool pre = s + 2 < ns;                     // wave-uniform: ONE loop body for every super-stage (two specialised copies made
+                                                         // the compiler permute the accumulator registers through scratch where they met)
+        const unsigned char* sb = smem + slot * HSLOT;
+        const int nslot = slot == 0 ? 2 : slot - 1;      // the slot stage s-1 just left
+        constexpr int LO_A = !LOW ? -1 : T == 1 ? 2 : T == 2 ? 6 : -1;       // first low piece of the pair issued in phase A / B
+        constexpr int LO_B = !LOW ? -1 : T == 0 ? 0 : T == 1 ? 4 : -1;
+        // phase A
+        read_b(sb);
+        read_a(sb, 0, a);
+        if constexpr (LO_A >= 0) { issue_lo(LO_A, s >> 2); issue_lo(LO_A + 1, s >> 2); }
+        mx_barrier();
+        mma_hi(0, a);
+        mx_barrier();
+        // phase B
+        read_a(sb, 1, a);
+        if constexpr (LO_B >= 0) { issue_lo(LO_B, s >> 2); issue_lo(LO_B + 1, s >> 2); }
+        if (pre) {
+            issue_hi(0, s + 2, nslot); issue_hi(1, s + 2, nslot); issue_hi(2, s + 2, nslot); issue_hi(3, s + 2, nslot);
+            mx_wait_vmcnt<4>();
+        } else mx_wait_vmcnt<0>();                        // last two stages of a tile: everything (the low operands included) has landed
+        mx_barrier();
+        mma_hi(1, a);
+        mx_barrier();
+    };
+    auto lo_block = [&]() {
+        if constexpr (LOW) {
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            read_la(0); read_lb(0);
+            mx_barrier(); mma_lo(I0{}, I0{}); mx_barrier();
+            read_lb(1);
+            mx_barrier(); mma_lo(I0{}, I1{}); mx_barrier();
+            read_la(1);
+            mx_barrier(); mma_lo(I1{}, I1{}); mx_barrier();
+            read_lb(0);
+            mx_barrier(); mma_lo(I1{}, I0{}); mx_barrier();
+        }
+    };
+
+    auto first_stages = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_hi(q, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_hi(q, 1, 1);
+    };
+    first_stages();
+    mx_wait_vmcnt<4>();
+    mx_barrier();
+    if (wave >= NW / 2) mx_barrier();     // stagger the second wave row by one barrier
+
+    using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>; using T3 = std::integral_constant<int, 3>;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int slot = 0, s = 0;
+        auto nxt = [&]() { slot = slot == 2 ? 0 : slot + 1; ++s; };
+        for (int ss = 0; ss < nss; ++ss) {
+            hi_stage(T0{}, s, slot); nxt();
+            hi_stage(T1{}, s, slot); nxt();
+            hi_stage(T2{}, s, slot); nxt();
+            hi_stage(T3{}, s, slot); nxt();
+            lo_block();
+        }
+        if (wave < NW / 2) mx_barrier();     // re-align the two wave rows: nobody reads the LDS any more
+
+        // the workgroup's next tile: its first two high stages go out BEFORE this tile's stores (the epilogue needs no LDS); one full
+        // vmcnt(0) then covers both (gemm_pp.hip: stores and LDS-DMA loads share the counter)
+        const int row0 = bm * BM + wm * TM, col0 = bn * BN + wn * TN;
+        const int nvb = vb + (int)gridDim.x;
+        const bool more = nvb < nblk;
+        if (more) {
+            vb = nvb;
+            setup(vb);
+            first_stages();
+        }
+        pp_epilogue<ACT, FM, FN, true>(p, acc, row0, col0, lane, Meff);
+        if (!more) break;
+        mx_wait_vmcnt<0>();
+        mx_barrier();
+        if (wave >= NW / 2) mx_barrier();     // stagger again
+    }
+}
+
+static int mx_cu_count() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+                   ? prop.multiProcessorCount / 8 * 8 : 8;
+    }
+    return n_cu;
+}
+
+template <bool LOW>
+static void launch_mx(const GemmParams& p, hipStream_t st) {
+    const int nblk = ((p.M + 255) / 256) * (p.N / 256);
+    const dim3 grid(nblk > mx_cu_count() ? mx_cu_count() : nblk), block(512);
+    switch (p.act) {
+        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_mx_kernel<ACT_GELU_TANH, LOW>), grid, block, 0, st, p); break;
+        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_mx_kernel<ACT_GELU_ERF, LOW>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_mx_kernel<ACT_NONE, LOW>), grid, block, 0, st, p); break;
+    }
+}
+
+// any M (A rows allocated up to a multiple of 256), N % 256 == 0, K % 256 == 0 (two super-stages at least), identity row maps,
+// activation none / GELU
+bool launch_gemm_mx(const GemmParams& p, hipStream_t st) {
+    if (p.M <= 0) return true;
+    if (p.N % 256 || p.K % 256 || !p.a8 || !p.w8 || !p.w8_scale4 || !p.col_scale || p.a_index || p.amap.grp || p.r_hi) return false;
+    if (p.act != ACT_NONE && p.act != ACT_GELU_TANH && p.act != ACT_GELU_ERF) return false;
+    launch_mx<true>(p, st);
+    return true;
+}
+#ifdef MMS_LAB
+bool launch_gemm_mx_hi_only(const GemmParams& p, hipStream_t st) {       // lab: the high pass alone (timing reference)
+    if (p.M <= 0 || p.N % 256 || p.K % 256) return false;
+    launch_mx<false>(p, st);
+    return true;
+}
+#endif

@@ -28,27 +28,36 @@ __device__ __forceinline__ void pp_store_plane_pair(bf16* lane_row, int j, bf16x
     *reinterpret_cast<u32x4*>(lane_row + 64 * (j >> 1)) = v;
 }
 
-template <int ACT, int FM, int FN>
+// AGPR_ACC (gemm_mx.hip): the accumulators live in the accumulator half of the register file; an empty asm with an "+a" operand at the
+// top of every strip keeps the compiler from copying all 128 of them into arch VGPRs before the first strip (it has only 128 of those)
+template <int ACT, int FM, int FN, bool AGPR_ACC = false>
 __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int row0, int col0, int lane, int Meff) {
     const int mrow = lane & 15, nq = lane >> 4;
     const int col = col0 + nq * 4;                       // + 16 j
     f32x4 bias4[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.col_scale) {   // fp8 weights: the accumulator is in units of the weight row's quantisation scale
+    // fp8 / h3 weights: the accumulator is in units of the weight row's power-of-two quantisation scale.  Applied strip by strip (not to
+    // all accumulators up front): gemm_mx.hip keeps its accumulators in the AGPR half of the register file and only one strip of them
+    // should be in arch VGPRs at a time
+    const bool scaled = p.col_scale != nullptr;
+    f32x4 scale4[FN];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.col_scale + col + 16 * j);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) acc[i][j] *= s4;
-        }
-    }
+    for (int j = 0; j < FN; ++j) scale4[j] = scaled ? *reinterpret_cast<const f32x4*>(p.col_scale + col + 16 * j) : f32x4{1.f, 1.f, 1.f, 1.f};
     const bool f32_out = p.out_kind == OUT_F32, resid = p.r_hi != nullptr;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+        if constexpr (AGPR_ACC) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
+        }
         const int row = row0 + 16 * i + mrow;
         if (row >= Meff) continue;
         const long long orow = p.cmap(row);
+        if (scaled) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] *= scale4[j];
+        }
         if (resid) {
             const long long ro = (p.r_index ? (long long)p.r_index[row] : p.rmap(row)) * (long long)p.ldr + col;
 #pragma unroll
@@ -79,6 +88,30 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT);
                 *reinterpret_cast<f32x4*>(dst + 16 * j + (j >> 2) * head_step) = v;
+            }
+        } else if (p.out_kind == OUT_H3) {
+            // h3 operand planes (common.h), row-major: the same pairing of column fragments as the bf16 planes -- after the exchange a lane
+            // owns 8 consecutive columns: one 16-byte store of fp16 and one 8-byte store of e4m3 residuals per fragment pair
+            static_assert(FN % 2 == 0, "plane stores pair up column fragments");
+            const long long lrow = orow * p.ldh + col0 + 16 * (nq & 1) + 4 * (nq & 2);
+            f16* dh = p.c_h16 + lrow;
+            unsigned char* dl = p.c_l8 + lrow;
+#pragma unroll
+            for (int j = 0; j < FN; j += 2) {
+                f16x4 h[2];
+                unsigned l[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float v[4] = {apply_act(acc[i][j + jj][0], ACT), apply_act(acc[i][j + jj][1], ACT), apply_act(acc[i][j + jj][2], ACT),
+                                        apply_act(acc[i][j + jj][3], ACT)};
+                    split_h3(v, h[jj], l[jj]);
+                }
+                const pp_u32x2 x = __builtin_bit_cast(pp_u32x2, h[0]), y = __builtin_bit_cast(pp_u32x2, h[1]);
+                const auto r0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
+                *reinterpret_cast<u32x4*>(dh + 16 * j) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                const auto rl = __builtin_amdgcn_permlane16_swap(l[0], l[1], false, false);
+                *reinterpret_cast<pp_u32x2*>(dl + 16 * j) = pp_u32x2{rl[0], rl[1]};
             }
         } else if (p.out_kind == OUT_F8) {
             unsigned char* d8 = p.c_f8 + orow * p.ldf8 + col;

@@ -37,6 +37,12 @@ struct GemmParams {
     // fused bias + residual + LayerNorm epilogue (gemm_pp_ln.h; N == 768, rows of the residual = rows of the output): ln_gamma != nullptr
     // selects it.  Outputs: planes c_hi / c_lo (+ c_f8) when the launch runs fused, plain fp32 c_f32 when it falls back (then the
     // LayerNorm kernel queued behind the GEMM does the work; it skips itself when ln_ctl[1] == 1).
+    // precision mode 5 (gemm_mx.hip; h3 operands, common.h): a_hi = fp16 high plane [rows][lda] row-major (rows allocated up to a
+    // multiple of 256), a8 = e4m3 low plane [rows][lda]; w = fp16 weights (w * 2^e16[n]) in 16 x 32 tiles, w8 = e4m3 weights
+    // (w * 2^e8[n]) in 8-row x 128-byte tiles, w8_scale4 = per 64-channel group g and r < 16 one dword of e8m0 bytes
+    // {127 + e16 - e8 of channels 64 g + r, + 16, + 32, + 48}, col_scale[n] = 2^-e16[n].  OUT_H3 stores c_h16 / c_l8 [rows][ldh].
+    const unsigned char* a8; const unsigned char* w8; const unsigned* w8_scale4;
+    f16* c_h16; unsigned char* c_l8; int ldh;
     const float* ln_gamma; const float* ln_beta;
     float* ln_stats;             // [rows][3 tiles][2] 8-byte {value, tag} granules
     unsigned ln_tag;             // unique per launch
@@ -48,6 +54,10 @@ bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t 
 bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist = false);                     // gemm_pp.hip (variant 20: 256x256 ping-pong phases)
 bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm_pp.hip + gemm_pp_ln.h: N = 768 with the fused residual + LayerNorm epilogue (nsplit 2)
 bool launch_gemm_pp_f8(const GemmParams& p, hipStream_t st);                            // gemm_pp.hip with e4m3 operands (precision mode 4)
+#ifdef MMS_LAB
+bool launch_gemm_mx_hi_only(const GemmParams& p, hipStream_t st);                        // lab: timing reference, the high pass alone
+#endif
+bool launch_gemm_mx(const GemmParams& p, hipStream_t st);                                // gemm_mx.hip: precision mode 5, fp16 high pass + MX-scaled e4m3 low pass
 bool launch_gemm_ppw(const GemmParams& p, hipStream_t st);                               // gemm_ppw.hip: precision mode 3 (A and W split), 256x128 ping-pong phases
 void set_gemm_variant(int v);   // test hook, see gemm_dispatch.hip
 int get_gemm_variant();
@@ -179,6 +189,11 @@ void launch_corners(const float* boxes5, float* boxes4, long long B, hipStream_t
 void launch_merge4(const float* const probs[4], const float w[4], float* merged, float* members, long long n, hipStream_t st);
 void launch_xnorm(const bf16* hi, const bf16* lo, float* out, int rows, hipStream_t st);
 
+// precision mode 5 helpers (rowops.hip): h3 operand planes, weight copies of gemm_mx.hip (N % 64 == 0, K % 128 == 0)
+void launch_split_h3(const float* in, f16* o_h, unsigned char* o_l, long long n, hipStream_t st);
+void launch_planes_to_h3(const bf16* hi, const bf16* lo, f16* o_h, unsigned char* o_l, long long n, hipStream_t st);
+void launch_h3_to_f32(const f16* h, const unsigned char* l, float* out, long long n, hipStream_t st);
+void launch_prep_w_mx(const float* w, f16* w16, unsigned char* w8, unsigned* w8_scale4, float* col_scale, int N, int K, hipStream_t st);
 // precision mode 4 helpers (rowops.hip)
 void launch_planes_to_f8(const bf16* hi, const bf16* lo, unsigned char* out, long long n, hipStream_t st);
 void launch_f32_to_f8(const float* in, unsigned char* out, long long n, hipStream_t st);

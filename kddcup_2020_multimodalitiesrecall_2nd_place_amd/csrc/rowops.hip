@@ -254,6 +254,80 @@ void launch_quant_rows_f8(const float* w, unsigned char* out, float* scale, int 
     if (N > 0) hipLaunchKernelGGL(k_quant_rows_f8, row_grid(N), dim3(256), 0, st, w, out, scale, N, K);
 }
 
+// ---- precision mode 5: h3 operand planes (common.h) and the weight copies of gemm_mx.hip ----
+__global__ __launch_bounds__(256) void k_split_h3(const float* in, f16* o_h, unsigned* o_l, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 f = reinterpret_cast<const float4*>(in)[i];
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        f16x4 h; unsigned l;
+        split_h3(v, h, l);
+        reinterpret_cast<f16x4*>(o_h)[i] = h;
+        o_l[i] = l;
+    }
+}
+void launch_split_h3(const float* in, f16* o_h, unsigned char* o_l, long long n, hipStream_t st) {
+    const long long n4 = n / 4;
+    if (n4 > 0) hipLaunchKernelGGL(k_split_h3, dim3((unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256)), dim3(256), 0, st, in, o_h, (unsigned*)o_l, n4);
+}
+__global__ __launch_bounds__(256) void k_planes_to_h3(const bf16* hi, const bf16* lo, f16* o_h, unsigned* o_l, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>(plane_ptr(hi, i * 4));
+        const bf16x4 c = *reinterpret_cast<const bf16x4*>(plane_ptr(lo, i * 4));
+        const float v[4] = {join_bf16(a[0], c[0]), join_bf16(a[1], c[1]), join_bf16(a[2], c[2]), join_bf16(a[3], c[3])};
+        f16x4 h; unsigned l;
+        split_h3(v, h, l);
+        reinterpret_cast<f16x4*>(o_h)[i] = h;
+        o_l[i] = l;
+    }
+}
+void launch_planes_to_h3(const bf16* hi, const bf16* lo, f16* o_h, unsigned char* o_l, long long n, hipStream_t st) {
+    const long long n4 = n / 4;
+    if (n4 > 0) hipLaunchKernelGGL(k_planes_to_h3, dim3((unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256)), dim3(256), 0, st, hi, lo, o_h, (unsigned*)o_l, n4);
+}
+__global__ __launch_bounds__(256) void k_h3_to_f32(const f16* h, const unsigned char* l, float* out, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (float)h[i] + e4m3_to_f32(l[i]) * (1.0f / (float)(1 << MMS_H3_SA));
+}
+void launch_h3_to_f32(const f16* h, const unsigned char* l, float* out, long long n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_h3_to_f32, dim3((unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256)), dim3(256), 0, st, h, l, out, n);
+}
+// one wavefront per weight row n of W[N][K] (fp32, bf16-exact values): m = max|w|.
+//   w16 = fp16(w 2^e16), e16 the exponent that puts m into [2^13, 2^14): exact for every bf16 weight down to 2^-28 m; 16 x 32 tiles (wtile_off)
+//   w8  = e4m3(w 2^-e),  2^e the smallest power of two with m / 2^e <= 448 (as launch_quant_rows_f8);           8-row x 128-byte tiles
+//   scale byte (e8m0) = 127 + e16 + e: the MX low pass then accumulates in the high pass's units; col_scale = 2^-e16 brings both back
+__global__ __launch_bounds__(256) void k_prep_w_mx(const float* w, f16* w16, unsigned char* w8, unsigned char* scale_bytes, float* col_scale, int N, int K) {
+    const int row = wave_row();
+    if (row >= N) return;
+    const float* src = w + (long long)row * K;
+    float m = 0.f;
+    for (int k = lane_id() * 4; k < K; k += 256) {
+        const float4 f = *reinterpret_cast<const float4*>(src + k);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    int ex = 0;
+    const float fr = frexpf(m, &ex);                       // m = fr * 2^ex, fr in [0.5, 1)
+    const int e16 = m > 0.f ? 14 - ex : 0;
+    const int e = m > 0.f ? (fr <= 0.875f ? ex - 9 : ex - 8) : 0;
+    const float s16 = ldexpf(1.0f, e16), s8 = ldexpf(1.0f, -e);
+    if (lane_id() == 0) {
+        col_scale[row] = ldexpf(1.0f, -e16);
+        scale_bytes[(((row >> 6) * 16 + (row & 15)) << 2) + ((row >> 4) & 3)] = (unsigned char)(127 + e16 + e);
+    }
+    for (int k = lane_id() * 4; k < K; k += 256) {
+        const float4 f = *reinterpret_cast<const float4*>(src + k);
+        f16x4 h;
+        h[0] = (f16)(f.x * s16); h[1] = (f16)(f.y * s16); h[2] = (f16)(f.z * s16); h[3] = (f16)(f.w * s16);
+        *reinterpret_cast<f16x4*>(w16 + wtile_off(row, k, K)) = h;
+        *reinterpret_cast<unsigned*>(w8 + (((long long)(row >> 3) * (K >> 7) + (k >> 7)) << 10) + ((row & 7) << 7) + (k & 127)) =
+            pack4_f8(f.x * s8, f.y * s8, f.z * s8, f.w * s8);
+    }
+}
+void launch_prep_w_mx(const float* w, f16* w16, unsigned char* w8, unsigned* w8_scale4, float* col_scale, int N, int K, hipStream_t st) {
+    if (N > 0) hipLaunchKernelGGL(k_prep_w_mx, row_grid(N), dim3(256), 0, st, w, w16, w8, (unsigned char*)w8_scale4, col_scale, N, K);
+}
+
 __global__ __launch_bounds__(256) void k_mean8(const float* in, float* out, int U) {
     const int row = wave_row();
     if (row >= U) return;

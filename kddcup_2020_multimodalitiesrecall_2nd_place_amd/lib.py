@@ -62,7 +62,7 @@ ABI_VERSION = 3     # include/mmscore.h MMS_ABI_VERSION
 
 EXPORTS = ("mms_version", "mms_global_error", "mms_create", "mms_destroy", "mms_last_error", "mms_load_weight",
            "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_score_ensemble", "mms_gemm_timing",
-           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_ln", "mms_dbg_attention", "mms_dbg_layernorm", "mms_set_gemm_variant",
+           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_mx", "mms_dbg_gemm_ln", "mms_dbg_attention", "mms_dbg_layernorm", "mms_set_gemm_variant",
            "mms_dbg_gemm_bench")
 
 _lib = None
@@ -98,6 +98,7 @@ def load(path=None):
     lib.mms_score_lxmert.argtypes = [vp, C.POINTER(LxmertBatch), vp, vp, vp]
     lib.mms_score_ensemble.argtypes = [vp, vp, vp, C.POINTER(EnsembleBatch), C.POINTER(C.c_float), vp, vp, vp]
     lib.mms_dbg_gemm_f8.argtypes = [vp, i64, i64, vp, i64, vp, i32, i32, vp, vp]
+    lib.mms_dbg_gemm_mx.argtypes = [vp, i64, i64, vp, i64, vp, i32, i32, vp, vp]
     lib.mms_dbg_gemm_ln.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, i32, vp, C.POINTER(i32), vp]
     lib.mms_gemm_timing.argtypes = [vp, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.mms_debug_read_x.argtypes = [vp, vp, i64, vp]
