@@ -31,11 +31,11 @@ struct Planes {
     Planes at(long long elem_off) const { Planes p; p.hi = hi + 2 * elem_off; p.lo = lo + 2 * elem_off; p.f8 = f8 ? f8 + elem_off : nullptr; return p; }
 };
 
-// *8 / *s: e4m3 copy of the matrix and its per-output-channel scales (precision mode 4 only)
-struct AttW { bf16* wqkv; float* bqkv; bf16* wo; float* bo; float* g; float* b; unsigned char* wqkv8 = nullptr; float* wqkvs = nullptr;
-              unsigned char* wo8 = nullptr; float* wos = nullptr; };
-struct FfnW { bf16* wi; float* bi; bf16* wd; float* bd; float* g; float* b; unsigned char* wi8 = nullptr; float* wis = nullptr;
-              unsigned char* wd8 = nullptr; float* wds = nullptr; };
+// *8 / *s: e4m3 copy of the matrix (8 x 128-byte tiles) and its per-output-channel scales as packed e8m0 bytes (precision mode 4 only)
+struct AttW { bf16* wqkv; float* bqkv; bf16* wo; float* bo; float* g; float* b; unsigned char* wqkv8 = nullptr; unsigned* wqkvs = nullptr;
+              unsigned char* wo8 = nullptr; unsigned* wos = nullptr; };
+struct FfnW { bf16* wi; float* bi; bf16* wd; float* bd; float* g; float* b; unsigned char* wi8 = nullptr; unsigned* wis = nullptr;
+              unsigned char* wd8 = nullptr; unsigned* wds = nullptr; };
 struct LayerW { AttW att; FfnW ffn; };
 struct XLayerW { AttW cross, lang_self, visn_self; FfnW lang_ffn, visn_ffn; };
 
@@ -226,7 +226,7 @@ int upload_mat(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, bf16**
 }
 // precision mode 4: e4m3 copy [N][K] of the same sources + one power-of-two scale per output channel (quantised on the device:
 // launch_quant_rows_f8, the routine mms_dbg_gemm_f8 exposes to the kernel tests)
-int upload_mat_f8(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, unsigned char** out, float** scale) {
+int upload_mat_f8(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, unsigned char** out, unsigned** scale) {
     int64_t N = 0;
     for (auto& s : srcs) N += s.n;
     std::vector<float> buf((size_t)(N * K));
@@ -242,17 +242,18 @@ int upload_mat_f8(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, uns
     void *q = nullptr, *sc = nullptr;
     int rc = e == hipSuccess ? MMS_OK : h->fail(MMS_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
     if (!rc) rc = dev_alloc(h, h->w_allocs, &q, (size_t)(N * K));
-    if (!rc) rc = dev_alloc(h, h->w_allocs, &sc, (size_t)N * 4);
+    if (!rc && (N % 64 || K % 128)) rc = h->fail(MMS_ERR_WEIGHT, "fp8 GEMM weight matrix must have N % 64 == 0 and K % 128 == 0");
+    if (!rc) rc = dev_alloc(h, h->w_allocs, &sc, (size_t)N);
     if (!rc) {
-        launch_quant_rows_f8(tmp, (unsigned char*)q, (float*)sc, (int)N, (int)K, 0);
+        launch_quant_rows_f8(tmp, (unsigned char*)q, nullptr, (unsigned*)sc, (int)N, (int)K, 0);
         e = hipDeviceSynchronize();
         if (e != hipSuccess) rc = h->fail(MMS_ERR_HIP, std::string("quantise weights: ") + hipGetErrorString(e));
     }
     (void)hipFree(tmp);
-    *out = (unsigned char*)q; *scale = (float*)sc;
+    *out = (unsigned char*)q; *scale = (unsigned*)sc;
     return rc;
 }
-int mat_f8(mms_handle* h, const std::string& name, int64_t N, int64_t K, bool in_out, unsigned char** out, float** scale) {
+int mat_f8(mms_handle* h, const std::string& name, int64_t N, int64_t K, bool in_out, unsigned char** out, unsigned** scale) {
     const HostTensor* t = find(h, name);
     if (!t) return h->fail(MMS_ERR_WEIGHT, "missing weight: " + name);
     return upload_mat_f8(h, {{t->data.data(), N, in_out}}, K, out, scale);
@@ -449,13 +450,14 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     if (int rc = alloc_planes(h, h->ws_allocs, &h->y, rows * H)) return rc;
     if (int rc = alloc_planes(h, h->ws_allocs, &h->mid, mid_elems)) return rc;
     if (h->f8) {   // e4m3 copies of the GEMM A operands (x / y: LayerNorm outputs, ctx: attention output, mid: FFN intermediate)
-        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * H)) return rc;
+        // + 256 rows: gemm_mx8_kernel fetches whole 256-row panels (rows past the live count are multiplied and discarded, never clamped)
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(rows + 256) * H)) return rc;
         h->x.f8 = (unsigned char*)p;
-        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * H)) return rc;
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(rows + 256) * H)) return rc;
         h->y.f8 = (unsigned char*)p;
-        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * H)) return rc;
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(rows + 256) * H)) return rc;
         h->ctx.f8 = (unsigned char*)p;
-        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)mid_rows * c.inter)) return rc;
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(mid_rows + 256) * c.inter)) return rc;
         h->mid.f8 = (unsigned char*)p;
     }
     if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)rows * 3 * H * 4)) return rc;
@@ -559,15 +561,16 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     return MMS_OK;
 }
 
-// precision mode 4: C = act((A8 W8^T) * scale[n] + bias) on e4m3 operands; out: fp32 (out.f32) or e4m3 bytes (out.pl.f8)
-int gemm_f8(mms_handle* h, hipStream_t st, const unsigned char* a8, int lda, const unsigned char* w8, const float* wscale,
+// precision mode 4: C = act((A8 W8^T) * scale[n] + bias) on e4m3 operands, MX-scaled fp8 MFMA with the per-channel weight scale as the
+// weight operand's hardware scale (gemm_mx.hip gemm_mx8_kernel); out: fp32 (out.f32) or e4m3 bytes (out.pl.f8).  a8 rows must be readable
+// up to the next multiple of 256 (the workspace pads its byte planes)
+int gemm_f8(mms_handle* h, hipStream_t st, const unsigned char* a8, int lda, const unsigned char* w8, const unsigned* wscale4,
             const float* bias, int64_t M, int N, int K, int act, const GemmOut& out, const int* m_dev) {
     if (M <= 0) return MMS_OK;
-    if (N % 256 || K % 128 || lda % 2) return h->fail(MMS_ERR_ARG, "gemm_f8: N % 256, K % 128 or odd lda");
+    if (N % 256 || K % 128) return h->fail(MMS_ERR_ARG, "gemm_f8: N % 256 or K % 128");
     GemmParams p{};
-    p.f8 = 1;
-    p.a_hi = (const bf16*)a8; p.a_lo = p.a_hi; p.lda = lda / 2; p.amap = RowMap{0, 0, 0};
-    p.w = (const bf16*)w8; p.bias = bias; p.col_scale = wscale; p.M = (int)M; p.N = N; p.K = K / 2;
+    p.a8 = a8; p.lda = lda; p.amap = RowMap{0, 0, 0};
+    p.w8 = w8; p.w8_scale4 = wscale4; p.bias = bias; p.M = (int)M; p.N = N; p.K = K;
     p.act = act;
     if (out.f32) { p.out_kind = OUT_F32; p.c_f32 = out.f32; p.ldc = out.ldc; p.hm_rows = out.hm_rows; p.hm_col0 = out.hm_col0; }
     else { p.out_kind = OUT_F8; p.c_f8 = out.pl.f8; p.ldf8 = out.ldp; }
@@ -582,11 +585,11 @@ int gemm_f8(mms_handle* h, hipStream_t st, const unsigned char* a8, int lda, con
         }
         p.flop_counter = h->flop_counter;
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
-        if (!launch_gemm_pp_f8(p, st)) return h->fail(MMS_ERR_ARG, "gemm_f8: shape not supported");
+        if (!launch_gemm_mx8(p, st)) return h->fail(MMS_ERR_ARG, "gemm_f8: shape not supported");
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
         h->ev_used += 2;
         h->gemm_launches += 1;
-    } else if (!launch_gemm_pp_f8(p, st)) return h->fail(MMS_ERR_ARG, "gemm_f8: shape not supported");
+    } else if (!launch_gemm_mx8(p, st)) return h->fail(MMS_ERR_ARG, "gemm_f8: shape not supported");
     return MMS_OK;
 }
 
@@ -596,18 +599,15 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
 // out = LayerNorm(A W^T + bias + resid) for the N = 768 projections, the LayerNorm fused into the GEMM epilogue when the launch is big
 // enough for the persistent ping-pong engine (gemm_pp_ln.h).  Returns MMS_OK with *fused = false when the caller has to take the
 // two-kernel route itself (small M, precision modes 1 / 3, no control slot left).
-int gemm_ln(mms_handle* h, hipStream_t st, bool f8, const Planes& a, int lda, const bf16* w, const unsigned char* w8, const float* wscale,
+int gemm_ln(mms_handle* h, hipStream_t st, bool f8, const Planes& a, int lda, const bf16* w, const unsigned char* w8, const unsigned* wscale,
             const float* bias, int64_t M, int K, const Planes& resid, const float* g, const float* b, const Planes& out, float* t,
             const int* m_dev, bool* fused) {
     *fused = false;
     if (!h->fuse_ln || f8 || M < 16384 || h->nsplit != 2 || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
-    if (f8 ? (K % 128 != 0) : (K % 64 != 0)) return MMS_OK;
+    if (K % 64 != 0) return MMS_OK;
+    (void)w8; (void)wscale;          // the fp8 mode always takes the two-kernel route (f8 returned above)
     GemmParams p{};
-    if (f8) {
-        p.f8 = 1; p.a_hi = (const bf16*)a.f8; p.a_lo = p.a_hi; p.lda = lda / 2; p.w = (const bf16*)w8; p.col_scale = wscale; p.K = K / 2;
-    } else {
-        p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.w = w; p.K = K;
-    }
+    p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.w = w; p.K = K;
     p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
     p.bias = bias; p.M = (int)M; p.N = H; p.act = ACT_NONE;
     p.r_hi = resid.hi; p.r_lo = resid.lo; p.ldr = H;
@@ -1581,26 +1581,27 @@ int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32
                     int32_t out_f8, float* c_f32, void* stream) {
     if (!a_f32 || !w_f32_nk || !c_f32 || M <= 0 || N % 256 || K % 128) { g_err = "mms_dbg_gemm_f8: bad argument (N % 256, K % 128)"; return MMS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
+    const int64_t Mp = (M + 255) / 256 * 256;
     unsigned char *a8 = nullptr, *w8 = nullptr, *c8 = nullptr;
-    float* ws = nullptr;
-    DBG_TRY(hipMalloc((void**)&a8, (size_t)M * K));
+    unsigned* ws4 = nullptr;
+    DBG_TRY(hipMalloc((void**)&a8, (size_t)Mp * K));
+    DBG_TRY(hipMemsetAsync(a8, 0, (size_t)Mp * K, st));
     DBG_TRY(hipMalloc((void**)&w8, (size_t)N * K));
-    DBG_TRY(hipMalloc((void**)&ws, (size_t)N * 4));
+    DBG_TRY(hipMalloc((void**)&ws4, (size_t)N));
     launch_f32_to_f8(a_f32, a8, M * K, st);
-    launch_quant_rows_f8(w_f32_nk, w8, ws, (int)N, (int)K, st);
+    launch_quant_rows_f8(w_f32_nk, w8, nullptr, ws4, (int)N, (int)K, st);
     GemmParams p{};
-    p.f8 = 1;
-    p.a_hi = (const bf16*)a8; p.a_lo = p.a_hi; p.lda = (int)(K / 2); p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
-    p.w = (const bf16*)w8; p.col_scale = ws; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)(K / 2); p.act = act;
+    p.a8 = a8; p.lda = (int)K; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
+    p.w8 = w8; p.w8_scale4 = ws4; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
     if (out_f8) {
         DBG_TRY(hipMalloc((void**)&c8, (size_t)M * N));
         p.out_kind = OUT_F8; p.c_f8 = c8; p.ldf8 = (int)N;
     } else { p.out_kind = OUT_F32; p.c_f32 = c_f32; p.ldc = (int)N; }
-    if (!launch_gemm_pp_f8(p, st)) { g_err = "mms_dbg_gemm_f8: shape not supported"; return MMS_ERR_ARG; }
+    if (!launch_gemm_mx8(p, st)) { g_err = "mms_dbg_gemm_f8: shape not supported"; return MMS_ERR_ARG; }
     if (out_f8) launch_f8_to_f32(c8, c_f32, M * N, st);
     DBG_TRY(hipStreamSynchronize(st));
     DBG_TRY(hipGetLastError());
-    (void)hipFree(a8); (void)hipFree(w8); (void)hipFree(ws); (void)hipFree(c8);
+    (void)hipFree(a8); (void)hipFree(w8); (void)hipFree(ws4); (void)hipFree(c8);
     return MMS_OK;
 }
 
@@ -1658,14 +1659,8 @@ int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32
     launch_tile_weights(w_f32_nk, wp, wp + N * K, N, K, st);
     launch_split_f32(resid_f32, rp, rp + MMS_PLANE_LO, M * N, st);
     GemmParams p{};
-    if (f8) {
-        DBG_TRY(hipMalloc((void**)&a8, (size_t)M * K)); DBG_TRY(hipMalloc((void**)&w8, (size_t)N * K)); DBG_TRY(hipMalloc((void**)&ws, (size_t)N * 4));
-        launch_f32_to_f8(a_f32, a8, M * K, st);
-        launch_quant_rows_f8(w_f32_nk, w8, ws, (int)N, (int)K, st);
-        p.f8 = 1; p.a_hi = (const bf16*)a8; p.a_lo = p.a_hi; p.lda = (int)(K / 2); p.w = (const bf16*)w8; p.col_scale = ws; p.K = (int)(K / 2);
-    } else {
-        p.a_hi = ap; p.a_lo = ap + MMS_PLANE_LO; p.lda = (int)K; p.w = wp; p.K = (int)K;
-    }
+    if (f8) { g_err = "mms_dbg_gemm_ln: the fused LayerNorm epilogue exists for the bf16 two-pass engine only"; return MMS_ERR_ARG; }
+    p.a_hi = ap; p.a_lo = ap + MMS_PLANE_LO; p.lda = (int)K; p.w = wp; p.K = (int)K;
     p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
     p.bias = bias; p.M = (int)M; p.N = (int)N; p.act = ACT_NONE;
     p.r_hi = rp; p.r_lo = rp + MMS_PLANE_LO; p.ldr = (int)N;
@@ -1740,8 +1735,18 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     unsigned* ws4 = nullptr;
     float* cs = nullptr;
     GemmParams pm{};
-    const bool mx = variant == 50 || variant == 51;
-    if (mx) {
+    const bool mx = variant == 50 || variant == 51 || variant == 52;      // 52: precision mode 4 (gemm_mx8_kernel, e4m3 x e4m3)
+    if (variant == 52) {
+        if (N % 256 || K % 128 || resid) { g_err = "mms_dbg_gemm_bench: mx8 engine needs N % 256 == 0, K % 128 == 0, no residual"; return MMS_ERR_ARG; }
+        const int64_t Mp = (M + 255) / 256 * 256;
+        DBG_TRY(hipMalloc((void**)&a8, (size_t)Mp * K)); DBG_TRY(hipMemset(a8, 0, (size_t)Mp * K));
+        DBG_TRY(hipMalloc((void**)&w8, (size_t)N * K)); DBG_TRY(hipMalloc((void**)&ws4, (size_t)N)); DBG_TRY(hipMalloc((void**)&c8, (size_t)M * N));
+        launch_f32_to_f8(af, a8, M * K, 0);
+        launch_quant_rows_f8(wf, w8, nullptr, ws4, (int)N, (int)K, 0);
+        pm = p;
+        pm.a8 = a8; pm.w8 = w8; pm.w8_scale4 = ws4; pm.w_lo = nullptr;
+        if (out_planes) { pm.out_kind = OUT_F8; pm.c_f8 = c8; pm.ldf8 = (int)N; }
+    } else if (mx) {
         if (N % 256 || K % 256 || resid) { g_err = "mms_dbg_gemm_bench: mx engine needs N % 256 == 0, K % 256 == 0, no residual"; return MMS_ERR_ARG; }
         const int64_t Mp = (M + 255) / 256 * 256;
         DBG_TRY(hipMalloc((void**)&a16, (size_t)Mp * K * 2)); DBG_TRY(hipMalloc((void**)&a8, (size_t)Mp * K));
@@ -1760,6 +1765,7 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
 #ifdef MMS_LAB
         if (variant == 51) return launch_gemm_mx_hi_only(pm, 0);
 #endif
+        if (variant == 52) return launch_gemm_mx8(pm, 0);
         return launch_gemm_mx(pm, 0);
     };
     if (!run()) { g_err = "mms_dbg_gemm_bench: variant not available"; return MMS_ERR_ARG; }

@@ -275,6 +275,161 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(const GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Precision mode 4 GEMM: e4m3 x e4m3 on the MX-scaled instruction alone -- v_mfma_scale_f32_16x16x128_f8f6f4 runs at TWICE the rate of
+// the non-scaled v_mfma_f32_16x16x32_fp8_fp8 the round-2 fp8 path used (which is the bf16 rate).  Same tile, wave grid, ping-pong
+// stagger, persistent loop and epilogue as above; no high pass, so the LDS holds TWO 64-KiB operand regions (A8 [256][128 B] +
+// W8 [256][128 B] of one 128-k super-stage each) and a super-stage is 4 phases of 8 MX MFMAs (one 64x32 quadrant each, 256 cycles).
+// Operands: A8 = e4m3 activation bytes [rows][lda] row-major (as the round-2 mode produces them); W8 = e4m3(w / scale[n]) in 8-row x
+// 128-byte tiles; the per-channel power-of-two weight scale rides in the instruction's hardware scale of the weight operand
+// (w8_scale4 bytes = 127 + log2 scale[n]); the activation operand's hardware scale is 2^0.
+// Prefetch: the A quarters of super-stage ss+1 are issued in phases 1-2 of super-stage ss (their region's last readers were phases 1 / 3
+// of ss-1), the W quarters of super-stage ss+2 in phases 3-4 (all four W fragments of a super-stage are read in ITS phase 1, so the W
+// half of the current region is free again two phases later): W runs two super-stages ahead, A one.  Counted waits: end of phase 4
+// `vmcnt(6)` (everything but the six pieces issued since this super-stage's phase 1 -> A rows 0-63 and W of ss+1 have landed), end of
+// phase 2 `vmcnt(8)` (-> A rows 64-127 of the running super-stage).
+template <int ACT>
+__global__ __launch_bounds__(512) void gemm_mx8_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 256, NW = 8, WAVES_N = 4, TM = 128, TN = 64, FM = 8, FN = 4;
+    constexpr int LPLANE = 256 * 128, REGION = 2 * LPLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * REGION];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    int Meff = p.M;
+    if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
+    if (p.flop_counter && blockIdx.x == 0 && tid == 0)
+        atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
+    const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM, nblk = nbm * nbn;
+    int vb = blockIdx.x;
+    if (vb >= nblk) return;
+
+    const long long lda = p.lda, K = p.K;
+    const unsigned char* a8_src; const unsigned char* w8_src;
+    unsigned wscale = 0;
+    int bm, bn;
+    const int rl = wave * 8 + (lane >> 3), cl = ((lane & 7) ^ ((rl >> 1) & 7)) * 16;
+    auto setup = [&](int v) {
+        const int q = nblk >> 3, r8 = nblk & 7, xcd = v & 7, loc = v >> 3;
+        int bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+        if (p.reverse) bid = nblk - 1 - bid;
+        bm = bid / nbn; bn = bid % nbn;
+        a8_src = p.a8 + (long long)(bm * BM + rl) * lda + cl;
+        const int n = bn * BN + rl;
+        w8_src = p.w8 + ((long long)(n >> 3) * (K >> 7)) * 1024 + (n & 7) * 128 + cl;
+        wscale = p.w8_scale4[(bn * BN + wn * TN) / 4 + (lane & 15)];
+    };
+    setup(vb);
+    auto issue_a = [&](int q, int ss) {                   // A8 row quarter q of super-stage ss -> region ss & 1
+        unsigned char* d = smem + (ss & 1) * REGION + q * 8192 + wave * 1024;
+        __builtin_amdgcn_global_load_lds((glb_void*)(a8_src + (long long)q * 64 * lda + ss * 128), (lds_void*)d, 16, 0, 0);
+    };
+    auto issue_w = [&](int q, int ss) {
+        unsigned char* d = smem + (ss & 1) * REGION + LPLANE + q * 8192 + wave * 1024;
+        __builtin_amdgcn_global_load_lds((glb_void*)(w8_src + (long long)q * 64 * K + ss * 1024), (lds_void*)d, 16, 0, 0);
+    };
+
+    f32x4 acc[FM][FN];
+    const int nss = p.K / 128;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int c0 = (fk ^ ((fr >> 1) & 7)) << 4;
+    const int loA0 = (wm * TM + fr) * 128 + c0, loA1 = loA0 ^ 64, loB0 = LPLANE + (wn * TN + fr) * 128 + c0, loB1 = loB0 ^ 64;
+    i32x8 la[4], lb[4];
+    auto read_lo = [&](const unsigned char* rb, int off0, int off1, int imm, i32x8& dst) {
+        const i32x4 x = *reinterpret_cast<const i32x4*>(rb + off0 + imm);
+        const i32x4 y = *reinterpret_cast<const i32x4*>(rb + off1 + imm);
+        dst = i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    };
+    auto read_la = [&](const unsigned char* rb, int mh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) read_lo(rb, loA0, loA1, (mh * 64 + i * 16) * 128, la[i]);
+    };
+    auto read_lb = [&](const unsigned char* rb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) read_lo(rb, loB0, loB1, j * 16 * 128, lb[j]);
+    };
+    const int one_byte = 127;
+#define MX8_MFMA(J, SEL) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " SEL : "+a"(acc[mh * 4 + i][J]) : "v"(lb[J]), "v"(la[i]), "v"(wscale), "v"(one_byte))
+    auto mma = [&](auto mh_tag, auto nh_tag) {
+        constexpr int mh = decltype(mh_tag)::value, nh = decltype(nh_tag)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (nh == 0) { MX8_MFMA(0, "op_sel_hi:[0,0,0]"); MX8_MFMA(1, "op_sel:[1,0,0] op_sel_hi:[0,0,0]"); }
+            else { MX8_MFMA(2, "op_sel_hi:[1,0,0]"); MX8_MFMA(3, "op_sel:[1,0,0] op_sel_hi:[1,0,0]"); }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+#undef MX8_MFMA
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+
+    // prologue of a tile: W of super-stages 0 and 1, A of super-stage 0; wait for A(0) rows 0-63, W(0) [A(0) rows 64-127: phase 2's wait]
+    auto first_stages = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_w(q, 0);
+        issue_a(0, 0); issue_a(2, 0);
+        if (nss > 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) issue_w(q, 1);
+        }
+        issue_a(1, 0); issue_a(3, 0);
+    };
+    first_stages();
+    if (nss > 1) mx_wait_vmcnt<6>(); else mx_wait_vmcnt<2>();
+    mx_barrier();
+    if (wave >= NW / 2) mx_barrier();
+
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ss = 0; ss < nss; ++ss) {
+            const unsigned char* rb = smem + (ss & 1) * REGION;
+            const bool pa = ss + 1 < nss, pw = ss + 2 < nss;          // wave-uniform
+            // phase 1: (A rows 0-63, W columns 0-31); all four W fragments are read here
+            read_la(rb, 0); read_lb(rb);
+            if (pa) { issue_a(0, ss + 1); issue_a(2, ss + 1); }
+            mx_barrier(); mma(I0{}, I0{}); mx_barrier();
+            // phase 2: (A rows 0-63, W columns 32-63)
+            if (pa) { issue_a(1, ss + 1); issue_a(3, ss + 1); }
+            // A(ss) rows 64-127 (read next phase) must have landed; younger than them: the pieces of phases 3-4 of ss-1 and 1-2 of ss
+            if (ss == 0) { if (pa) mx_wait_vmcnt<4>(); else mx_wait_vmcnt<0>(); }      // first super-stage of a tile: they closed the prologue
+            else if (pa) mx_wait_vmcnt<8>();
+            else mx_wait_vmcnt<0>();                                  // last super-stage: nothing was issued since (ss-1 had no W left to fetch)
+            mx_barrier(); mma(I0{}, I1{}); mx_barrier();
+            // phase 3: (A rows 64-127, W columns 32-63)
+            read_la(rb, 1);
+            if (pw) { issue_w(0, ss + 2); issue_w(1, ss + 2); }
+            mx_barrier(); mma(I1{}, I1{}); mx_barrier();
+            // phase 4: (A rows 64-127, W columns 0-31)
+            if (pw) { issue_w(2, ss + 2); issue_w(3, ss + 2); }
+            if (pw) mx_wait_vmcnt<6>();                               // A(ss+1) rows 0-63 and W(ss+1) landed
+            else if (pa) mx_wait_vmcnt<2>();                          // no W issued in this super-stage: only A(ss+1) rows 64-127 may be in flight
+            else mx_wait_vmcnt<0>();
+            mx_barrier(); mma(I1{}, I0{}); mx_barrier();
+        }
+        if (wave < NW / 2) mx_barrier();
+
+        const int row0 = bm * BM + wm * TM, col0 = bn * BN + wn * TN;
+        const int nvb = vb + (int)gridDim.x;
+        const bool more = nvb < nblk;
+        if (more) {
+            vb = nvb;
+            setup(vb);
+            first_stages();
+        }
+        pp_epilogue<ACT, FM, FN, true>(p, acc, row0, col0, lane, Meff);
+        if (!more) break;
+        mx_wait_vmcnt<0>();
+        mx_barrier();
+        if (wave >= NW / 2) mx_barrier();
+    }
+}
+
 static int mx_cu_count() {
     static int n_cu = 0;
     if (!n_cu) {
@@ -304,6 +459,20 @@ bool launch_gemm_mx(const GemmParams& p, hipStream_t st) {
     if (p.N % 256 || p.K % 256 || !p.a8 || !p.w8 || !p.w8_scale4 || !p.col_scale || p.a_index || p.amap.grp || p.r_hi) return false;
     if (p.act != ACT_NONE && p.act != ACT_GELU_TANH && p.act != ACT_GELU_ERF) return false;
     launch_mx<true>(p, st);
+    return true;
+}
+// precision mode 4 on the MX-scaled instruction: any M (A8 rows allocated up to a multiple of 256), N % 256 == 0, K % 128 == 0 (bytes)
+bool launch_gemm_mx8(const GemmParams& p, hipStream_t st) {
+    if (p.M <= 0) return true;
+    if (p.N % 256 || p.K % 128 || !p.a8 || !p.w8 || !p.w8_scale4 || p.a_index || p.amap.grp || p.r_hi) return false;
+    const int nblk = ((p.M + 255) / 256) * (p.N / 256);
+    const dim3 grid(nblk > mx_cu_count() ? mx_cu_count() : nblk), block(512);
+    switch (p.act) {
+        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_mx8_kernel<ACT_GELU_TANH>), grid, block, 0, st, p); break;
+        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_mx8_kernel<ACT_GELU_ERF>), grid, block, 0, st, p); break;
+        case ACT_NONE: hipLaunchKernelGGL((gemm_mx8_kernel<ACT_NONE>), grid, block, 0, st, p); break;
+        default: return false;
+    }
     return true;
 }
 #ifdef MMS_LAB

@@ -73,13 +73,11 @@ __device__ __forceinline__ void pp_barrier() {
 
 // DIAG (timing diagnostics only, results WRONG): bit 0 drops the phase barriers, bit 1 the in-loop LDS-DMA issue, bit 2 the in-loop ds_reads,
 // bit 3 re-reads the first two K-stages (always cache hits)
-// F8 (precision mode 4): the A and W planes hold e4m3 bytes -- a 64-byte stage row is 64 k-values instead of 32 -- and every
-// fragment pair feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (the low and the high 8 bytes of the ds_read_b128; the k order inside the
-// contraction is the same permutation in both operands).  Staging, ring, phases and epilogue are the bf16 engine's.
+// (Precision mode 4 ran here on the non-scaled v_mfma_f32_16x16x32_fp8_fp8 in round 2; it now runs on the MX-scaled instruction at
+// twice that rate in gemm_mx.hip.)
 // LNF: N == 768 with the fused bias + residual + LayerNorm epilogue of gemm_pp_ln.h (persistent launches only).
-template <int NSPLIT, int ACT, int DIAG, bool PERSIST, bool F8 = false, bool LNF = false>
+template <int NSPLIT, int ACT, int DIAG, bool PERSIST, bool LNF = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
-    static_assert(!F8 || NSPLIT == 1, "fp8 operands are single-plane");
     static_assert(!LNF || (PERSIST && ACT == ACT_NONE && DIAG == 0), "the LayerNorm epilogue belongs to the persistent, activation-free kernel");
     constexpr int BM = 256, BN = 256, NW = 8, WAVES_N = LNF ? 4 : MMS_PP_WN, WAVES_M = NW / WAVES_N;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, FM = TM / 16, FN = TN / 16, HM = FM / 2, HN = FN / 2;     // HM x HN fragments per phase
@@ -101,7 +99,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     int Meff = p.M;
     if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
     if (!(DIAG & 32) && p.flop_counter && blockIdx.x == 0 && tid == 0)
-        atomicAdd(p.flop_counter, (F8 ? 4ull : 2ull) * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
+        atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
     if (LNF && tid == 0) atomicAdd(&p.ln_ctl[0], 1);     // check-in: "this workgroup is resident" (gemm_pp_ln.h)
     const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM;
     // LNF: whole row panels per XCD (the three tiles of a panel exchange row statistics), so the virtual index space is
@@ -121,8 +119,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     // piece h (0/1) = rows h*128 + wave*16 + lane/4, physical chunk lane%4 <- logical chunk (lane%4) ^ pp_swz(row).
     constexpr bool A2 = NSPLIT == 2;
     constexpr int NAP = A2 ? 4 : 2;                 // A pieces per wave and stage
-    constexpr int ASTEP = F8 ? 32 : 64;             // 2-byte elements between two K stages of an A row (hl32: a hi and a lo block per stage)
-    constexpr int WSTEP = F8 ? 32 : 512;            // ... of a W row (bf16 weights: one 1-KiB tile per stage; e4m3 bytes: row-major)
+    constexpr int ASTEP = 64;                       // elements between two K stages of an A row (hl32: a hi and a lo block per stage)
+    constexpr int WSTEP = 512;                      // ... of a W row (one 1-KiB tile per stage)
     const int gr_l = lane >> 2, gc = lane & 3;
     const bf16* a_src[NAP];
     const bf16* w_src[2];
@@ -144,7 +142,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
             int gr = bm * BM + r;
             gr = gr < Meff ? gr : Meff - 1;
             const long long lrow = (p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda;
-            return p.a_hi + (F8 ? lrow : 2 * lrow);
+            return p.a_hi + 2 * lrow;
         };
         if constexpr (A2) {
 #pragma unroll
@@ -162,7 +160,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = h * 128 + wave * 16 + gr_l;
-            w_src[h] = p.w + (F8 ? (long long)(bn * BN + r) * p.K : wtile_off(bn * BN + r, 0, p.K)) + (gc ^ pp_swz(r)) * 8;
+            w_src[h] = p.w + wtile_off(bn * BN + r, 0, p.K) + (gc ^ pp_swz(r)) * 8;
         }
     };
     setup(vb);
@@ -214,12 +212,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
             for (int i = 0; i < HM; ++i)
 #pragma unroll
                 for (int j = 0; j < HN; ++j) {
-                    if constexpr (F8) {
-                        typedef __attribute__((ext_vector_type(2))) long i64x2;
-                        const i64x2 bw = __builtin_bit_cast(i64x2, b[j]), aw = __builtin_bit_cast(i64x2, a[pl][i]);
-                        acc[mh * HM + i][nh * HN + j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bw[0], aw[0], acc[mh * HM + i][nh * HN + j], 0, 0, 0);
-                        acc[mh * HM + i][nh * HN + j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bw[1], aw[1], acc[mh * HM + i][nh * HN + j], 0, 0, 0);
-                    } else
                     acc[mh * HM + i][nh * HN + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[pl][i], acc[mh * HM + i][nh * HN + j], 0, 0, 0);   // swapped: C^T fragment
                 }
         __builtin_amdgcn_s_setprio(0);
@@ -316,19 +308,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
                 }
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    f32x4 add = f32x4{0.f, 0.f, 0.f, 0.f}, inv = f32x4{1.f, 1.f, 1.f, 1.f};
+                    f32x4 add = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (pl == 0 && p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + cbase + 16 * j);
-                    if constexpr (F8) {
-                        const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.col_scale + cbase + 16 * j);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) inv[e] = __frcp_rn(s4[e]);
-                    }
 #pragma unroll
                     for (int i = 0; i < RB; ++i)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float v = (float)t[i][j][e] + add[e];
-                            if constexpr (F8) v *= inv[e];
                             acc[ih + i][j][e] = pl ? acc[ih + i][j][e] + v : v;
                         }
                 }
@@ -429,16 +415,16 @@ static int pp_cu_count() {
     return n_cu;
 }
 
-template <int NSPLIT, int DIAG, bool PERSIST = false, bool F8 = false>
+template <int NSPLIT, int DIAG, bool PERSIST = false>
 static void launch_pp_ns(const GemmParams& p, hipStream_t st) {
     const int nblk = ((p.M + 255) / 256) * (p.N / 256);
     const dim3 grid(PERSIST && nblk > pp_cu_count() ? pp_cu_count() : nblk), block(512);
     switch (p.act) {
-        case ACT_RELU: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_RELU, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
-        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_TANH, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
-        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_ERF, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
-        case ACT_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_TANH, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_NONE, DIAG, PERSIST, F8>), grid, block, 0, st, p); break;
+        case ACT_RELU: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_RELU, DIAG, PERSIST>), grid, block, 0, st, p); break;
+        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_TANH, DIAG, PERSIST>), grid, block, 0, st, p); break;
+        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_GELU_ERF, DIAG, PERSIST>), grid, block, 0, st, p); break;
+        case ACT_TANH: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_TANH, DIAG, PERSIST>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, ACT_NONE, DIAG, PERSIST>), grid, block, 0, st, p); break;
     }
 }
 
@@ -454,18 +440,8 @@ bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st) {
     const int per_xcd = (pp_cu_count() / 8) / 3 * 3;
     const int full = per_xcd > 0 ? 8 * per_xcd : 24;
     const dim3 grid(nvirt > full ? full : nvirt), block(512);
-    // two-pass bf16 planes only: the e4m3 instantiation does not fit the 256-register budget without scratch, and scratch makes the
-    // dispatch slow enough for the residency check to time out now and then (results then flip between the two routes' round-off)
-    if (p.f8 || nsplit != 2) return false;
-    hipLaunchKernelGGL((gemm_pp_kernel<2, ACT_NONE, 0, true, false, true>), grid, block, 0, st, p);
-    return true;
-}
-
-// precision mode 4: e4m3 operands (p.f8 set; p.lda / p.K in byte PAIRS), any M, N % 256 == 0, K (in fp8 elements) % 128 == 0
-bool launch_gemm_pp_f8(const GemmParams& p, hipStream_t st) {
-    if (p.M <= 0) return true;
-    if (!p.f8 || p.N % 256 || p.K % 64) return false;
-    launch_pp_ns<1, 0, true, true>(p, st);
+    if (nsplit != 2) return false;      // two-pass bf16 planes only
+    hipLaunchKernelGGL((gemm_pp_kernel<2, ACT_NONE, 0, true, true>), grid, block, 0, st, p);
     return true;
 }
 

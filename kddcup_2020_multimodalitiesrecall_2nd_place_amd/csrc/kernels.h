@@ -53,10 +53,10 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
 bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist = false);                     // gemm_pp.hip (variant 20: 256x256 ping-pong phases)
 bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm_pp.hip + gemm_pp_ln.h: N = 768 with the fused residual + LayerNorm epilogue (nsplit 2)
-bool launch_gemm_pp_f8(const GemmParams& p, hipStream_t st);                            // gemm_pp.hip with e4m3 operands (precision mode 4)
 #ifdef MMS_LAB
 bool launch_gemm_mx_hi_only(const GemmParams& p, hipStream_t st);                        // lab: timing reference, the high pass alone
 #endif
+bool launch_gemm_mx8(const GemmParams& p, hipStream_t st);                               // gemm_mx.hip: precision mode 4 on the MX-scaled fp8 instruction
 bool launch_gemm_mx(const GemmParams& p, hipStream_t st);                                // gemm_mx.hip: precision mode 5, fp16 high pass + MX-scaled e4m3 low pass
 bool launch_gemm_ppw(const GemmParams& p, hipStream_t st);                               // gemm_ppw.hip: precision mode 3 (A and W split), 256x128 ping-pong phases
 void set_gemm_variant(int v);   // test hook, see gemm_dispatch.hip
@@ -198,5 +198,6 @@ void launch_prep_w_mx(const float* w, f16* w16, unsigned char* w8, unsigned* w8_
 void launch_planes_to_f8(const bf16* hi, const bf16* lo, unsigned char* out, long long n, hipStream_t st);
 void launch_f32_to_f8(const float* in, unsigned char* out, long long n, hipStream_t st);
 void launch_f8_to_f32(const unsigned char* in, float* out, long long n, hipStream_t st);
-// weight rows [N][K] fp32 -> e4m3 bytes + one power-of-two scale per row: the smallest 2^e with max|w| / 2^e <= 448
-void launch_quant_rows_f8(const float* w, unsigned char* out, float* scale, int N, int K, hipStream_t st);
+// weight rows [N][K] fp32 (N % 64 == 0, K % 128 == 0) -> e4m3 bytes in 8 x 128-byte tiles + one power-of-two scale per row (the smallest
+// 2^e with max|w| / 2^e <= 448) as e8m0 bytes packed for gemm_mx8_kernel (scale4) and, optionally, as fp32 (scale)
+void launch_quant_rows_f8(const float* w, unsigned char* out, float* scale, unsigned* scale4, int N, int K, hipStream_t st);

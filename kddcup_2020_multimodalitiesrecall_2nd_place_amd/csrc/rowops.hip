@@ -229,7 +229,10 @@ void launch_f8_to_f32(const unsigned char* in, float* out, long long n, hipStrea
     if (n > 0) hipLaunchKernelGGL(k_f8_to_f32, dim3((unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256)), dim3(256), 0, st, in, out, n);
 }
 // one wavefront per weight row: scale = the smallest power of two with max|w| / scale <= 448 (division by it is exact), bytes = e4m3(w / scale)
-__global__ __launch_bounds__(256) void k_quant_rows_f8(const float* w, unsigned char* out, float* scale, int N, int K) {
+// in 8-row x 128-byte tiles [N/8][K/128][8][128] (one LDS-DMA piece of gemm_mx8_kernel = 1 KiB of one tile), scale4 = the e8m0 byte
+// 127 + log2(scale) of every channel, four per dword: {channels 64 g + r, + 16, + 32, + 48} at dword 16 g + r (the hardware scale of the MX
+// instruction's weight operand); scale[n] = the same scale as fp32 (tests, tools)
+__global__ __launch_bounds__(256) void k_quant_rows_f8(const float* w, unsigned char* out, float* scale, unsigned char* scale_bytes, int N, int K) {
     const int row = wave_row();
     if (row >= N) return;
     const float* src = w + (long long)row * K;
@@ -244,14 +247,18 @@ __global__ __launch_bounds__(256) void k_quant_rows_f8(const float* w, unsigned 
     const float fr = frexpf(m, &ex);                       // m = fr * 2^ex, fr in [0.5, 1); 448 = 0.875 * 2^9
     const int e = m > 0.f ? (fr <= 0.875f ? ex - 9 : ex - 8) : 0;
     const float inv = ldexpf(1.0f, -e);
-    if (lane_id() == 0) scale[row] = ldexpf(1.0f, e);
+    if (lane_id() == 0) {
+        if (scale) scale[row] = ldexpf(1.0f, e);
+        scale_bytes[(((row >> 6) * 16 + (row & 15)) << 2) + ((row >> 4) & 3)] = (unsigned char)(127 + e);
+    }
     for (int k = lane_id() * 4; k < K; k += 256) {
         const float4 f = *reinterpret_cast<const float4*>(src + k);
-        *reinterpret_cast<unsigned*>(out + (long long)row * K + k) = pack4_f8(f.x * inv, f.y * inv, f.z * inv, f.w * inv);
+        *reinterpret_cast<unsigned*>(out + (((long long)(row >> 3) * (K >> 7) + (k >> 7)) << 10) + ((row & 7) << 7) + (k & 127)) =
+            pack4_f8(f.x * inv, f.y * inv, f.z * inv, f.w * inv);
     }
 }
-void launch_quant_rows_f8(const float* w, unsigned char* out, float* scale, int N, int K, hipStream_t st) {
-    if (N > 0) hipLaunchKernelGGL(k_quant_rows_f8, row_grid(N), dim3(256), 0, st, w, out, scale, N, K);
+void launch_quant_rows_f8(const float* w, unsigned char* out, float* scale, unsigned* scale4, int N, int K, hipStream_t st) {
+    if (N > 0) hipLaunchKernelGGL(k_quant_rows_f8, row_grid(N), dim3(256), 0, st, w, out, scale, (unsigned char*)scale4, N, K);
 }
 
 // ---- precision mode 5: h3 operand planes (common.h) and the weight copies of gemm_mx.hip ----

@@ -62,8 +62,13 @@ def ensemble_main(rank, world):
         checks = {"scores_bitwise": bool(torch.equal(all_s, ref)), "max_score_diff": float((all_s - ref).abs().max()),
                   "query_ids": bool(np.array_equal(all_q.numpy(), whole.query_id)), "product_ids": bool(np.array_equal(all_p.numpy(), whole.product_id)),
                   "submission_rows": rows == rows_ref, "n_rows": len(rows)}
-        n_kept = sum(len(v) for v in E.uniqueness_filter({str(int(q)): {} for q in []}).values())        # (empty table: 0)
-        ok = all(v for k, v in checks.items() if k not in ("max_score_diff", "n_rows")) and 0 < len(rows) <= NQ and n_kept == 0
+        # the filter must have had work to do: fewer surviving (query, product) entries than pairs
+        tab = OrderedDict()
+        for q, p_, m_ in zip(whole.query_id, whole.product_id, ref.numpy()):
+            tab.setdefault(str(int(q)), OrderedDict())[str(int(p_))] = float(m_)
+        n_kept = sum(len(v) for v in E.uniqueness_filter(tab).values())
+        checks["filter_dropped"] = int(whole.n) - n_kept
+        ok = all(v for k, v in checks.items() if k not in ("max_score_diff", "n_rows", "filter_dropped")) and 0 < len(rows) <= NQ and n_kept < whole.n
         json.dump({"ok": ok, "pairs": int(whole.n), "counts": counts, "queries": len(rows), "checks": checks}, open(sys.argv[1], "w"))
     ens.close()
     dist.destroy_process_group()
