@@ -39,13 +39,15 @@ from kddcup_2020_multimodalitiesrecall_2nd_place_amd import scorers, sharding, s
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd.config import (FEAT_DIM, N_BOX, LdsConfig, LxmertConfig,  # noqa: E402
                                                                     ZkConfig, flops_per_pair)
 
-PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (non-scaled fp8 MFMA runs at the same rate)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0   # dense MX-scaled fp8 MFMA peak (same guide): what precision mode 4's GEMMs are priced against
 BASELINE_FLOPS = {"zk": 5.174e9, "lds": 6.886e9, "lxmert": 6.829e9}
 CFGS = {"zk": ZkConfig, "lds": LdsConfig, "lxmert": LxmertConfig}
 DTYPES = {1: "bf16 MFMA operands, 1 pass (weights bf16; activations bf16)",
           2: "bf16 MFMA operands (weights bf16; activations split hi+lo bf16, 2 passes), fp32 accumulate/residual/LN/softmax",
           3: "bf16 MFMA operands (weights and activations split hi+lo bf16, 3 passes), fp32 accumulate/residual/LN/softmax",
-          4: "fp8 e4m3 MFMA operands on the encoder GEMMs (weights: per-channel scale; activations fp8), rest as mode 2"}
+          4: "fp8 e4m3 MFMA operands on the encoder GEMMs, MX-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (weights: per-channel hardware scale; "
+             "activations e4m3), rest as mode 2"}
 
 
 def device_feats(ps, device, seed):
@@ -325,7 +327,8 @@ def main():
             traffic_src = "profiles/pmc_traffic_%s.json (builder's rocprofv3 --pmc run of this workload, FETCH_SIZE x 2 + WRITE_SIZE; not re-measured here)" % a.model
         avg_launch_s = gemm_ms * 1e-3 / max(gemm_n, 1)
         kern = {1: "gemm_pp_kernel<1,*,0,true> 256x256 ping-pong phases, persistent", 2: "gemm_pp_kernel<2,*,0,true> 256x256 ping-pong phases, persistent",
-                3: "gemm_ppw_kernel<*> 256x128 ping-pong phases, 3 passes", 4: "gemm_pp_kernel<1,*,0,true,fp8> 256x256 ping-pong phases on e4m3 operands"}[a.precision]
+                3: "gemm_ppw_kernel<*> 256x128 ping-pong phases, 3 passes", 4: "gemm_mx8_kernel<*> 256x256 ping-pong phases, 128-k super-stages of MX-scaled fp8 MFMAs"}[a.precision]
+        peak = PEAK_FP8_TFLOPS if a.precision == 4 else PEAK_BF16_TFLOPS
         res = {
             "metric": "query-image pairs scored/sec (whole node)", "value": round(value, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -344,14 +347,14 @@ def main():
             # a utilisation; roofline.achieved below counts executed FLOPs only.
             "reference_graph_tflops_per_gpu": round(value / world * fpp / 1e12, 2),
             "roofline": {"bound": "mfma", "kernel": kern + " (all dense contractions; small GEMMs: gemm_tile_kernel)",
-                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          # the second resource of the same launches: traffic / 6.3 TB/s (achievable HBM rate, MI355X_MICROARCH.md) over the
                          # average launch -- MFMA issue time and this add up to most of a launch
                          "hbm_time_frac": round(traffic / 6.3e12 / avg_launch_s, 4) if traffic and avg_launch_s > 0 else None,
                          # SURVEY.md section 8(d)'s literal accounting: pairs/s x the PADDED reference graph's FLOPs per pair / peak.  Token packing
                          # skips the padded rows, so this is an equivalent rate of the reference graph, not a utilisation of this chip
-                         "frac_reference_graph": round(value / world * fpp / 1e12 / PEAK_BF16_TFLOPS, 4),
+                         "frac_reference_graph": round(value / world * fpp / 1e12 / peak, 4),
                          "launches": int(gemm_n), "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                          "algorithmic_flops_per_launch": round(gemm_fl / max(gemm_n, 1), 1),
                          "note": "achieved = sum over GEMM launches of executed 2*M_live*N*K (device-counted) / sum of hipEvent "

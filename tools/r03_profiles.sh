@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage (GPU box): tools/r02_profiles.sh <tag>   -- the evidence set behind DESIGN.md section 6: bench lines, rocprofv3 kernel stats of the
+# usage (GPU box): tools/r03_profiles.sh <tag>   -- the evidence set behind DESIGN.md section 6: bench lines, rocprofv3 kernel stats of the
 # same commands, PMC HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes) for the three models.  Everything lands in gpurun_out/<tag>/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-T=${1:-r02}
+T=${1:-r03}
 O=$R/gpurun_out/$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -12,6 +12,10 @@ done
 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 python $R/bench.py --model ensemble --no-cpu --no-secondary > $O/bench_ensemble.json 2> $O/bench_ensemble.err
 python $R/bench.py --precision 4 --no-cpu --no-secondary > $O/bench_zk_fp8.json 2> $O/bench_zk_fp8.err
+python $R/bench.py --model ensemble --precision 4 --no-cpu --no-secondary > $O/bench_ensemble_fp8.json 2> $O/bench_ensemble_fp8.err
+python $R/bench.py --workload valid --no-cpu --no-secondary > $O/bench_zk_valid.json 2> $O/bench_zk_valid.err
+python $R/bench.py --fuse-ln --no-cpu --no-secondary > $O/bench_zk_fuseln.json 2> $O/bench_zk_fuseln.err
+MMS_BENCH_SHARE_GPU=1 MMS_BENCH_BACKEND=gloo python $R/bench.py --gpus 2 --no-cpu > $O/bench_zk_2ranks_shared_gpu.json 2> $O/bench_zk_2ranks_shared_gpu.err
 python $R/bench.py --workload testB --no-cpu --no-secondary > $O/bench_zk_testB.json 2> $O/bench_zk_testB.err
 for m in zk ensemble; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -o $m -- python $R/bench.py --model $m --steps 3 --warmup 1 --no-cpu --no-secondary > $O/prof_$m.log 2>&1
@@ -22,5 +26,6 @@ for m in zk lds lxmert; do
   $R/tools/pmc_traffic.sh $m --model $m --no-secondary > $O/pmc_traffic_$m.log 2>&1
   cp $R/gpurun_out/pmc/${m}_traffic.json $O/pmc_traffic_$m.json
 done
+$R/tools/pmc_mfma_busy.sh zk > $O/mfma_busy_zk.log 2>&1; cp $R/gpurun_out/pmc/zk_mfma_busy.json $O/mfma_busy_zk.json 2>/dev/null
 rm -rf $R/gpurun_out/pmc
 ls -la $O
