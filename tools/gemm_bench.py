@@ -19,7 +19,7 @@ SHAPES = [  # name, N, K, act, planes, resid
 if os.environ.get("GB_SHAPES"):   # "name,N,K,act,planes,resid;..."
     SHAPES = [(f[0],) + tuple(int(x) for x in f[1:]) for f in (t.split(",") for t in os.environ["GB_SHAPES"].split(";"))]
 NSPLITS = [int(x) for x in os.environ.get("GB_NSPLIT", "2,1").split(",")]
-l = lib.load(lib.LAB_LIB_PATH)   # lab build: `make -C kddcup_2020_multimodalitiesrecall_2nd_place_amd/csrc lab`
+l = lib.load(os.environ.get("MMS_LAB_LIB", lib.LAB_LIB_PATH))   # lab build: `make -C kddcup_2020_multimodalitiesrecall_2nd_place_amd/csrc lab`; MMS_LAB_LIB = another lab build
 variants = [int(v) for v in sys.argv[1:]] or [26, 16, 4, 50, 52]    # 26 persistent ping-pong, 16 / 4 register-staged tiles, 50 fp16 + MX low pass, 52 MX fp8
 for nsplit in NSPLITS:
     for name, N, K, act, planes, resid in SHAPES:
