@@ -22,6 +22,16 @@
  *     the caller owns every input/output buffer, the handle owns weights and workspace.
  *   - one handle per GPU/stream; calls on one handle must be serialised by the caller; kernels are
  *     enqueued asynchronously on the hipStream_t passed as `stream` (NULL = default stream).
+ *     Host synchronisation points inside a scoring call (each a 4-byte device->host read + hipStreamSynchronize of `stream`):
+ *       * dense label ids (uniq_label_ids == NULL): the count of distinct label tuples, once per call;
+ *       * lxmert / ensemble with pack_tokens = 1 and >= 2 pairs: the count of distinct (input_ids, input_mask) rows, once per call
+ *         -- ALSO when the caller passes uniq_label_ids (the language layers run once per distinct query, api.hip lx_query_stage);
+ *       * ensemble: the per-wave counts of pairs whose query the sen2forest rewrite changed, once per call;
+ *       * a workspace that has to grow (first call, or a larger batch than any before) allocates, which synchronises the device.
+ *     A zk / lds call with de-duplicated labels on a warmed-up handle is fully asynchronous.
+ *     Memory: the workspace is sized for the largest launch wave seen (<= chunk_pairs pairs, ~1 MB per pair); lxmert additionally
+ *     keeps the language rows of the distinct queries of the largest BATCH seen (Q x text_len x 768 x 4 bytes, Q <= B / 2) outside
+ *     the per-wave workspace; nothing shrinks before mms_destroy.
  *   - integer dtypes are the reference feed dtypes (zk: int32 ids, int64 labels; lds/lxmert: int64).
  *   - the library reads no environment variable (A/B knobs and timing-only diagnostics live in the separate lab build,
  *     csrc/Makefile `make lab`, which the package never loads).
@@ -182,8 +192,9 @@ int mms_debug_read_x(mms_handle* h, float* dst_dev, int64_t rows, void* stream);
 int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const float* w_f32_nk, int64_t N,
                  const float* bias, const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes,
                  float* c_f32, void* stream);
-/* fp8 GEMM (precision 4) on fp32 operands: A and W are quantised exactly as the forward does it (A: e4m3 RNE of the value;
- * W: per-output-channel scale max|w|/448, e4m3 RNE of w/scale) */
+/* fp8 GEMM (precision 4, MX-scaled fp8 MFMA) on fp32 operands: A and W are quantised exactly as the forward does it (A: e4m3 RNE of the
+ * value; W: per output channel the smallest POWER OF TWO scale with max|w| / scale <= 448, e4m3 RNE of w / scale; the scale is applied
+ * by the MFMA instruction itself as the weight operand's e8m0 hardware scale).  N % 256 == 0, K % 128 == 0 */
 int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, int64_t N, const float* bias, int32_t act,
                     int32_t out_f8, float* c_f32, void* stream);
 /* precision-5 GEMM (gemm_mx.hip: fp16 high pass + MX-scaled e4m3 low pass) on fp32 operands, N % 256 == 0, K % 256 == 0; A is split into

@@ -105,7 +105,7 @@ struct mms_handle {
     int32_t* dd_uniq32 = nullptr; int64_t* dd_uniq64 = nullptr;
     // lxmert distinct-query stage: the language stream of the first l_layers runs once per distinct (input_ids, input_mask)
     // row; lq_store holds its output rows, dense by (query, token), for the pair chunks to copy from
-    std::vector<void*> lq_allocs;
+    std::vector<void*> lq_allocs, lq_sub_allocs;      // lq_sub_allocs: the two sub-batch gather buffers (replaced, not piled up, when they grow)
     int64_t lq_pairs = 0, lq_store_q = 0, lq_sub = 0;
     int *lq_slots = nullptr, *lq_rep = nullptr, *lq_uid = nullptr, *lq_counter = nullptr, *lq_rows_of = nullptr, *lq_index = nullptr;
     int lq_cap = 0;
@@ -113,7 +113,7 @@ struct mms_handle {
     Planes lq_store;
     bool lq_active = false;
     // fused three-model entry point: feed conversions and member outputs, sized for ens_pairs
-    std::vector<void*> ens_allocs;
+    std::vector<void*> ens_allocs, ens_c_allocs;      // ens_c_allocs: the changed-query buffers of the second zk member (replaced when they grow)
     int64_t ens_pairs = 0;
     int32_t* ens_seg = nullptr; int64_t *ens_ids64 = nullptr, *ens_seg64 = nullptr, *ens_lab64 = nullptr, *ens_mask64 = nullptr;
     float *ens_vmask = nullptr, *ens_boxes4 = nullptr, *ens_logits = nullptr, *ens_probs = nullptr, *ens_tok = nullptr;
@@ -1009,6 +1009,7 @@ int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int
     const int T = c.text_len;
     if (B > h->lq_pairs) {
         free_pool(h->lq_allocs);
+        free_pool(h->lq_sub_allocs);
         h->lq_pairs = 0; h->lq_store_q = 0; h->lq_sub = 0;
         int cap = 1024;
         while (cap < 2 * B) cap <<= 1;
@@ -1039,9 +1040,10 @@ int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int
     }
     if (cs > h->lq_sub) {                               // gathered inputs of one sub-batch of distinct queries
         void* p;
-        if (int rc = dev_alloc(h, h->lq_allocs, &p, (size_t)cs * T * 8)) return rc;
+        free_pool(h->lq_sub_allocs);                    // hipFree waits for the work that may still read the old pair
+        if (int rc = dev_alloc(h, h->lq_sub_allocs, &p, (size_t)cs * T * 8)) return rc;
         h->lq_ids = (int64_t*)p;
-        if (int rc = dev_alloc(h, h->lq_allocs, &p, (size_t)cs * T * 8)) return rc;
+        if (int rc = dev_alloc(h, h->lq_sub_allocs, &p, (size_t)cs * T * 8)) return rc;
         h->lq_mask = (int64_t*)p;
         h->lq_sub = cs;
     }
@@ -1239,7 +1241,9 @@ void mms_destroy(mms_handle* h) {
     free_pool(h->lab_allocs);
     free_pool(h->dd_allocs);
     free_pool(h->ens_allocs);
+    free_pool(h->ens_c_allocs);
     free_pool(h->lq_allocs);
+    free_pool(h->lq_sub_allocs);
     if (h->lq_store.hi) (void)hipFree(h->lq_store.hi);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     delete h;
@@ -1349,6 +1353,7 @@ int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, fl
 static int ensure_ens_ws(mms_handle* z, int64_t B, int T, int TL) {
     if (B <= z->ens_pairs) return MMS_OK;
     free_pool(z->ens_allocs);
+    free_pool(z->ens_c_allocs);
     z->ens_pairs = 0;
     void* p;
     auto get = [&](size_t bytes, void** out) { int rc = dev_alloc(z, z->ens_allocs, &p, bytes); *out = p; return rc; };
@@ -1455,20 +1460,21 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
         for (int v : changed) need = v > need ? v : need;
         if (need > z->ens_cpairs) {
             void* p;
+            free_pool(z->ens_c_allocs);
             const int S = T + MMS_NBOX; (void)S;
-            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * T * 4)) return rc;
+            if (int rc = dev_alloc(z, z->ens_c_allocs, &p, (size_t)need * T * 4)) return rc;
             z->ens_cq = (int32_t*)p;
-            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * 4)) return rc;
+            if (int rc = dev_alloc(z, z->ens_c_allocs, &p, (size_t)need * 4)) return rc;
             z->ens_clen = (int32_t*)p;
-            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * 4)) return rc;
+            if (int rc = dev_alloc(z, z->ens_c_allocs, &p, (size_t)need * 4)) return rc;
             z->ens_cnb = (int32_t*)p;
-            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * 8)) return rc;
+            if (int rc = dev_alloc(z, z->ens_c_allocs, &p, (size_t)need * 8)) return rc;
             z->ens_clab = (int64_t*)p;
-            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * MMS_NBOX * H * 4)) return rc;
+            if (int rc = dev_alloc(z, z->ens_c_allocs, &p, (size_t)need * MMS_NBOX * H * 4)) return rc;
             z->ens_ctok = (float*)p;
-            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * 2 * 4)) return rc;
+            if (int rc = dev_alloc(z, z->ens_c_allocs, &p, (size_t)need * 2 * 4)) return rc;
             z->ens_clog = (float*)p;
-            if (int rc = dev_alloc(z, z->ens_allocs, &p, (size_t)need * 2 * 4)) return rc;
+            if (int rc = dev_alloc(z, z->ens_c_allocs, &p, (size_t)need * 2 * 4)) return rc;
             z->ens_cprob = (float*)p;
             z->ens_cpairs = need;
         }

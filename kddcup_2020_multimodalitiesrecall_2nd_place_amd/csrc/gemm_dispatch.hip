@@ -38,7 +38,7 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
 #ifdef MMS_LAB
     if (variant > 100) {   // timing diagnostics (201-232 ping-pong): WRONG results on purpose, only with MMS_GEMM_DIAG
         static const bool diag_ok = getenv("MMS_GEMM_DIAG") != nullptr;
-        if (diag_ok && variant > 200 && variant < 233 && launch_gemm_pp(p, nsplit, variant - 200, st)) return;
+        if (diag_ok && variant > 200 && (variant < 233 || variant == 264) && launch_gemm_pp(p, nsplit, variant - 200, st)) return;
         variant = 99;
     }
 #endif

@@ -92,16 +92,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     static_assert(NSLOT >= 3 && NSLOT * SLOT <= 160 * 1024 && (D - 1) * P < 64, "ring must fit the LDS and the vmcnt counter");
     constexpr int EPI_BYTES = NW * 16 * (TN + 4) * 4;
     static_assert(NSLOT * SLOT >= EPI_BYTES, "epilogue strip must fit in the ring");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * SLOT];
+    // DIAG 64 (lab): per-phase barrier stamps of waves 0 and 4 of workgroup 0's first tile, kept in 8 KiB of LDS behind the ring (stores to
+    // global memory would sit in vmcnt and disturb the counted LDS-DMA waits) and dumped after the tile: tools/pp_phase.py
+    constexpr int STAMP_BYTES = (DIAG & 64) ? 8192 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * SLOT + STAMP_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    int stamp_i = 0;
+    const bool stamping = (DIAG & 64) && blockIdx.x == 0 && (tid == 0 || tid == 256);
+    auto stamp = [&]() {
+        if constexpr ((DIAG & 64) != 0) {
+            if (stamping && stamp_i < 512) { reinterpret_cast<unsigned long long*>(smem + NSLOT * SLOT)[(tid >> 8) * 512 + stamp_i] = __builtin_readcyclecounter(); ++stamp_i; }
+        }
+    };
 
     const unsigned long long tr0 = (DIAG & 32) ? wall_clock64() : 0;      // DIAG 32: per-workgroup timeline (100 MHz ticks) into p.flop_counter
     int Meff = p.M;
     if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
-    if (!(DIAG & 32) && p.flop_counter && blockIdx.x == 0 && tid == 0)
+    if (!(DIAG & 96) && p.flop_counter && blockIdx.x == 0 && tid == 0)
         atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
     if (LNF && tid == 0) atomicAdd(&p.ln_ctl[0], 1);     // check-in: "this workgroup is resident" (gemm_pp_ln.h)
     const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM;
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         const unsigned char* sb = smem + slot * SLOT;
         const int nslot = slot == 0 ? NSLOT - 1 : slot - 1;     // (slot + D) % NSLOT: the slot stage s-1 just left
         constexpr bool DMA = PRE && !(DIAG & 2), RD = !(DIAG & 4);
-        auto bar = [&]() { if (DIAG & 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } else pp_barrier(); };
+        auto bar = [&]() { stamp(); if (DIAG & 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } else pp_barrier(); stamp(); };
         // LDS-DMA pieces of stage s+D: two per phase in phases 1-3 (other placements measured no better, profiles/r01c_gemm_variants.txt)
         auto dma = [&](int ph) {
             if (!DMA) return;
@@ -409,6 +419,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
             else pp_epilogue_plain_f32<FM, FN>(p, acc, row0, col0, lane, Meff);   // the LayerNorm kernel behind this launch finishes the job
         } else
         pp_epilogue<ACT, FM, FN>(p, acc, row0, col0, lane, Meff);
+        if ((DIAG & 64) && stamping && p.flop_counter) {
+            unsigned long long* out = p.flop_counter + (tid >> 8) * 512;
+            for (int i = 0; i < 512; ++i) out[i] = i < stamp_i ? reinterpret_cast<unsigned long long*>(smem + NSLOT * SLOT)[(tid >> 8) * 512 + i] : 0ull;
+            stamp_i = 512;       // first tile only
+        }
         if ((DIAG & 32) && tid == 0 && p.flop_counter) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // epilogue stores acknowledged
             unsigned long long* t = p.flop_counter + 5ull * blockIdx.x;
@@ -487,6 +502,19 @@ bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, b
                 (void)hipMemcpy(h.data(), buf, (size_t)nblk * 40, hipMemcpyDeviceToHost);
                 (void)hipFree(buf);
                 if (FILE* f = fopen("/tmp/pp_trace.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+                break;
+            }
+            case 64: {   // phase stamps: /tmp/pp_phase.bin = 2 x 512 u64 shader-clock stamps (wave 0, wave 4) of workgroup 0's first tile
+                unsigned long long* buf = nullptr;
+                if (hipMalloc(&buf, 8192) != hipSuccess) return false;
+                (void)hipMemsetAsync(buf, 0, 8192, st);
+                GemmParams q = p; q.flop_counter = buf;
+                launch_pp_ns<2, 64, true>(q, st);
+                std::vector<unsigned long long> h(1024);
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(h.data(), buf, 8192, hipMemcpyDeviceToHost);
+                (void)hipFree(buf);
+                if (FILE* f = fopen("/tmp/pp_phase.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
                 break;
             }
             case 8: launch_pp_ns<2, 8>(p, st); break; case 16: launch_pp_ns<2, 16>(p, st); break; case 23: launch_pp_ns<2, 23>(p, st); break;
