@@ -60,9 +60,6 @@ template <int N> __device__ __forceinline__ void pp_wait_vmcnt() {
 #ifndef MMS_PP_WN
 #define MMS_PP_WN 4
 #endif
-#ifndef MMS_PP_ORDER
-#define MMS_PP_ORDER 0
-#endif
 
 __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
@@ -219,23 +216,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     auto mma = [&](int mh, int nh, const bf16x8 (&b)[HN]) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
-#if MMS_PP_ORDER == 1     // experiment: the W fragment outermost (one operand constant over 8 consecutive MFMAs; dependent pairs 4 apart)
-#pragma unroll
-        for (int j = 0; j < HN; ++j)
-#pragma unroll
-            for (int pl = 0; pl < NSPLIT; ++pl)
-#pragma unroll
-                for (int i = 0; i < HM; ++i)
-                    acc[mh * HM + i][nh * HN + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[pl][i], acc[mh * HM + i][nh * HN + j], 0, 0, 0);
-#elif MMS_PP_ORDER == 2   // experiment: the A fragment outermost (constant over 2 MFMAs, hi / lo planes alternate every 2: pairs 2 apart)
-#pragma unroll
-        for (int i = 0; i < HM; ++i)
-#pragma unroll
-            for (int pl = 0; pl < NSPLIT; ++pl)
-#pragma unroll
-                for (int j = 0; j < HN; ++j)
-                    acc[mh * HM + i][nh * HN + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[pl][i], acc[mh * HM + i][nh * HN + j], 0, 0, 0);
-#else
 #pragma unroll
         for (int pl = 0; pl < NSPLIT; ++pl)
 #pragma unroll
@@ -244,7 +224,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
                 for (int j = 0; j < HN; ++j) {
                     acc[mh * HM + i][nh * HN + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[pl][i], acc[mh * HM + i][nh * HN + j], 0, 0, 0);   // swapped: C^T fragment
                 }
-#endif
         __builtin_amdgcn_s_setprio(0);
     };
 
