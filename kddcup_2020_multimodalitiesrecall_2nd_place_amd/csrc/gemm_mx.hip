@@ -279,15 +279,16 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(const GemmParams p) {
 // Precision mode 4 GEMM: e4m3 x e4m3 on the MX-scaled instruction alone -- v_mfma_scale_f32_16x16x128_f8f6f4 runs at TWICE the rate of
 // the non-scaled v_mfma_f32_16x16x32_fp8_fp8 the round-2 fp8 path used (which is the bf16 rate).  Same tile, wave grid, ping-pong
 // stagger, persistent loop and epilogue as above; no high pass, so the LDS holds TWO 64-KiB operand regions (A8 [256][128 B] +
-// W8 [256][128 B] of one 128-k super-stage each) and a super-stage is 4 phases of 8 MX MFMAs (one 64x32 quadrant each, 256 cycles).
+// W8 [256][128 B] of one 128-k super-stage each).
 // Operands: A8 = e4m3 activation bytes [rows][lda] row-major (as the round-2 mode produces them); W8 = e4m3(w / scale[n]) in 8-row x
 // 128-byte tiles; the per-channel power-of-two weight scale rides in the instruction's hardware scale of the weight operand
 // (w8_scale4 bytes = 127 + log2 scale[n]); the activation operand's hardware scale is 2^0.
-// Prefetch: the A quarters of super-stage ss+1 are issued in phases 1-2 of super-stage ss (their region's last readers were phases 1 / 3
-// of ss-1), the W quarters of super-stage ss+2 in phases 3-4 (all four W fragments of a super-stage are read in ITS phase 1, so the W
-// half of the current region is free again two phases later): W runs two super-stages ahead, A one.  Counted waits: end of phase 4
-// `vmcnt(6)` (everything but the six pieces issued since this super-stage's phase 1 -> A rows 0-63 and W of ss+1 have landed), end of
-// phase 2 `vmcnt(8)` (-> A rows 64-127 of the running super-stage).
+// A super-stage is TWO phases of 16 MX MFMAs (A rows 0-63 / 64-127 of the wave tile x all 64 columns).  Prefetch: the four A quarters of
+// super-stage ss+1 are issued in phase A of super-stage ss, the four W quarters of super-stage ss+2 in phase B (all four W fragments of a
+// super-stage are read in ITS phase A, so the W half of the current region is free again one phase later): W runs two super-stages ahead,
+// A one.  WAR: the region super-stage ss+1 goes to was last read in phase B of ss-1 (A rows 64-127), whose reads are retired before that
+// phase's first barrier.  Counted waits: phase A `vmcnt(8)` (everything but the 4 W + 4 A pieces issued since -> A rows 64-127 of the
+// running super-stage), phase B `vmcnt(4)` (everything but W(ss+2) -> all of super-stage ss+1).
 template <int ACT>
 __global__ __launch_bounds__(512) void gemm_mx8_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 256, NW = 8, WAVES_N = 4, TM = 128, TN = 64, FM = 8, FN = 4;
@@ -390,27 +391,25 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(const GemmParams p) {
         for (int ss = 0; ss < nss; ++ss) {
             const unsigned char* rb = smem + (ss & 1) * REGION;
             const bool pa = ss + 1 < nss, pw = ss + 2 < nss;          // wave-uniform
-            // phase 1: (A rows 0-63, W columns 0-31); all four W fragments are read here
+            // phase A: A rows 0-63 x all 64 W columns (16 MX MFMAs); all four W fragments of the super-stage are read here.
+            // (Round 3 first ran four phases of 8; every barrier hand-over costs ~90 idle cycles, so half as many is faster.)
             read_la(rb, 0); read_lb(rb);
-            if (pa) { issue_a(0, ss + 1); issue_a(2, ss + 1); }
-            mx_barrier(); mma(I0{}, I0{}); mx_barrier();
-            // phase 2: (A rows 0-63, W columns 32-63)
-            if (pa) { issue_a(1, ss + 1); issue_a(3, ss + 1); }
-            // A(ss) rows 64-127 (read next phase) must have landed; younger than them: the pieces of phases 3-4 of ss-1 and 1-2 of ss
+            if (pa) { issue_a(0, ss + 1); issue_a(2, ss + 1); issue_a(1, ss + 1); issue_a(3, ss + 1); }
+            // A(ss) rows 64-127 (read next phase) must have landed; younger than them: the W pieces of phase B of ss-1 and the 4 A pieces above
             if (ss == 0) { if (pa) mx_wait_vmcnt<4>(); else mx_wait_vmcnt<0>(); }      // first super-stage of a tile: they closed the prologue
             else if (pa) mx_wait_vmcnt<8>();
             else mx_wait_vmcnt<0>();                                  // last super-stage: nothing was issued since (ss-1 had no W left to fetch)
-            mx_barrier(); mma(I0{}, I1{}); mx_barrier();
-            // phase 3: (A rows 64-127, W columns 32-63)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the W reads above are the last of this region's W half: retired before the
+                                                                      // barrier, so phase B may start refilling it (free: the DMA issue covered them)
+            mx_barrier(); mma(I0{}, I0{}); mma(I0{}, I1{}); mx_barrier();
+            // phase B: A rows 64-127 x all 64 W columns.  Its A reads are retired before its first barrier (they are the last reads of
+            // this region's A half, which phase A of the NEXT super-stage starts to refill)
             read_la(rb, 1);
-            if (pw) { issue_w(0, ss + 2); issue_w(1, ss + 2); }
-            mx_barrier(); mma(I1{}, I1{}); mx_barrier();
-            // phase 4: (A rows 64-127, W columns 0-31)
-            if (pw) { issue_w(2, ss + 2); issue_w(3, ss + 2); }
-            if (pw) mx_wait_vmcnt<6>();                               // A(ss+1) rows 0-63 and W(ss+1) landed
-            else if (pa) mx_wait_vmcnt<2>();                          // no W issued in this super-stage: only A(ss+1) rows 64-127 may be in flight
+            if (pw) { issue_w(0, ss + 2); issue_w(1, ss + 2); issue_w(2, ss + 2); issue_w(3, ss + 2); }
+            if (pw) mx_wait_vmcnt<4>();                               // A(ss+1) and W(ss+1) landed; only W(ss+2) may be in flight
             else mx_wait_vmcnt<0>();
-            mx_barrier(); mma(I1{}, I0{}); mx_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mx_barrier(); mma(I1{}, I1{}); mma(I1{}, I0{}); mx_barrier();
         }
         if (wave < NW / 2) mx_barrier();
 

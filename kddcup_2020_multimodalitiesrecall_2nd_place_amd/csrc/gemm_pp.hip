@@ -10,22 +10,23 @@
 // swizzles are applied on the per-lane SOURCE address (LDS-DMA writes lane-linear) and undone by the fragment reads' addresses:
 // 128-byte A rows: 16-B chunk c of row r sits at chunk c ^ ((r >> 1) & 7); 64-byte rows (W, one-pass A): c ^ {0,3,2,1}[(r>>2)&3];
 // both make every ds_read_b128 lane group hit 16 distinct 16-B slots.
-// Each stage runs as 4 PHASES, one 64x32 quadrant of the wave's outputs per phase (16 MFMAs at two passes):
+// Each stage runs as 2 PHASES of two 64x32 quadrants of the wave's outputs (32 MFMAs at two passes; rounds 1-2: 4 phases of 16):
 //
-//     phase:   L: ds_read the fragments this phase needs (+ issue 2 LDS-DMA pieces of stage s+2)
+//     phase:   L: ds_read the fragments this phase needs (+ issue 3 LDS-DMA pieces of stage s+2)
 //              s_barrier ; s_waitcnt lgkmcnt(0)
-//              M: s_setprio 1 ; 16 x v_mfma_f32_16x16x32_bf16 ; s_setprio 0
+//              M: s_setprio 1 ; 32 x v_mfma_f32_16x16x32_bf16 ; s_setprio 0
 //              s_barrier
 //
 // The two wave rows (wm = 0 / 1; one wave of each per SIMD) run STAGGERED by one barrier, so on every SIMD one wave is
 // in its M section while the other is in its L section: the matrix pipe sees back-to-back MFMAs while LDS reads,
-// DMA issue and address math ride in the other wave's slots.  Quadrant order (A0,B0) (A0,B1) (A1,B1) (A1,B0) reuses
-// one register set per operand half: 10 / 2 / 8 / 0 ds_read_b128 per phase at two passes.
+// DMA issue and address math ride in the other wave's slots.  Quadrant order (A0,B0) (A0,B1) | (A1,B1) (A1,B0) reuses
+// one register set per A half: 12 / 8 ds_read_b128 per phase at two passes.
 //
-// DMA waits are COUNTED: stage s+2 is issued during phases 1-3 of stage s; phase 4 waits `vmcnt(pieces per stage)`
+// DMA waits are COUNTED: stage s+2 is issued during stage s; its second phase waits `vmcnt(pieces per stage)`
 // (= everything but the stage just issued), so one full stage stays in flight across every barrier.
-// RAW: the wait sits before phase 4's first barrier and the first read of that data is in the next phase (one
-// barrier later for the staggered wave row).  WAR: a slot is refilled >= 2 phases after its last ds_read.
+// RAW: the wait sits before the second phase's first barrier and the first read of that data is in the next phase (one
+// barrier later for the staggered wave row).  WAR: a slot's last reads (second phase) are retired (`lgkmcnt(0)`) before that
+// phase's first barrier; its refill starts one phase later.
 //
 // Two shape parameters are compile-time (both measured, profiles/r02f_*; the defaults are what ships): MMS_PP_NSLOT1, the ring depth
 // of the single-plane instantiations whose 32 KiB stages leave room for 4 or 5 slots (D = slots - 1 stages in flight; not faster),
@@ -59,6 +60,10 @@ template <int N> __device__ __forceinline__ void pp_wait_vmcnt() {
 // are the expensive ones: 4 x 2 + 8 = 16 ds_read_b128 per stage and wave instead of 8 x 2 + 4 = 20)
 #ifndef MMS_PP_WN
 #define MMS_PP_WN 4
+#endif
+// phases per K stage: 2 (product) or 4 (the rounds 1-2 schedule: one 64x32 quadrant of 16 MFMAs per phase)
+#ifndef MMS_PP_PHASES
+#define MMS_PP_PHASES 2
 #endif
 
 __device__ __forceinline__ void pp_barrier() {
@@ -242,6 +247,34 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
             for (int q = 0; q < P; ++q)
                 if (q / 2 == ph) issue(q, s + D, nslot);
         };
+#if MMS_PP_PHASES == 2
+        // TWO phases of 2 x 16 MFMAs per stage (round 3): every barrier hand-over between the wave rows costs ~90 cycles of idle matrix pipe
+        // (profiles/r03h_pp_phase_stamps.txt), so 32 MFMAs per hand-over instead of 16 is worth ~5 % of a launch
+        // (profiles/r03g_two_phases.txt; round 1 had measured "no difference" on an earlier engine).
+        // phase A: quadrants (A0, B0), (A0, B1) -- 12 fragment reads at two passes, three LDS-DMA pieces of stage s+D
+        if (RD) { read_b(sb, 0, b0); read_b(sb, 1, b1); read_a(sb, 0); }
+        if (DMA) {
+#pragma unroll
+            for (int q = 0; q < P / 2; ++q) issue(q, s + D, nslot);
+        }
+        bar();
+        mma(0, 0, b0); mma(0, 1, b1);
+        bar();
+        // phase B: quadrants (A1, B1), (A1, B0) -- 8 reads, the other pieces; my pieces of stage s+1 have landed before the first barrier
+        // -> readable next phase.  The reads are RETIRED before that barrier too (lgkmcnt(0)): they are the last reads of this slot, and the
+        // first piece that refills it is issued one phase later (phase A of the next stage) -- by then every wave of either row has passed a
+        // barrier behind its reads.
+        if (RD) read_a(sb, 1);
+        if (DMA) {
+#pragma unroll
+            for (int q = P / 2; q < P; ++q) issue(q, s + D, nslot);
+        }
+        if (WAITN >= 0) pp_wait_vmcnt<(WAITN >= 0 && !(DIAG & 2) ? WAITN : 0)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+        mma(1, 1, b1); mma(1, 0, b0);
+        bar();
+#else
         // phase 1: (A0, B0)
         if (RD) { read_b(sb, 0, b0); read_a(sb, 0); }
         dma(0);
@@ -266,6 +299,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         bar();
         mma(1, 0, b0);
         bar();
+#endif
     };
 
     // prologue: stages 0 .. D-1 in flight (fewer when K is that short), stage 0 landed

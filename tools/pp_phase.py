@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd import lib  # noqa: E402
 
 N, K = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2304, 768)
-l = lib.load(lib.LAB_LIB_PATH)
+l = lib.load(os.environ.get("MMS_LAB_LIB", lib.LAB_LIB_PATH))
 ms = C.c_float(0)
 assert l.mms_dbg_gemm_bench(122880, N, K, 2, 0, 0, 0, 264, 1, C.byref(ms)) == 0, l.mms_global_error()
 t = np.fromfile("/tmp/pp_phase.bin", np.uint64).reshape(2, 512).astype(np.int64)
