@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(const GemmParams p) {
             setup(vb);
             first_stages();
         }
-        pp_epilogue<ACT, FM, FN, true>(p, acc, row0, col0, lane, Meff);
+        pp_epilogue<ACT, FM, FN, true, true>(p, acc, row0, col0, lane, Meff);
         if (!more) break;
         mx_wait_vmcnt<0>();
         mx_barrier();
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(const GemmParams p) {
             setup(vb);
             first_stages();
         }
-        pp_epilogue<ACT, FM, FN, true>(p, acc, row0, col0, lane, Meff);
+        pp_epilogue<ACT, FM, FN, true, true>(p, acc, row0, col0, lane, Meff);
         if (!more) break;
         mx_wait_vmcnt<0>();
         mx_barrier();

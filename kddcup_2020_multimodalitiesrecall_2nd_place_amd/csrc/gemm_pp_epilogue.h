@@ -30,7 +30,9 @@ __device__ __forceinline__ void pp_store_plane_pair(bf16* lane_row, int j, bf16x
 
 // AGPR_ACC (gemm_mx.hip): the accumulators live in the accumulator half of the register file; an empty asm with an "+a" operand at the
 // top of every strip keeps the compiler from copying all 128 of them into arch VGPRs before the first strip (it has only 128 of those)
-template <int ACT, int FM, int FN, bool AGPR_ACC = false>
+// SCALED: the accumulators are in units of a per-column power-of-two scale (p.col_scale: the h3 / fp8 engines of gemm_mx.hip); the bf16
+// engines pass false so that no registers are set aside for it
+template <int ACT, int FM, int FN, bool AGPR_ACC = false, bool SCALED = false>
 __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int row0, int col0, int lane, int Meff) {
     const int mrow = lane & 15, nq = lane >> 4;
     const int col = col0 + nq * 4;                       // + 16 j
@@ -40,10 +42,12 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
     // fp8 / h3 weights: the accumulator is in units of the weight row's power-of-two quantisation scale.  Applied strip by strip (not to
     // all accumulators up front): gemm_mx.hip keeps its accumulators in the AGPR half of the register file and only one strip of them
     // should be in arch VGPRs at a time
-    const bool scaled = p.col_scale != nullptr;
-    f32x4 scale4[FN];
+    const bool scaled = SCALED && p.col_scale != nullptr;
+    f32x4 scale4[SCALED ? FN : 1];
+    if constexpr (SCALED) {
 #pragma unroll
-    for (int j = 0; j < FN; ++j) scale4[j] = scaled ? *reinterpret_cast<const f32x4*>(p.col_scale + col + 16 * j) : f32x4{1.f, 1.f, 1.f, 1.f};
+        for (int j = 0; j < FN; ++j) scale4[j] = scaled ? *reinterpret_cast<const f32x4*>(p.col_scale + col + 16 * j) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
     const bool f32_out = p.out_kind == OUT_F32, resid = p.r_hi != nullptr;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -54,9 +58,11 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
         const int row = row0 + 16 * i + mrow;
         if (row >= Meff) continue;
         const long long orow = p.cmap(row);
-        if (scaled) {
+        if constexpr (SCALED) {
+            if (scaled) {
 #pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] *= scale4[j];
+                for (int j = 0; j < FN; ++j) acc[i][j] *= scale4[j];
+            }
         }
         if (resid) {
             const long long ro = (p.r_index ? (long long)p.r_index[row] : p.rmap(row)) * (long long)p.ldr + col;
