@@ -2,8 +2,8 @@
 // passes per product  a_hi*w_hi + a_lo*w_hi + a_hi*w_lo  (the a_lo*w_lo term is below 2^-17 of the product).
 //
 // The gemm_pp.hip engine re-cut for four operand planes: 256x128 tile (a 32-wide K stage = A [256][hi 64 B | lo 64 B] + W_hi, W_lo
-// [128][64 B] = 48 KiB, so the 3-slot LDS-DMA ring still fits), 8 wavefronts as 2(M) x 4(N), 128x32 outputs per wave, TWO phases per
-// stage (rows 0-63 / 64-127 of the wave tile x both column fragments: 4 x 2 x 3 = 24 MFMAs each), wave rows staggered by one
+// [128][64 B] = 48 KiB, so the 3-slot LDS-DMA ring still fits), 8 wavefronts as 2(M) x 4(N), 128x32 outputs per wave, ONE phase of
+// 8 x 2 x 3 = 48 MFMAs per stage (round 3; before: two phases of 24, the schedule sketched below), wave rows staggered by one
 // barrier, swapped MFMA operands + LDS-free epilogue (gemm_pp_epilogue.h), persistent workgroups.
 //
 //     phase 1:  ds_read W fragments (hi, lo) + A rows 0-63 (hi, lo)        | s_barrier | 24 MFMAs | s_barrier
@@ -92,7 +92,11 @@ __global__ __launch_bounds__(512) void gemm_ppw_kernel(const GemmParams p) {
     const int fr = lane & 15, fk = lane >> 4;
     const int laneA = (wm * TM + fr) * 128 + ((fk ^ ((fr >> 1) & 7)) << 4);      // hi fragment; the lo one: chunk ^ 4
     const int laneB = WOFF + (wn * TN + fr) * 64 + ((fk ^ pw_swz(fr)) << 4);
-    bf16x8 a[2][4], b[2][2];      // [plane][fragment]
+#ifndef MMS_PPW_PHASES
+#define MMS_PPW_PHASES 1
+#endif
+    constexpr int AF = MMS_PPW_PHASES == 1 ? 8 : 4;
+    bf16x8 a[2][AF], b[2][2];      // [plane][fragment]
     auto read_a = [&](const unsigned char* sb, int mh) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
@@ -127,6 +131,36 @@ __global__ __launch_bounds__(512) void gemm_ppw_kernel(const GemmParams p) {
         constexpr int WAITN = decltype(wait_tag)::value;
         const unsigned char* sb = smem + slot * SLOT;
         const int nslot = slot == 0 ? 2 : slot - 1;
+#if MMS_PPW_PHASES == 1
+        // ONE phase of 48 MFMAs per stage (round 3; rounds 1-2: two of 24): the wave tile is only 128x32, so all 16 A fragments and
+        // 4 W fragments of a stage fit in registers (64 accumulator + 80 fragment VGPRs), and every barrier hand-over between the wave
+        // rows costs ~90 idle matrix-pipe cycles (profiles/r03h_pp_phase_stamps.txt).  The reads are retired before the first barrier
+        // (the slot is refilled from the next phase on); the counted wait for stage s+1 sits before it too (first read: next phase).
+        read_b(sb);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(sb + (laneA ^ (pl << 6)) + i * 16 * 128);
+        if (PRE) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) issue(q, s + 2, nslot);
+        }
+        if (WAITN == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (WAITN == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pw_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[pass == 2 ? 1 : 0][j], a[pass == 1 ? 1 : 0][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        pw_barrier();
+        return;
+#endif
         read_b(sb);
         read_a(sb, 0);
         pw_barrier();
