@@ -126,7 +126,7 @@ def cpu_baseline(cfg, w, hip_logits_fn=None, budget_s=20.0):
 
 def make_members(name, a, local):
     """-> (scorer, {member name: (cfg, weights, member scorer)})"""
-    kw = dict(device=local, chunk_pairs=a.chunk, fuse_layernorm=a.fuse_ln)
+    kw = dict(device=local, chunk_pairs=a.chunk, fuse_layernorm=a.fuse_ln, fuse_attention=a.fuse_attn)
     if name != "ensemble":
         cfg = CFGS[name]()
         w = weights.make_weights(cfg, bf16_matrices=not a.fp32_weights)
@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (precision 3 on fp32 weights, lds, lxmert, H2D-inclusive)")
     ap.add_argument("--fp32-weights", action="store_true", help="seeded weights NOT rounded to bf16 (what a real checkpoint looks like)")
+    ap.add_argument("--fuse-attn", type=int, default=0, help="mms_config.fuse_attention: QKV projection + self-attention in one kernel; 1 = exact-fp32 attention MFMAs (bit-identical to the two-kernel route), 2 = split-bf16 MFMAs")
     ap.add_argument("--fuse-ln", action="store_true", help="LayerNorm fused into the N = 768 GEMM epilogues (mms_config.fuse_layernorm)")
     ap.add_argument("--dense", action="store_true", help="keep padded tokens (reference layout) instead of packing live tokens")
     ap.add_argument("--all-boxes", action="store_true", help="worst case: every pair has 10 boxes")

@@ -88,6 +88,12 @@ typedef struct mms_config {
                                  writing the fp32 sum for a separate LayerNorm kernel.  Same results to fp32 round-off; 12 -> 6 KB
                                  of HBM traffic per row and LayerNorm, but measured NOT faster on MI355X, so the
                                  default is 0 */
+    int32_t fuse_attention;   /* 1: the self-attention sub-layers of launches with >= 16384 rows run the Q / K / V projection and the
+                                 attention in ONE kernel (qkv_attn.hip: a workgroup projects one head of a 256-row tile, keeps the 192
+                                 result columns in LDS and attends from there), so the fp32 [rows][2304] Q | K | V tensor never goes
+                                 through HBM.  Precision mode 2 only; context rows bit-identical to the two-kernel route.
+                                 2: the same with the attention's Q K^T and P V on split-bf16 MFMAs (hi + lo operands, three products,
+                                 v_exp_f32 / v_rcp_f32 softmax) instead of exact-fp32 MFMAs: ~2^-16 relative on the scores */
 } mms_config;
 
 /* zk feed, code/imagebert_zk/evaluate_normal.py:141-152.  np_idx_class_labels [B,10,8] is either passed as the reference
@@ -158,9 +164,9 @@ typedef struct mms_ensemble_batch {
 
 /* ABI revision of the structs and entry points declared in this header.  It changes whenever a struct gains a field or an entry
  * point changes its signature (r1: 1; r2 added mms_config.fuse_layernorm, mms_zk_batch.label_ids, mms_lxmert_batch.label_ids / x_norm
- * without bumping it; r3: 3).  A caller built against another revision would make the library read past its structs, so compare
+ * without bumping it; r3: 3, then 4 with mms_config.fuse_attention).  A caller built against another revision would make the library read past its structs, so compare
  * BEFORE the first mms_create:  if (mms_version() != MMS_ABI_VERSION) abort();   (lib.py's load() does) */
-#define MMS_ABI_VERSION 3
+#define MMS_ABI_VERSION 4
 int mms_version(void);
 const char* mms_global_error(void);              /* message of the last failing mms_create */
 
@@ -212,6 +218,8 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
                        int32_t variant, int32_t iters, float* ms_out);
 int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B, int32_t Sq, int32_t Sk,
                       const float* key_add, float* out_f32, void* stream);
+/* launch counters since mms_create: which = 0 -> fused QKV + attention launches (mms_config.fuse_attention took effect); -1: unknown */
+int64_t mms_dbg_counter(mms_handle* h, int32_t which);
 int mms_dbg_layernorm(const float* x, const float* gamma, const float* beta, int64_t M, float* out_f32, void* stream);
 
 #ifdef __cplusplus

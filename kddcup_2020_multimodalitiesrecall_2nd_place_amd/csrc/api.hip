@@ -33,7 +33,8 @@ struct Planes {
 
 // *8 / *s: e4m3 copy of the matrix (8 x 128-byte tiles) and its per-output-channel scales as packed e8m0 bytes (precision mode 4 only)
 struct AttW { bf16* wqkv; float* bqkv; bf16* wo; float* bo; float* g; float* b; unsigned char* wqkv8 = nullptr; unsigned* wqkvs = nullptr;
-              unsigned char* wo8 = nullptr; unsigned* wos = nullptr; };
+              unsigned char* wo8 = nullptr; unsigned* wos = nullptr;
+              bf16* wqkv_hm = nullptr; float* bqkv_hm = nullptr; };   // head-major [12][Q 64 | K 64 | V 64] rows: the fused QKV + attention kernel (qkv_attn.hip)
 struct FfnW { bf16* wi; float* bi; bf16* wd; float* bd; float* g; float* b; unsigned char* wi8 = nullptr; unsigned* wis = nullptr;
               unsigned char* wd8 = nullptr; unsigned* wds = nullptr; };
 struct LayerW { AttW att; FfnW ffn; };
@@ -94,6 +95,8 @@ struct mms_handle {
     float* ln_stats = nullptr; int* ln_ctl = nullptr; int ln_slot = 0; unsigned ln_tag = 0;
     static constexpr int LN_SLOTS = 2048;
     int fuse_ln = 0;       // mms_config.fuse_layernorm (lab build: env MMS_FUSE_LN overrides)
+    int fuse_attn = 0;     // mms_config.fuse_attention: QKV projection + self-attention in one kernel (qkv_attn.hip; precision mode 2)
+    int4* qa_sub[2] = {nullptr, nullptr}; int* qa_nsub = nullptr;     // sub-tile tables of the (up to two) token streams of a launch wave
     // label-text workspace, sized for lab_cap unique labels
     int64_t lab_cap = 0;
     Planes lab_planes; float *lab_f32 = nullptr, *lab_feat = nullptr; int64_t lab_feat_cap = 0;
@@ -127,6 +130,7 @@ struct mms_handle {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     int64_t gemm_launches = 0;
+    int64_t fused_attn_launches = 0;     // qkv_attn.hip launches since mms_create (mms_dbg_counter)
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
@@ -191,7 +195,7 @@ int tab(mms_handle* h, const std::string& name, std::vector<int64_t> shape, floa
 
 // Build a bf16 [N][K] device matrix from a list of host sources.  Each source contributes n_i output
 // rows; `in_out` sources are [K, n_i] (TF dense kernel), otherwise [n_i, K] (torch Linear weight).
-struct MatSrc { const float* p; int64_t n; bool in_out; };
+struct MatSrc { const float* p; int64_t n; bool in_out; int64_t col0 = 0, ld = 0; };   // ld != 0: rows col0 .. col0 + n of a source with ld output rows
 int upload_mat(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, bf16** out) {
     int64_t N = 0;
     for (auto& s : srcs) N += s.n;
@@ -206,7 +210,7 @@ int upload_mat(mms_handle* h, const std::vector<MatSrc>& srcs, int64_t K, bf16**
     for (auto& s : srcs) {
         for (int64_t n = 0; n < s.n; ++n)
             for (int64_t k = 0; k < K; ++k) {
-                const float w = s.in_out ? s.p[k * s.n + n] : s.p[n * K + k];
+                const float w = s.in_out ? s.p[k * (s.ld ? s.ld : s.n) + s.col0 + n] : s.p[(s.col0 + n) * K + k];
                 const uint16_t hi = f2bf(w);
                 const size_t at = (size_t)wtile_off(r0 + n, k, K);
                 buf[at] = hi;
@@ -294,6 +298,19 @@ int load_att(mms_handle* h, bool tf, const std::string& self_scope, const std::s
         if (int rc = mat_f8(h, out_scope + (tf ? "/dense/kernel" : ".dense.weight"), H, H, tf, &w->wo8, &w->wos)) return rc;
     }
     if (int rc = cat_vec(h, bnames, H, &w->bqkv)) return rc;
+    if (h->fuse_attn && h->nsplit == 2) {
+        std::vector<MatSrc> hm;
+        std::vector<float> bhm;
+        for (int hd = 0; hd < MMS_HEADS; ++hd)
+            for (int i = 0; i < 3; ++i) {
+                hm.push_back({srcs[i].p, MMS_HEAD_DIM, tf, (int64_t)hd * MMS_HEAD_DIM, H});
+                const HostTensor* bt;
+                if (int rc = need(h, bnames[i], {H}, &bt)) return rc;
+                bhm.insert(bhm.end(), bt->data.begin() + hd * MMS_HEAD_DIM, bt->data.begin() + (hd + 1) * MMS_HEAD_DIM);
+            }
+        if (int rc = upload_mat(h, hm, H, &w->wqkv_hm)) return rc;
+        if (int rc = upload_f32(h, bhm.data(), bhm.size(), &w->bqkv_hm)) return rc;
+    }
     if (int rc = mat(h, out_scope + (tf ? "/dense/kernel" : ".dense.weight"), H, H, tf, &w->wo)) return rc;
     if (int rc = vec(h, out_scope + (tf ? "/dense/bias" : ".dense.bias"), H, &w->bo)) return rc;
     if (int rc = vec(h, out_scope + (tf ? "/LayerNorm/gamma" : ".LayerNorm.weight"), H, &w->g)) return rc;
@@ -482,6 +499,12 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     }
     if (int rc = dev_alloc(h, h->ws_allocs, &p, 16)) return rc;
     h->pk_rows = (int*)p;
+    for (int s = 0; s < 2; ++s) {      // a sub-tile holds at least one pair
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(pairs + 2) * sizeof(int4))) return rc;
+        h->qa_sub[s] = (int4*)p;
+    }
+    if (int rc = dev_alloc(h, h->ws_allocs, &p, 16)) return rc;
+    h->qa_nsub = (int*)p;
     if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(rows + 256) * 3 * 2 * 8)) return rc;
     h->ln_stats = (float*)p;
     HIP_TRY(h, hipMemset(p, 0, (size_t)(rows + 256) * 3 * 2 * 8));
@@ -675,7 +698,15 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
 
 // Packed-stream descriptor: per-pair first row / live count (relative to the stream's first row) and the
 // device-side number of live rows.  off == nullptr: dense layout (row of (b, s) = b * S + s).
-struct Pack { const int* off = nullptr; const int* cnt = nullptr; const int* rows = nullptr; };
+struct Pack { const int* off = nullptr; const int* cnt = nullptr; const int* rows = nullptr;
+              const int4* sub = nullptr; const int* n_sub = nullptr; };     // sub-tile table of the fused QKV + attention kernel (plan_tiles)
+
+// sub-tile table of one token stream (n pairs of at most S tokens; packed or dense) for qkv_attn.hip, in table slot `slot`
+void plan_tiles(mms_handle* h, hipStream_t st, Pack& pk, int64_t n, int S, int slot) {
+    if (!h->fuse_attn || h->nsplit != 2 || h->f8 || S > 48) return;
+    launch_qkv_tile_plan(pk.off, pk.cnt, pk.rows, (int)n, S, h->qa_sub[slot], h->qa_nsub + slot, st);
+    pk.sub = h->qa_sub[slot]; pk.n_sub = h->qa_nsub + slot;
+}
 
 int attend(mms_handle* h, AttnParams& a, hipStream_t st) {
     if (h->alternate) { a.reverse = h->flip; h->flip ^= 1; }
@@ -690,6 +721,31 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
               const float* key_add, const Pack& pk = Pack()) {
     const int64_t M = B * S;
     const bool f8 = h->f8 && in.f8;
+    // one kernel for projection + attention (qkv_attn.hip) when the launch is big enough for a persistent grid and runs two-pass bf16
+    const bool fused_attn = pk.sub && w.wqkv_hm && !f8 && M >= 16384 && h->nsplit == 2 && !(h->x1_mask & 1);
+    if (fused_attn) {
+        QkvAttnParams q{};
+        const Planes a_in = in.at(row0 * H), c_out = h->ctx.at(row0 * H);
+        q.a_hi = a_in.hi; q.lda = H; q.w = w.wqkv_hm; q.bias = w.bqkv_hm; q.K = H;
+        q.sub = pk.sub; q.n_sub = pk.n_sub; q.pair_off = pk.off; q.pair_cnt = pk.cnt; q.S = S;
+        q.key_add = key_add; q.o_hi = c_out.hi; q.o_lo = c_out.lo; q.ldo = H;
+        q.M = (int)M; q.m_dev = pk.rows; q.fast = h->fuse_attn == 2;
+        if (h->alternate) { q.reverse = h->flip; h->flip ^= 1; }
+        if (h->timing) {
+            if (h->ev_used + 2 > h->ev.size()) {
+                h->ev.resize(h->ev_used + 2);
+                HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used]));
+                HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used + 1]));
+            }
+            q.flop_counter = h->flop_counter;
+            HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
+            if (!launch_qkv_attn(q, st)) return h->fail(MMS_ERR_ARG, "qkv_attn: shape not supported");
+            HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
+            h->ev_used += 2;
+            h->gemm_launches += 1;
+        } else if (!launch_qkv_attn(q, st)) return h->fail(MMS_ERR_ARG, "qkv_attn: shape not supported");
+        h->fused_attn_launches += 1;
+    } else {
     if (f8) {
         if (int rc = gemm_f8(h, st, in.f8 + row0 * H, H, w.wqkv8, w.wqkvs, w.bqkv, M, 3 * H, H, ACT_NONE, to_qkv(h, row0, M), pk.rows)) return rc;
     } else if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wqkv, w.bqkv, M, 3 * H, H, ACT_NONE,
@@ -703,6 +759,7 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     a.q_off = a.kv_off = pk.off; a.q_cnt = a.kv_cnt = pk.cnt;
     if (f8) a.o_f8 = h->ctx.f8 + row0 * H;
     if (int rc = attend(h, a, st)) return rc;
+    }
     const Planes resid = in.at(row0 * H);
     bool fused = false;
     if (int rc = gemm_ln(h, st, f8, h->ctx.at(row0 * H), H, w.wo, w.wo8, w.wos, w.bo, M, H, resid, w.g, w.b, out.at(row0 * H), h->t + row0 * H,
@@ -915,6 +972,7 @@ int zk_encode(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, 
         launch_zk_mask(b->len_query + p0, b->num_boxes + p0, T, h->key_add, (int)n, st);
     }
     if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, n * S * H, st);   // layer 0's A operand (rows past the live count are never read)
+    plan_tiles(h, st, pk, n, S, 0);
     // --- encoder ---
     const int nl = (c.stop_after >= 0 && c.stop_after < c.layers) ? c.stop_after : c.layers;
     const bool cls_only = c.stop_after < 0 && c.layers > 0;   // debug runs keep the full hidden state
@@ -966,6 +1024,7 @@ int lds_chunk(mms_handle* h, hipStream_t st, const mms_lds_batch* b, int64_t p0,
         pk.off = h->pk_off[0]; pk.cnt = h->pk_cnt[0]; pk.rows = h->pk_rows;
         key_add = h->key_add;
     }
+    plan_tiles(h, st, pk, n, S, 0);
     if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, n * S * H, st);
     const int nl = (c.stop_after >= 0 && c.stop_after < c.layers) ? c.stop_after : c.layers;
     const bool cls_only = c.stop_after < 0 && c.layers > 0;
@@ -1057,6 +1116,7 @@ int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int
         pl.off = h->pk_off[0]; pl.cnt = h->pk_cnt[0]; pl.rows = h->pk_rows;
         launch_lx_embed_lang_packed(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, h->lq_ids, T, c.vocab, h->pk_src[0], h->pk_rows,
                                     (int)(n * T), h->x.hi, h->x.lo, st);
+        plan_tiles(h, st, pl, n, T, 0);
         if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, n * T * H, st);
         for (int i = 0; i < c.layers; ++i) {
             if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, T, n, h->key_add, pl)) return rc;
@@ -1101,6 +1161,8 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
         launch_lx_visn(xf, h->g_visn, h->be_visn, b->boxes + p0 * V * 4, 4, h->w_box, h->b_box, h->g_box, h->be_box, h->lab_feat,
                        label_index + p0 * V, (int)h->n_labels, h->x.at(ML * H).hi, h->x.at(ML * H).lo, (int)MV, st);
     }
+    plan_tiles(h, st, pl, n, T, 0);
+    plan_tiles(h, st, pv, n, V, 1);
     if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, R * H, st);
     int budget = c.stop_after >= 0 ? c.stop_after : (1 << 30);
     for (int i = 0; i < c.layers && budget > 0 && !h->lq_active; ++i, --budget) {
@@ -1222,6 +1284,7 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
     h->cfg = *cfg;
     h->f8 = cfg->precision == 4;
     h->fuse_ln = cfg->fuse_layernorm != 0;
+    h->fuse_attn = cfg->fuse_attention;
     h->nsplit = h->f8 ? 2 : cfg->precision;
 #ifdef MMS_LAB   // A/B knobs exist in libmmscore_lab.so only; the product library reads no environment variable
     if (const char* e = getenv("MMS_FUSE_LN")) h->fuse_ln = atoi(e);
@@ -1698,6 +1761,11 @@ __global__ void k_fill_random(float* p, long long n, unsigned seed) {
     }
 }
 
+int64_t mms_dbg_counter(mms_handle* h, int32_t which) {
+    if (!h) return -1;
+    return which == 0 ? h->fused_attn_launches : -1;
+}
+
 int mms_set_gemm_variant(int32_t v) { set_gemm_variant(v); return MMS_OK; }
 
 // GEMM micro-benchmark on random operands: returns the average kernel time (ms) over `iters` launches.
@@ -1767,6 +1835,13 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
         if (out_planes) { pm.out_kind = OUT_H3; pm.c_h16 = c16; pm.c_l8 = c8; pm.ldh = (int)N; }
     }
     auto run = [&]() {
+        if (variant == 60 || variant == 61) {     // the LayerNorm kernel (with / without the residual planes) on M rows: HBM-bound, 9 / 6 KB per row
+            if (N != H) return false;
+            LnResid res;
+            if (variant == 60) { res.hi = rp; res.lo = rp + MMS_PLANE_LO; res.ld = H; }
+            launch_ln_to_planes(cf, H, bias, bias, cp, cp + MMS_PLANE_LO, H, (int)M, 0, nullptr, res);
+            return true;
+        }
         if (!mx) { launch_gemm(p, nsplit, 0); return true; }
 #ifdef MMS_LAB
         if (variant == 51) return launch_gemm_mx_hi_only(pm, 0);

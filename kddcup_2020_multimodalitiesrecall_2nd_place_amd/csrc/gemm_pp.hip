@@ -240,13 +240,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         const int nslot = slot == 0 ? NSLOT - 1 : slot - 1;     // (slot + D) % NSLOT: the slot stage s-1 just left
         constexpr bool DMA = PRE && !(DIAG & 2), RD = !(DIAG & 4);
         auto bar = [&]() { stamp(); if (DIAG & 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } else pp_barrier(); stamp(); };
-        // LDS-DMA pieces of stage s+D: two per phase in phases 1-3 (other placements measured no better, profiles/r01c_gemm_variants.txt)
-        auto dma = [&](int ph) {
-            if (!DMA) return;
-#pragma unroll
-            for (int q = 0; q < P; ++q)
-                if (q / 2 == ph) issue(q, s + D, nslot);
-        };
 #if MMS_PP_PHASES == 2
         // TWO phases of 2 x 16 MFMAs per stage (round 3): every barrier hand-over between the wave rows costs ~90 cycles of idle matrix pipe
         // (profiles/r03h_pp_phase_stamps.txt), so 32 MFMAs per hand-over instead of 16 is worth ~5 % of a launch
@@ -275,6 +268,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         mma(1, 1, b1); mma(1, 0, b0);
         bar();
 #else
+        // LDS-DMA pieces of stage s+D: two per phase in phases 1-3 (other placements measured no better, profiles/r01c_gemm_variants.txt)
+        auto dma = [&](int ph) {
+            if (!DMA) return;
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+                if (q / 2 == ph) issue(q, s + D, nslot);
+        };
         // phase 1: (A0, B0)
         if (RD) { read_b(sb, 0, b0); read_a(sb, 0); }
         dma(0);

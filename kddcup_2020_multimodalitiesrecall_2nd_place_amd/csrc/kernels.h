@@ -84,6 +84,26 @@ struct AttnParams {
 };
 bool launch_attention(const AttnParams& p, hipStream_t st);   // false: (Sq, Sk) beyond the instantiated tiles (> 48 tokens)
 
+// Fused QKV projection + self-attention of one token stream (qkv_attn.hip; precision mode 2).  The stream's pairs are packed into
+// sub-tiles of <= 128 rows by launch_qkv_tile_plan (once per stream and call); the weights / bias are in head-major order
+// ([12 heads][Q 64 | K 64 | V 64] rows).
+struct QkvAttnParams {
+    const bf16* a_hi; int lda;               // hidden-state planes (hl32), row stride in elements
+    const bf16* w; const float* bias; int K; // head-major tiled [2304][K] weights, head-major bias
+    const int4* sub; const int* n_sub;       // sub-tile table {first row, rows, first pair, pairs} and its device-side length
+    const int* pair_off; const int* pair_cnt; int S;   // packed: first row / live tokens per pair; dense (nullptr): S tokens per pair.  S = maximum tokens
+    const float* key_add;                    // additive key mask by stream row, or nullptr
+    bf16* o_hi; bf16* o_lo; int ldo;         // context planes
+    int M; const int* m_dev;                 // rows of the stream (upper bound / device-side live count): grid size, FLOP count
+    int reverse;
+    int fast;                                // 1: attention on split-bf16 MFMAs (three products per operand pair) instead of exact-fp32 MFMAs
+    unsigned long long* flop_counter;
+    unsigned long long* trace;               // lab builds: per-tile timeline (qkv_attn.hip), nullptr otherwise
+    int lab_flags;                           // lab builds: timing-only knock-outs
+};
+void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, hipStream_t st);   // rows_dev: device-side row total of a packed stream (or nullptr)
+bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st);   // false: shape not supported (S > 48, K % 64)
+
 // ---------------------------------------------------------------------------------------------
 // Row-wise kernels (one wavefront per 768-wide row)                   (rowops.hip)
 // ---------------------------------------------------------------------------------------------

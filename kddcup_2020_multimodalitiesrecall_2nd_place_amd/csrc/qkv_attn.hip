@@ -1,0 +1,627 @@
+// Fused QKV projection + self-attention (precision mode 2): one workgroup computes [Q_h | K_h | V_h] = X W_h^T + b_h of ONE head for a
+// 256-row tile of the token stream with the ping-pong engine of gemm_pp.hip, leaves the 192 result columns in LDS and runs the
+// attention of the tile's pairs for that head straight from there -- the fp32 Q / K / V tensor ([rows][2304], 9.2 KB per row written
+// by the projection and read back by attn.hip) never exists in HBM, and the attention launch disappears.
+//
+// Reference: pixelbert.py:767-836 / pixelmodel.py:770-831 (zk, lds) and lxrt/modeling.py:326-352 (lxmert self-attention): the three
+// dense projections, scores = Q K^T / sqrt(64) + (1 - mask) * -10000, softmax over the keys, probs @ V, heads concatenated.
+//
+// Tile = two SUB-TILES of up to 128 rows, each holding whole pairs (a pair's tokens are consecutive rows, at most 48 of them):
+// k_qkv_tile_plan packs the pairs greedily.  Wave grid 4(M) x 2(N), 64 x 96 outputs per wave; waves 0-3 own sub-tile 0, waves 4-7
+// sub-tile 1 (the two staggered halves of the ping-pong).  K runs in 32-wide stages through the 3-slot LDS ring exactly as in
+// gemm_pp.hip (A [256][hi 64 B | lo 64 B] + W [192][64 B] per stage, LDS-DMA, counted waits, swizzles on the source address); a stage
+// is ONE phase of 48 MFMAs per wave (14 ds_read_b128).  Weights are stored head-major ([12][Q 64 | K 64 | V 64][768], tiled): a column
+// tile is one head.
+//
+// Epilogue, per sub-tile: its four waves add the bias and write their accumulators to LDS as fp32 [128][196] (98 KB over the idle
+// ring; row stride 784 B = 16 B mod 256 B: conflict-free for the row-strided fragment reads below) -> barrier -> the eight waves take
+// the sub-tile's pairs round-robin and run attn.hip's register choreography with ds_read_b128 in place of the global loads (same
+// v_mfma_f32_16x16x4_f32 sequence, same softmax: the context rows are BIT-IDENTICAL to the two-kernel route) -> split-bf16 context rows
+// to HBM -> barrier.  The staging area overlays ring slots 1-2 (and the unused top of slot 0): the next tile's stage 0 is fetched into
+// slot 0 during the epilogue, its stage 1 after the last barrier.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+#include "kernels.h"
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+namespace {
+
+__device__ __forceinline__ int qa_swz(int r) { return (4 - ((r >> 2) & 3)) & 3; }
+
+template <int N> __device__ __forceinline__ void qa_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void qa_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int QA_SUB = 128;          // rows of a sub-tile
+constexpr int QA_LDROW = 196;        // floats per staged row: 192 + 4 (784 B = 16 B mod 256 B)
+
+}  // namespace
+
+// ---- tile plan: pairs -> sub-tiles of <= 128 rows ----
+// sub[u] = {first stream row, rows, first pair, pairs}; *n_sub = number of sub-tiles.  off == nullptr: dense stream (pair b = rows b*S ..).
+// The stream is cut into SEGMENTS of about QA_SEG rows at pair boundaries (binary search in the row offsets); one thread packs the pairs
+// of its segment greedily in pair order (first pass: count; block scan; second pass: write).  Only a segment's last sub-tile is left
+// underfull by the cut: ~0.5 sub-tiles of 64.  (A single greedy chain over all pairs is 30 000 dependent steps: 2 ms per plan.)
+constexpr int QA_PLAN_THREADS = 1024;
+constexpr int QA_SEG = 8192;
+
+__global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __restrict__ off, const int* __restrict__ cnt, int n, int S,
+                                                                   const int* __restrict__ rows_dev, int4* __restrict__ sub, int* __restrict__ n_sub) {
+    __shared__ int sh[QA_PLAN_THREADS];
+    const int tid = threadIdx.x;
+    const long long total = off ? (rows_dev ? (long long)*rows_dev : (long long)off[n - 1] + cnt[n - 1]) : (long long)n * S;
+    long long seg = QA_SEG;
+    if (total > seg * QA_PLAN_THREADS) seg = ((total + QA_PLAN_THREADS - 1) / QA_PLAN_THREADS + 127) / 128 * 128;
+    const int nseg = (int)((total + seg - 1) / seg);
+    auto first_pair = [&](long long row) -> int {       // first pair whose first row is >= row
+        if (!off) { const long long b = (row + S - 1) / S; return b < n ? (int)b : n; }
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (off[mid] < row) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    int p0 = n, p1 = n;
+    if (tid < nseg) { p0 = first_pair((long long)tid * seg); p1 = tid + 1 < nseg ? first_pair((long long)(tid + 1) * seg) : n; }
+    auto pack = [&](int out) {       // out < 0: count only
+        int rows = 0, row0 = 0, pair0 = p0, ns = 0;
+        for (int b = p0; b < p1; ++b) {
+            const int c = cnt ? cnt[b] : S;
+            if (rows + c > QA_SUB) {
+                if (out >= 0) sub[out + ns] = make_int4(row0, rows, pair0, b - pair0);
+                ++ns;
+                rows = 0;
+            }
+            if (rows == 0) { row0 = off ? off[b] : b * S; pair0 = b; }
+            rows += c;
+        }
+        if (rows > 0) {
+            if (out >= 0) sub[out + ns] = make_int4(row0, rows, pair0, p1 - pair0);
+            ++ns;
+        }
+        return ns;
+    };
+    const int mine = pack(-1);
+    sh[tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < QA_PLAN_THREADS; o <<= 1) {
+        const int v = tid >= o ? sh[tid - o] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    if (mine > 0) pack(sh[tid] - mine);
+    if (tid == QA_PLAN_THREADS - 1) *n_sub = sh[tid];
+}
+void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_qkv_tile_plan, dim3(1), dim3(QA_PLAN_THREADS), 0, st, off, cnt, n, S, rows_dev, sub, n_sub);
+}
+
+// MAXT: 16-token tiles per side of the attention (2: pairs of <= 32 tokens, 3: <= 48)
+template <int MAXT, bool FAST>
+__global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
+    constexpr int NW = 8, WAVES_N = 2, TM = 64, TN = 96, FM = TM / 16, FN = TN / 16, BN = 192;
+    constexpr int PLANE = 256 * 64;                 // 16 KiB: one 64-byte-per-row operand plane of 256 rows
+    constexpr int SLOT = 3 * PLANE;                 // A [256][128 B] + W [192][64 B] (+ 4 KiB unused)
+    constexpr int NSLOT = 3, D = 2, P = 6;          // pieces per wave and stage: 4 A + 2 W (waves 4-7 repeat waves 0-3's second W piece)
+    static_assert(QA_SUB * QA_LDROW * 4 <= NSLOT * SLOT, "Q | K | V staging overlays the ring");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * SLOT];
+    // per-tile metadata of the epilogue, fetched with the tile's addresses (setup) and parked here after the main loop: a dependent
+    // global load inside the attention phase costs a full memory latency with only eight waves on the CU (the phase took 16 k cycles per
+    // sub-tile with the pair offsets / key mask / bias read from memory where they are used: profiles/r03n_qa_trace.txt)
+    __shared__ __attribute__((aligned(16))) float m_keyadd[256];     // additive key mask by tile row
+    __shared__ __attribute__((aligned(16))) float m_bias[192];       // this head's [Q | K | V] bias
+    __shared__ int2 m_pair[256 + 64];                                // [sub-tile][pair]: first stream row, live tokens (+ 64: whole-wave reads)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int n_sub = *p.n_sub;
+    const int nbm = (n_sub + 1) >> 1, nblk = nbm * MMS_HEADS;
+    if (p.flop_counter && blockIdx.x == 0 && tid == 0) {
+        int Meff = p.M;
+        if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
+        atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)(3 * MMS_HIDDEN) * (unsigned long long)p.K);
+    }
+    int vb = blockIdx.x;
+    if (vb >= nblk) return;
+
+    const int gr_l = lane >> 2, gc = lane & 3;
+    const bf16* a_src[4];
+    const bf16* w_src[2];
+    int head;
+    int4 sub0, sub1;
+    int meta_a = 0, meta_b = 0;          // thread < 256: key mask of tile row tid, bias[tid]; else pair (tid - 256): first row, tokens
+    // where virtual block v works: head and the two sub-tile records (uniform: scalar loads).  Done one tile ahead (top of the main loop), so
+    // that the address set-up behind the loop has no dependent memory access in front of it
+    int nhead = 0;
+    int4 nsub0 = make_int4(0, 0, 0, 0), nsub1 = nsub0;
+    auto locate = [&](int v) {
+        // bijective XCD remap (virtual block v runs on XCD v % 8): the twelve heads of a row tile stay on one XCD's L2
+        const int q = nblk >> 3, r8 = nblk & 7, xcd = v & 7, loc = v >> 3;
+        int bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+        if (p.reverse) bid = nblk - 1 - bid;
+        const int nb = bid / MMS_HEADS;
+        nhead = bid % MMS_HEADS;
+        auto uni = [](int4 v) {      // wave-uniform by construction: keep the record in scalar registers
+            return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z),
+                             __builtin_amdgcn_readfirstlane(v.w));
+        };
+        nhead = __builtin_amdgcn_readfirstlane(nhead);
+        nsub0 = uni(p.sub[2 * nb]);
+        nsub1 = 2 * nb + 1 < n_sub ? uni(p.sub[2 * nb + 1]) : make_int4(nsub0.x, 0, 0, 0);
+    };
+    auto setup = [&]() {
+        head = nhead; sub0 = nsub0; sub1 = nsub1;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int r = q4 * 64 + wave * 8 + (lane >> 3);          // tile row: sub-tile r >> 7, its row r & 127 (clamped to the last live one)
+            const int4 sb = (r >> 7) ? sub1 : sub0;
+            int lr = r & 127;
+            lr = lr < sb.y ? lr : (sb.y > 0 ? sb.y - 1 : 0);
+            a_src[q4] = p.a_hi + 2 * ((long long)(sb.x + lr) * (long long)p.lda) + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        }
+        {
+            const int t = tid & 255, i = t & 127;
+            const int4 sb = (t >> 7) ? sub1 : sub0;
+            if (tid < 256) {
+                meta_a = (p.key_add && i < sb.y) ? __float_as_int(p.key_add[sb.x + i]) : 0;
+                meta_b = tid < BN ? __float_as_int(p.bias[head * BN + tid]) : 0;
+            } else if (i < sb.w) {
+                const int b = sb.z + i;
+                meta_a = p.pair_off ? p.pair_off[b] : b * p.S;
+                meta_b = p.pair_cnt ? p.pair_cnt[b] : p.S;
+            }
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int r = h2 ? 128 + (wave & 3) * 16 + gr_l : wave * 16 + gr_l;
+            w_src[h2] = p.w + wtile_off(head * BN + r, 0, p.K) + (gc ^ qa_swz(r)) * 8;
+        }
+    };
+    locate(vb);
+    setup();
+    auto issue = [&](int q, int st, int slot) {
+        unsigned char* d;
+        const bf16* s;
+        if (q < 4) { d = smem + slot * SLOT + q * 8192 + wave * 1024; s = a_src[q] + st * 64; }
+        else if (q == 4) { d = smem + slot * SLOT + 2 * PLANE + wave * 1024; s = w_src[0] + st * 512; }
+        else { d = smem + slot * SLOT + 2 * PLANE + 8192 + (wave & 3) * 1024; s = w_src[1] + st * 512; }
+        __builtin_amdgcn_global_load_lds((glb_void*)s, (lds_void*)d, 16, 0, 0);
+    };
+
+    f32x4 acc[FM][FN];
+    const int ns = p.K / 32;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int laneA = (wm * TM + fr) * 128 + ((fk ^ ((fr >> 1) & 7)) << 4);          // hi fragment; lo: chunk ^ 4
+    const int laneB = 2 * PLANE + (wn * TN + fr) * 64 + ((fk ^ qa_swz(fr)) << 4);
+
+    // one phase per stage: all fragment reads (+ the six LDS-DMA pieces of stage s+2), counted wait, reads retired, barrier, 48 MFMAs,
+    // barrier.  Hazards as in gemm_pp.hip / gemm_ppw.hip: a slot's reads are retired before the first barrier of its stage, its refill is
+    // issued after the second; a stage's data is waited for one stage before it is read.
+    auto stage = [&](auto pre_tag, auto wait_tag, int s, int slot) {
+        constexpr bool PRE = decltype(pre_tag)::value;
+        constexpr int WAITN = decltype(wait_tag)::value;
+        const unsigned char* sb = smem + slot * SLOT;
+        const int nslot = slot == 0 ? NSLOT - 1 : slot - 1;
+        bf16x8 a[2][FM], b[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + laneB + j * 16 * 64);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(sb + (laneA ^ (pl << 6)) + i * 16 * 128);
+        if (PRE) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) issue(q, s + D, nslot);
+        }
+        if (WAITN >= 0) qa_wait_vmcnt<(WAITN >= 0 ? WAITN : 0)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        qa_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[pl][i], acc[i][j], 0, 0, 0);   // swapped operands: C^T fragment
+        __builtin_amdgcn_s_setprio(0);
+        qa_barrier();
+    };
+    auto first_stages = [&]() {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) issue(q, d, d);
+        }
+    };
+    first_stages();
+    qa_wait_vmcnt<P>();
+    qa_barrier();
+    if (wave >= NW / 2) qa_barrier();     // stagger the two halves by one barrier
+
+    // the staging area sits at the TOP of the ring, above the 44 KiB that a stage occupies in slot 0: the next tile's first stage is
+    // fetched into slot 0 while this tile's epilogue runs
+    float* stg = reinterpret_cast<float*>(smem + NSLOT * SLOT - QA_SUB * QA_LDROW * 4);
+    static_assert(NSLOT * SLOT - QA_SUB * QA_LDROW * 4 >= 2 * PLANE + 12 * 1024, "slot 0's stage must lie below the staging area");
+#ifdef MMS_LAB
+    // lab (timing only, results WRONG): p.lab_flags bit 0 drops the P V MFMAs, 1 the Q K^T MFMAs, 3 the context stores, 4 all attention work
+    const int QA_FLAGS = p.lab_flags;
+#else
+    constexpr int QA_FLAGS = 0;
+#endif
+#ifdef MMS_LAB
+    // lab: per-tile timeline of thread 0 (shader-clock stamps: loop start, loop end, dump 0, attention 0, dump 1, attention 1, next
+    // prologue done), first 8 tiles of every workgroup -> p.trace[(blockIdx.x * 8 + tile) * 8 + k]   (tools/qa_trace.py)
+    unsigned long long tr[7];
+    int tile_i = 0;
+#define QA_STAMP(k) do { if (p.trace) tr[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define QA_STAMP(k) do { } while (0)
+#endif
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        QA_STAMP(0);
+        const bool more = vb + (int)gridDim.x < nblk;
+        if (more) locate(vb + (int)gridDim.x);
+        int slot = 0, s = 0;
+        for (; s + D < ns; ++s) {
+            stage(std::true_type{}, std::integral_constant<int, (D - 1) * P>{}, s, slot);
+            slot = slot == NSLOT - 1 ? 0 : slot + 1;
+        }
+        stage(std::false_type{}, std::integral_constant<int, 0>{}, s, slot);         // stage ns-2: the last stage must have landed
+        slot = slot == NSLOT - 1 ? 0 : slot + 1;
+        ++s;
+        // park this tile's metadata in LDS; every wave passes a barrier between its own writes and the first read (waves 4-7: the last
+        // stage's; waves 0-3: the re-aligning one)
+        if (wave >= NW / 2) m_pair[tid - 256] = make_int2(meta_a, meta_b);
+        stage(std::false_type{}, std::integral_constant<int, -1>{}, s, slot);        // stage ns-1
+        if (wave < NW / 2) {
+            m_keyadd[tid] = __int_as_float(meta_a);
+            if (tid < BN) m_bias[tid] = __int_as_float(meta_b);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            qa_barrier();     // re-align the halves: nobody reads the ring any more
+        }
+        QA_STAMP(1);
+
+        // this tile's identity for the epilogue; then the next tile's addresses and its stage 0 (slot 0 is idle and below the staging area)
+        const int ehead = head;
+        const int4 esub0 = sub0, esub1 = sub1;
+        if (more) vb += (int)gridDim.x;
+        // ---- epilogue: per sub-tile  accumulators -> LDS, attention of its pairs for this head ----
+        const int mrow = lane & 15, nq = lane >> 4;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            if ((wm >> 1) == half) {
+                const float* bias = m_bias + wn * TN + nq * 4;
+                float* dst = stg + ((wm & 1) * TM + mrow) * QA_LDROW + wn * TN + nq * 4;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 16 * j);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        f32x4 v = acc[i][j];
+                        v += b4;
+                        *reinterpret_cast<f32x4*>(dst + 16 * i * QA_LDROW + 16 * j) = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if (more) {
+                // the four waves that have nothing to write in this phase set up their next tile and send out its stage 0 (slot 0 lies below
+                // the staging area)
+                setup();
+#pragma unroll
+                for (int q = 0; q < P; ++q) issue(q, 0, 0);
+            }
+            qa_barrier();
+#ifdef MMS_LAB
+            if (p.trace) tr[2 + 2 * half] = __builtin_readcyclecounter();
+#endif
+            const int4 sb = half ? esub1 : esub0;
+            // work items = (pair, 16-query tile), dealt round-robin to the eight waves in pair order: a pair of 17 .. 32 tokens is two items
+            // (four times the MFMAs of a short pair), and the phase lasts as long as its slowest wave
+            int item = 0;
+            int2 recs = make_int2(0, 0);
+#pragma unroll 1
+            for (int unit = 0; unit < sb.w; ++unit) {
+                if ((unit & 63) == 0) recs = m_pair[half * 128 + unit + lane];      // 64 pair records per read; the loop itself is scalar
+                const int g0 = __builtin_amdgcn_readlane(recs.x, unit & 63);       // the pair's first stream row
+                const int S = __builtin_amdgcn_readlane(recs.y, unit & 63);        // its live tokens (queries == keys)
+                const int nqt = (S + 15) >> 4;
+                const int first = item;
+                item += nqt;
+                // does any of this pair's query tiles fall to this wave?  tile qt belongs to wave (first + qt) % 8
+                if (S <= 0 || (((wave - first) & (NW - 1)) >= nqt) || (QA_FLAGS & 16)) continue;
+                const float* kadd = m_keyadd + half * 128 + (g0 - sb.x);
+                const float* base = stg + (g0 - sb.x) * QA_LDROW;           // staged rows of the pair: [Q 0..63 | K 64..127 | V 128..191]
+                float add[MAXT][4];
+#pragma unroll
+                for (int jt = 0; jt < MAXT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = jt * 16 + fk * 4 + r;
+                        add[jt][r] = j < S ? kadd[j] : -INFINITY;
+                    }
+#pragma unroll
+                for (int qt = 0; qt < MAXT; ++qt) {
+                    if (qt * 16 >= S || ((first + qt) & (NW - 1)) != wave) continue;
+                    f32x4 sc[MAXT];
+                    f32x4 o[4];
+                    if constexpr (FAST) {
+                        // ---- split-bf16 MFMA route (mms_config.fuse_attention = 2): Q, K, P, V as hi + lo bf16, three products each
+                        // (hi hi, hi lo, lo hi) on v_mfma_f32_16x16x32_bf16: 1/5 of the matrix-pipe time of the exact-fp32 route ----
+                        auto split8 = [](const float4& u, const float4& v, bf16x8& h, bf16x8& l) {
+                            const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { bf16 a, c; split_bf16(x[e], a, c); h[e] = a; l[e] = c; }
+                        };
+                        // S^T = K Q^T: first operand = K rows (j = 16 jt + fr), second = Q rows (i = 16 qt + fr); lane: d = 32 ds + 8 fk + 0..7
+                        bf16x8 qh[2], ql[2];
+                        {
+                            int i = qt * 16 + fr;
+                            i = i < S ? i : S - 1;
+                            const float* qp = base + i * QA_LDROW + 8 * fk;
+#pragma unroll
+                            for (int ds = 0; ds < 2; ++ds)
+                                split8(*reinterpret_cast<const float4*>(qp + 32 * ds), *reinterpret_cast<const float4*>(qp + 32 * ds + 4), qh[ds], ql[ds]);
+                        }
+#pragma unroll
+                        for (int jt = 0; jt < MAXT; ++jt) {
+                            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+                            if (jt * 16 < S && !(QA_FLAGS & 2)) {
+                                int j = jt * 16 + fr;
+                                j = j < S ? j : S - 1;
+                                const float* kp = base + j * QA_LDROW + 64 + 8 * fk;
+#pragma unroll
+                                for (int ds = 0; ds < 2; ++ds) {
+                                    bf16x8 kh, kl;
+                                    split8(*reinterpret_cast<const float4*>(kp + 32 * ds), *reinterpret_cast<const float4*>(kp + 32 * ds + 4), kh, kl);
+                                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ds], a4, 0, 0, 0);
+                                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ds], a4, 0, 0, 0);
+                                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ds], a4, 0, 0, 0);
+                                }
+                            }
+                            sc[jt] = a4;
+                        }
+                        // softmax over the keys (lane: key j = 16 jt + 4 fk + r of query i = fr): v_exp_f32 / v_rcp_f32 forms
+                        float m = -INFINITY;
+#pragma unroll
+                        for (int jt = 0; jt < MAXT; ++jt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = sc[jt][r] * 0.125f + add[jt][r];
+                                sc[jt][r] = v;
+                                m = fmaxf(m, v);
+                            }
+                        m = fmaxf(m, __shfl_xor(m, 16, 64));
+                        m = fmaxf(m, __shfl_xor(m, 32, 64));
+                        float sum = 0.f;
+#pragma unroll
+                        for (int jt = 0; jt < MAXT; ++jt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float e = __builtin_amdgcn_exp2f((sc[jt][r] - m) * 1.44269504088896340736f);
+                                sc[jt][r] = e;
+                                sum += e;
+                            }
+                        sum += __shfl_xor(sum, 16, 64);
+                        sum += __shfl_xor(sum, 32, 64);
+                        const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+                        for (int jt = 0; jt < MAXT; ++jt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sc[jt][r] *= inv;
+                        // O = P V, contraction over 32 key slots per MFMA: slot (fk, e) = key 16 (e >> 2) + 4 fk + (e & 3) of key-tile pair kp2 --
+                        // exactly the lane's own probabilities as first operand; second operand = V[key][d = 4 fr + dt], one MFMA triple per dt
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kp2 = 0; kp2 < (MAXT + 1) / 2; ++kp2) {
+                            if (kp2 * 32 >= S || (QA_FLAGS & 1)) continue;
+                            const bool two = 2 * kp2 + 1 < MAXT;
+                            bf16x8 ph, pl;
+                            {
+                                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                                const f32x4 p0 = sc[2 * kp2], p1 = two ? sc[2 * kp2 + 1 < MAXT ? 2 * kp2 + 1 : 0] : z;
+                                split8(float4{p0[0], p0[1], p0[2], p0[3]}, float4{p1[0], p1[1], p1[2], p1[3]}, ph, pl);
+                            }
+                            float4 vrow[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                int j = (2 * kp2 + (e >> 2)) * 16 + fk * 4 + (e & 3);
+                                j = j < S ? j : S - 1;       // P is exactly 0 there
+                                vrow[e] = *reinterpret_cast<const float4*>(base + j * QA_LDROW + 128 + fr * 4);
+                            }
+#pragma unroll
+                            for (int dt = 0; dt < 4; ++dt) {
+                                auto comp = [&](const float4& v) { return dt == 0 ? v.x : dt == 1 ? v.y : dt == 2 ? v.z : v.w; };
+                                bf16x8 vh, vl;
+                                split8(float4{comp(vrow[0]), comp(vrow[1]), comp(vrow[2]), comp(vrow[3])},
+                                       float4{comp(vrow[4]), comp(vrow[5]), comp(vrow[6]), comp(vrow[7])}, vh, vl);
+                                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh, o[dt], 0, 0, 0);
+                                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl, o[dt], 0, 0, 0);
+                                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh, o[dt], 0, 0, 0);
+                            }
+                        }
+                    } else {
+                    float4 qf[4];
+                    {
+                        int i = qt * 16 + fr;
+                        i = i < S ? i : S - 1;
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) qf[s4] = *reinterpret_cast<const float4*>(base + i * QA_LDROW + s4 * 16 + fk * 4);
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < MAXT; ++jt) {
+                        f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+                        if (jt * 16 < S && !(QA_FLAGS & 2)) {
+                            // K fragment of this key tile (attn.hip's layout: row j = 16 jt + fr, d = 16 s + 4 fk + 0..3), re-read per query
+                            // tile: LDS reads are cheap here, registers are not (the other sub-tile's accumulators are still live)
+                            int j = jt * 16 + fr;
+                            j = j < S ? j : S - 1;
+                            float4 kf[1][4];
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) kf[0][s4] = *reinterpret_cast<const float4*>(base + j * QA_LDROW + 64 + s4 * 16 + fk * 4);
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0][s4].x, qf[s4].x, a4, 0, 0, 0);
+                                a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0][s4].y, qf[s4].y, a4, 0, 0, 0);
+                                a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0][s4].z, qf[s4].z, a4, 0, 0, 0);
+                                a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0][s4].w, qf[s4].w, a4, 0, 0, 0);
+                            }
+                        }
+                        sc[jt] = a4;
+                    }
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int jt = 0; jt < MAXT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = sc[jt][r] * 0.125f + add[jt][r];
+                            sc[jt][r] = v;
+                            m = fmaxf(m, v);
+                        }
+                    m = fmaxf(m, __shfl_xor(m, 16, 64));
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    float sum = 0.f;
+#pragma unroll
+                    for (int jt = 0; jt < MAXT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = expf(sc[jt][r] - m);
+                            sc[jt][r] = e;
+                            sum += e;
+                        }
+                    sum += __shfl_xor(sum, 16, 64);
+                    sum += __shfl_xor(sum, 32, 64);
+                    const float inv = 1.0f / sum;
+#pragma unroll
+                    for (int jt = 0; jt < MAXT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[jt][r] *= inv;
+                    // O = P V: V fragment rows j = 16 jt + 4 fk + r, columns d = 4 fr + 0..3
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int jt = 0; jt < MAXT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (jt * 16 >= S || (QA_FLAGS & 1)) continue;
+                            int j = jt * 16 + fk * 4 + r;
+                            j = j < S ? j : S - 1;       // P is exactly 0 there
+                            const float4 vf = *reinterpret_cast<const float4*>(base + j * QA_LDROW + 128 + fr * 4);
+                            const float pv = sc[jt][r];
+                            o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.x, o[0], 0, 0, 0);
+                            o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.y, o[1], 0, 0, 0);
+                            o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.z, o[2], 0, 0, 0);
+                            o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.w, o[3], 0, 0, 0);
+                        }
+                    }
+                    // lane holds O[i = 16 qt + 4 fk + r][d = 4 fr + dt]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = qt * 16 + fk * 4 + r;
+                        if (i >= S || (QA_FLAGS & 8)) continue;
+                        const long long off = (long long)(g0 + i) * p.ldo + ehead * MMS_HEAD_DIM + fr * 4;
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            bf16 x, y;
+                            split_bf16(o[dt][r], x, y);
+                            hi[dt] = x;
+                            lo[dt] = y;
+                        }
+                        *reinterpret_cast<bf16x4*>(plane_ptr(p.o_hi, off)) = hi;
+                        *reinterpret_cast<bf16x4*>(plane_ptr(p.o_lo, off)) = lo;
+                    }
+                }
+            }
+            qa_barrier();
+#ifdef MMS_LAB
+            if (p.trace) tr[3 + 2 * half] = __builtin_readcyclecounter();
+#endif
+        }
+#ifdef MMS_LAB
+        auto dump_trace = [&]() {
+            if (p.trace && tid == 0 && tile_i < 8) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) p.trace[((long long)blockIdx.x * 8 + tile_i) * 8 + k] = tr[k];
+            }
+            ++tile_i;
+        };
+        if (!more) { tr[6] = tr[5]; dump_trace(); }
+#endif
+        if (!more) break;
+#pragma unroll
+        for (int q = 0; q < P; ++q) issue(q, 1, 1);       // slots 1 / 2 were under the staging area until the barrier above
+        // stage 0 has landed once at most P operations are outstanding: loads complete in issue order, so the six pieces just issued are
+        // all outstanding as long as any older load is (the context stores in between only add to the count)
+        qa_wait_vmcnt<P>();
+        qa_barrier();
+#ifdef MMS_LAB
+        QA_STAMP(6);
+        dump_trace();
+#endif
+        if (wave >= NW / 2) qa_barrier();    // stagger again
+    }
+}
+
+bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st) {
+    if (p.M <= 0) return true;
+    if (p.K % 64 || p.K < 128 || p.S > 48 || p.S <= 0 || !p.sub || !p.n_sub) return false;
+    int dev = 0;
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+                   ? prop.multiProcessorCount / 8 * 8 : 8;
+    }
+    // an upper bound of the tile count (the live count is on the device): every sub-tile but the last of a stream holds > 128 - S rows
+    const long long max_sub = p.M / (QA_SUB - p.S + 1) + 2, max_blk = (max_sub + 1) / 2 * MMS_HEADS;
+    const dim3 grid((unsigned)(max_blk < n_cu ? max_blk : n_cu)), block(512);
+    auto go = [&](const QkvAttnParams& q) {
+        // (pairs of 33 .. 48 tokens keep the exact-fp32 attention: the <3, true> instantiation does not fit the register file without scratch)
+        if (q.fast && q.S <= 32) hipLaunchKernelGGL((qkv_attn_kernel<2, true>), grid, block, 0, st, q);
+        else if (q.S <= 32) hipLaunchKernelGGL((qkv_attn_kernel<2, false>), grid, block, 0, st, q);
+        else hipLaunchKernelGGL((qkv_attn_kernel<3, false>), grid, block, 0, st, q);
+    };
+#ifdef MMS_LAB
+    static const bool want_trace = getenv("MMS_QA_TRACE") != nullptr;      // first launch only: /tmp/qa_trace.bin = [workgroup][8 tiles][8] u64
+    static bool traced = false;
+    if (want_trace && !traced) {
+        traced = true;
+        const size_t bytes = (size_t)grid.x * 8 * 8 * 8;
+        unsigned long long* buf = nullptr;
+        if (hipMalloc((void**)&buf, bytes) != hipSuccess) return false;
+        (void)hipMemsetAsync(buf, 0, bytes, st);
+        QkvAttnParams q = p;
+        q.trace = buf;
+        if (const char* e = getenv("MMS_QA_FLAGS")) q.lab_flags = atoi(e);
+        go(q);
+        std::vector<unsigned long long> hst(bytes / 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hst.data(), buf, bytes, hipMemcpyDeviceToHost);
+        (void)hipFree(buf);
+        if (FILE* f = fopen("/tmp/qa_trace.bin", "wb")) { fwrite(hst.data(), 8, hst.size(), f); fclose(f); }
+        return true;
+    }
+#endif
+    go(p);
+    return true;
+}

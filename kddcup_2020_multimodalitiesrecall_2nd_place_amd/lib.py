@@ -29,7 +29,7 @@ class MmsError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "model", "layers", "r_layers", "x_layers", "vocab", "inter", "max_pos", "type_vocab", "text_len",
-        "precision", "chunk_pairs", "stop_after", "device", "pack_tokens", "fuse_layernorm")]
+        "precision", "chunk_pairs", "stop_after", "device", "pack_tokens", "fuse_layernorm", "fuse_attention")]
 
 
 class ZkBatch(C.Structure):
@@ -58,12 +58,12 @@ class EnsembleBatch(C.Structure):
                 ("lx_input_ids", C.c_void_p), ("lx_input_mask", C.c_void_p)]
 
 
-ABI_VERSION = 3     # include/mmscore.h MMS_ABI_VERSION
+ABI_VERSION = 4     # include/mmscore.h MMS_ABI_VERSION
 
 EXPORTS = ("mms_version", "mms_global_error", "mms_create", "mms_destroy", "mms_last_error", "mms_load_weight",
            "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_score_ensemble", "mms_gemm_timing",
            "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_mx", "mms_dbg_gemm_ln", "mms_dbg_attention", "mms_dbg_layernorm", "mms_set_gemm_variant",
-           "mms_dbg_gemm_bench")
+           "mms_dbg_gemm_bench", "mms_dbg_counter")
 
 _lib = None
 
@@ -106,6 +106,8 @@ def load(path=None):
     lib.mms_dbg_attention.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     lib.mms_dbg_layernorm.argtypes = [vp, vp, vp, i64, vp, vp]
     lib.mms_set_gemm_variant.argtypes = [i32]
+    lib.mms_dbg_counter.argtypes = [vp, i32]
+    lib.mms_dbg_counter.restype = i64
     lib.mms_dbg_gemm_bench.argtypes = [i64, i64, i64, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float)]
     _lib = lib
     return lib
@@ -115,7 +117,7 @@ class Handle:
     """Owns one ``mms_handle`` (one model on one GPU)."""
 
     def __init__(self, cfg, precision: int = 2, device: int = 0, chunk_pairs: int = 0, stop_after: int = -1,
-                 pack_tokens: bool = True, fuse_layernorm: bool = False):
+                 pack_tokens: bool = True, fuse_layernorm: bool = False, fuse_attention: int = 0):
         self.lib = load()
         self.cfg = cfg
         c = Config()
@@ -128,6 +130,7 @@ class Handle:
         c.precision, c.chunk_pairs, c.stop_after, c.device = precision, chunk_pairs, stop_after, device
         c.pack_tokens = int(bool(pack_tokens))
         c.fuse_layernorm = int(bool(fuse_layernorm))
+        c.fuse_attention = int(fuse_attention)
         self._h = C.c_void_p()
         rc = self.lib.mms_create(C.byref(c), C.byref(self._h))
         if rc != 0:
@@ -156,6 +159,10 @@ class Handle:
         else:
             self._check(self.lib.mms_gemm_timing(self._h, int(enable), int(reset), None, None, None), "mms_gemm_timing")
         return ms.value, n.value, fl.value
+
+    def counter(self, which: int) -> int:
+        """mms_dbg_counter: 0 = fused QKV + attention launches since creation."""
+        return int(self.lib.mms_dbg_counter(self._h, which))
 
     def debug_read_x(self, dst_ptr, rows, stream_ptr):
         self._check(self.lib.mms_debug_read_x(self._h, dst_ptr, rows, stream_ptr), "mms_debug_read_x")

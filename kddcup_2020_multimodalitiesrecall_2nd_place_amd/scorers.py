@@ -30,7 +30,7 @@ def _is_np(x):
 
 class _Base:
     def __init__(self, cfg, weights: dict, precision="auto", device: int = 0, chunk_pairs: int = 0,
-                 stop_after: int = -1, dedup_labels: bool = True, pack_tokens: bool = True, fuse_layernorm: bool = False):
+                 stop_after: int = -1, dedup_labels: bool = True, pack_tokens: bool = True, fuse_layernorm: bool = False, fuse_attention: int = 0):
         """precision: 1 / 2 / 3 / 4 (4 = fp8 weights and activations on the big encoder GEMMs, outside the
         1e-3 contract) or "auto" = ``weights.auto_precision``: 2 for bf16-representable matrices, 3 for a real fp32 checkpoint."""
         if not torch.cuda.is_available():
@@ -43,7 +43,7 @@ class _Base:
         self.dedup_labels = dedup_labels
         self.precision = precision
         self.handle = _lib.Handle(cfg, precision=precision, device=device, chunk_pairs=chunk_pairs, stop_after=stop_after,
-                                  pack_tokens=pack_tokens, fuse_layernorm=fuse_layernorm)
+                                  pack_tokens=pack_tokens, fuse_layernorm=fuse_layernorm, fuse_attention=fuse_attention)
         self.handle.load_weights(weights)
         self.logits = None
 
