@@ -163,14 +163,17 @@ def run_timed(step, steps, warmup, world, dev, handles):
     per = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
     med = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
     gms = gn = gfl = 0.0
+    fused = [0.0, 0.0, 0.0]
     for h in handles:
+        for i, v in enumerate(h.fused_timing()):       # before the reset below
+            fused[i] += v
         ms, n, fl = h.gemm_timing(False, True, read=True)
         gms += ms; gn += n; gfl += fl
     if world > 1:
         t = torch.tensor([dt, med], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, med = float(t[0].item()), float(t[1].item())
-    return dt, med, gms, gn, gfl
+    return dt, med, gms, gn, gfl, fused
 
 
 def spawn_ranks(n, argv):
@@ -205,11 +208,13 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (precision 3 on fp32 weights, lds, lxmert, H2D-inclusive)")
     ap.add_argument("--fp32-weights", action="store_true", help="seeded weights NOT rounded to bf16 (what a real checkpoint looks like)")
-    ap.add_argument("--fuse-attn", type=int, default=0, help="mms_config.fuse_attention: QKV projection + self-attention in one kernel; 1 = exact-fp32 attention MFMAs (bit-identical to the two-kernel route), 2 = split-bf16 MFMAs")
+    ap.add_argument("--fuse-attn", type=int, default=-1, help="mms_config.fuse_attention (default: 2 in precision mode 2, else 0): QKV projection + self-attention in one kernel; 1 = exact-fp32 attention MFMAs (bit-identical to the two-kernel route), 2 = split-bf16 MFMAs")
     ap.add_argument("--fuse-ln", action="store_true", help="LayerNorm fused into the N = 768 GEMM epilogues (mms_config.fuse_layernorm)")
     ap.add_argument("--dense", action="store_true", help="keep padded tokens (reference layout) instead of packing live tokens")
     ap.add_argument("--all-boxes", action="store_true", help="worst case: every pair has 10 boxes")
     a = ap.parse_args()
+    if a.fuse_attn < 0:
+        a.fuse_attn = 2 if a.precision == 2 else 0
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a.gpus, sys.argv[1:])
@@ -287,7 +292,7 @@ def main():
         return step, feats_, feed_
 
     step, feats, feed = make_step(ps, counts, valid=a.workload == "valid")
-    dt, med, gemm_ms, gemm_n, gemm_fl = run_timed(step, a.steps, a.warmup, world, dev, handles)
+    dt, med, gemm_ms, gemm_n, gemm_fl, fused = run_timed(step, a.steps, a.warmup, world, dev, handles)
     value = total_pairs * a.steps / dt
     strong = None
     if world > 1 and a.workload == "bench":
@@ -295,7 +300,7 @@ def main():
         # (every rank takes part, so this runs on all ranks; rank 0 reports it)
         ps_s, counts_s, total_s, wl_s = one_job("bench-strong")
         step_s, _f, _fd = make_step(ps_s, counts_s)
-        dt_s, med_s, _gm, _gn, _gf = run_timed(step_s, a.steps, a.warmup, world, dev, handles)
+        dt_s, med_s, _gm, _gn, _gf, _fu = run_timed(step_s, a.steps, a.warmup, world, dev, handles)
         strong = {"value": round(total_s * a.steps / dt_s, 1), "unit": "pairs/s", "scaling": "strong", "ms_per_step": round(dt_s / a.steps * 1e3, 3),
                   "workload": wl_s, "pairs_per_gpu": [int(c) for c in counts_s], "pairs_total": int(total_s)}
         del _f, _fd
@@ -321,10 +326,12 @@ def main():
             live_frac = 1.0 if a.dense else round(float((cfgs["lds"].text_len + nb + (nb < N_BOX) + distinct).sum()) / (ps.n * cfgs["lds"].seq), 4)
         # HBM bytes per GEMM launch: NOT measured in this run (PMC passes need rocprofv3 around the process) -- the committed result of
         # tools/pmc_traffic.sh on this very workload, labelled as such
-        traffic = traffic_src = None
+        traffic = traffic_src = fused_traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % a.model)
-        if os.path.exists(tp) and not a.dense and a.precision == 2 and a.workload == "bench":
+        if os.path.exists(tp) and not a.dense and a.precision == 2 and a.workload == "bench" and \
+                json.load(open(tp)).get("fuse_attention", 0) == a.fuse_attn:
             traffic = round(json.load(open(tp))["hbm_bytes_per_launch"], 1)
+            fused_traffic = json.load(open(tp)).get("fused_hbm_bytes_per_launch")
             traffic_src = "profiles/pmc_traffic_%s.json (builder's rocprofv3 --pmc run of this workload, FETCH_SIZE x 2 + WRITE_SIZE; not re-measured here)" % a.model
         avg_launch_s = gemm_ms * 1e-3 / max(gemm_n, 1)
         kern = {1: "gemm_pp_kernel<1,*,0,true> 256x256 ping-pong phases, persistent", 2: "gemm_pp_kernel<2,*,0,true> 256x256 ping-pong phases, persistent",
@@ -361,6 +368,19 @@ def main():
                          "note": "achieved = sum over GEMM launches of executed 2*M_live*N*K (device-counted) / sum of hipEvent "
                                  "launch durations in the timed region (rank 0); traffic = PMC HBM bytes per launch from profiles/"},
         }
+        res["config"]["fuse_attention"] = a.fuse_attn
+        if fused[1] > 0:
+            # mms_config.fuse_attention: the QKV projections run inside qkv_attn_kernel, whose launches also do the attention of their
+            # pairs -- timed apart from the GEMM launches above, priced on the projection FLOPs alone
+            f_ach = fused[2] / (fused[0] * 1e-3) / 1e12
+            res["roofline"]["fused_qkv_attention"] = {
+                "kernel": "qkv_attn_kernel<*,%s> 256x192 tile (one head of [Q|K|V]) + in-LDS attention" % ("true" if a.fuse_attn == 2 else "false"),
+                "launches": int(fused[1]), "avg_launch_ms": round(fused[0] / fused[1], 4),
+                "achieved": round(f_ach, 2), "frac": round(f_ach / peak, 4),
+                "traffic": round(fused_traffic, 1) if fused_traffic else None,
+                "note": "projection FLOPs (2*M_live*2304*768) / launch duration INCLUDING the attention of the tile's pairs"}
+            res["roofline"]["achieved_incl_fused"] = round((gemm_fl + fused[2]) / ((gemm_ms + fused[0]) * 1e-3) / 1e12, 2)
+            res["roofline"]["frac_incl_fused"] = round(res["roofline"]["achieved_incl_fused"] / peak, 4)
         if strong is not None:
             res["strong"] = strong
         if world == 1 and not a.no_secondary and a.workload == "bench":
@@ -447,7 +467,7 @@ def secondary(a, local, dev, ps, feats, members, scorer, feed, value):
         fd = device_feed(name, {name: cfg}, ps, feats, dev)
         def st(first=False):
             s.score_prepared(prepare(s, name, fd))
-        dt, med, gms, gn, gfl = run_timed(st, 3, 1, 1, dev, [s.handle])
+        dt, med, gms, gn, gfl, _fu = run_timed(st, 3, 1, 1, dev, [s.handle])
         r = {"value": round(ps.n * 3 / dt, 1), "unit": "pairs/s", "precision_mode": s.precision,
              "gemm_tflops": round(gfl / (gms * 1e-3) / 1e12, 1), "frac": round(gfl / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
         if parity:   # checker: the oracle's fp32 port on the same (unrounded) weights, on 64 pairs OF THE TIMED BATCH ITSELF (the logits

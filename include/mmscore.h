@@ -192,6 +192,10 @@ int mms_score_ensemble(mms_handle* zk, mms_handle* lds, mms_handle* lxmert, cons
 /* accumulated hipEvent time (ms) and launch count of the GEMM kernels since the last reset;
  * enable = 1 brackets every GEMM launch with events on its stream (bench / roofline only) */
 int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out, int64_t* launches_out, double* flops_out);
+/* The fused QKV + attention launches (mms_config.fuse_attention) of the calls timed through mms_gemm_timing (enabled / reset there),
+ * reported apart from the GEMM launches because their duration includes the attention of their pairs: total ms, launches, executed
+ * projection FLOPs. */
+int mms_fused_timing(mms_handle* h, double* ms_out, int64_t* launches_out, double* flops_out);
 
 /* ---- debug / test hooks (kernel-level parity tests call the same kernels the scorers launch) ---- */
 int mms_debug_read_x(mms_handle* h, float* dst_dev, int64_t rows, void* stream); /* current hidden state -> fp32 [rows,768] */

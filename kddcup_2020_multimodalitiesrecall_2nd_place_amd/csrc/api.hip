@@ -131,6 +131,7 @@ struct mms_handle {
     size_t ev_used = 0;
     int64_t gemm_launches = 0;
     int64_t fused_attn_launches = 0;     // qkv_attn.hip launches since mms_create (mms_dbg_counter)
+    std::vector<hipEvent_t> ev_fused; size_t ev_fused_used = 0; int64_t fused_timed = 0;     // timing of the fused launches, apart from the GEMMs' (mms_fused_timing)
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
@@ -722,7 +723,9 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     const int64_t M = B * S;
     const bool f8 = h->f8 && in.f8;
     // one kernel for projection + attention (qkv_attn.hip) when the launch is big enough for a persistent grid and runs two-pass bf16
-    const bool fused_attn = pk.sub && w.wqkv_hm && !f8 && M >= 16384 && h->nsplit == 2 && !(h->x1_mask & 1);
+    // (streams of very short pairs -- lxmert's 10 box tokens -- stay on the two-kernel route: a dozen attention items per sub-tile make the
+    // fused epilogue cost more than the attention launch it replaces, profiles/r03q_*)
+    const bool fused_attn = pk.sub && w.wqkv_hm && !f8 && M >= 16384 && S >= 16 && h->nsplit == 2 && !(h->x1_mask & 1);
     if (fused_attn) {
         QkvAttnParams q{};
         const Planes a_in = in.at(row0 * H), c_out = h->ctx.at(row0 * H);
@@ -731,18 +734,18 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
         q.key_add = key_add; q.o_hi = c_out.hi; q.o_lo = c_out.lo; q.ldo = H;
         q.M = (int)M; q.m_dev = pk.rows; q.fast = h->fuse_attn == 2;
         if (h->alternate) { q.reverse = h->flip; h->flip ^= 1; }
-        if (h->timing) {
-            if (h->ev_used + 2 > h->ev.size()) {
-                h->ev.resize(h->ev_used + 2);
-                HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used]));
-                HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used + 1]));
+        if (h->timing) {      // timed apart from the GEMM launches: this launch's duration includes the attention of its pairs
+            if (h->ev_fused_used + 2 > h->ev_fused.size()) {
+                h->ev_fused.resize(h->ev_fused_used + 2);
+                HIP_TRY(h, hipEventCreate(&h->ev_fused[h->ev_fused_used]));
+                HIP_TRY(h, hipEventCreate(&h->ev_fused[h->ev_fused_used + 1]));
             }
-            q.flop_counter = h->flop_counter;
-            HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
+            q.flop_counter = h->flop_counter + 1;
+            HIP_TRY(h, hipEventRecord(h->ev_fused[h->ev_fused_used], st));
             if (!launch_qkv_attn(q, st)) return h->fail(MMS_ERR_ARG, "qkv_attn: shape not supported");
-            HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
-            h->ev_used += 2;
-            h->gemm_launches += 1;
+            HIP_TRY(h, hipEventRecord(h->ev_fused[h->ev_fused_used + 1], st));
+            h->ev_fused_used += 2;
+            h->fused_timed += 1;
         } else if (!launch_qkv_attn(q, st)) return h->fail(MMS_ERR_ARG, "qkv_attn: shape not supported");
         h->fused_attn_launches += 1;
     } else {
@@ -1309,6 +1312,7 @@ void mms_destroy(mms_handle* h) {
     free_pool(h->lq_sub_allocs);
     if (h->lq_store.hi) (void)hipFree(h->lq_store.hi);
     for (auto e : h->ev) (void)hipEventDestroy(e);
+    for (auto e : h->ev_fused) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -1579,9 +1583,9 @@ int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out
     DeviceScope dev(h->cfg.device);
     if (!h->flop_counter) {
         void* p;
-        if (int rc = dev_alloc(h, h->w_allocs, &p, 8)) return rc;
+        if (int rc = dev_alloc(h, h->w_allocs, &p, 16)) return rc;      // [0]: GEMM launches, [1]: fused QKV + attention launches
         h->flop_counter = (unsigned long long*)p;
-        HIP_TRY(h, hipMemset(p, 0, 8));
+        HIP_TRY(h, hipMemset(p, 0, 16));
     }
     if (ms_out || launches_out || flops_out) {
         double ms = 0;
@@ -1597,8 +1601,28 @@ int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out
         if (launches_out) *launches_out = h->gemm_launches;
         if (flops_out) *flops_out = (double)fl;
     }
-    if (reset) { h->ev_used = 0; h->gemm_launches = 0; HIP_TRY(h, hipMemset(h->flop_counter, 0, 8)); }
+    if (reset) { h->ev_used = 0; h->gemm_launches = 0; h->ev_fused_used = 0; h->fused_timed = 0; HIP_TRY(h, hipMemset(h->flop_counter, 0, 16)); }
     h->timing = enable != 0;
+    return MMS_OK;
+}
+
+// the fused QKV + attention launches (mms_config.fuse_attention) of the calls timed by mms_gemm_timing, which neither counts nor resets
+// them separately: total duration, launches, executed projection FLOPs (2 * M_live * 2304 * 768 per launch)
+int mms_fused_timing(mms_handle* h, double* ms_out, int64_t* launches_out, double* flops_out) {
+    if (!h) return MMS_ERR_ARG;
+    DeviceScope dev(h->cfg.device);
+    double ms = 0;
+    if (h->ev_fused_used) HIP_TRY(h, hipEventSynchronize(h->ev_fused[h->ev_fused_used - 1]));
+    for (size_t i = 0; i + 1 < h->ev_fused_used; i += 2) {
+        float t = 0;
+        HIP_TRY(h, hipEventElapsedTime(&t, h->ev_fused[i], h->ev_fused[i + 1]));
+        ms += t;
+    }
+    unsigned long long fl = 0;
+    if (h->flop_counter) HIP_TRY(h, hipMemcpy(&fl, h->flop_counter + 1, 8, hipMemcpyDeviceToHost));
+    if (ms_out) *ms_out = ms;
+    if (launches_out) *launches_out = h->fused_timed;
+    if (flops_out) *flops_out = (double)fl;
     return MMS_OK;
 }
 

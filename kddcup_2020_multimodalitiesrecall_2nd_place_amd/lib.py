@@ -63,7 +63,7 @@ ABI_VERSION = 4     # include/mmscore.h MMS_ABI_VERSION
 EXPORTS = ("mms_version", "mms_global_error", "mms_create", "mms_destroy", "mms_last_error", "mms_load_weight",
            "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_score_ensemble", "mms_gemm_timing",
            "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_mx", "mms_dbg_gemm_ln", "mms_dbg_attention", "mms_dbg_layernorm", "mms_set_gemm_variant",
-           "mms_dbg_gemm_bench", "mms_dbg_counter")
+           "mms_dbg_gemm_bench", "mms_dbg_counter", "mms_fused_timing")
 
 _lib = None
 
@@ -107,6 +107,7 @@ def load(path=None):
     lib.mms_dbg_layernorm.argtypes = [vp, vp, vp, i64, vp, vp]
     lib.mms_set_gemm_variant.argtypes = [i32]
     lib.mms_dbg_counter.argtypes = [vp, i32]
+    lib.mms_fused_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.mms_dbg_counter.restype = i64
     lib.mms_dbg_gemm_bench.argtypes = [i64, i64, i64, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float)]
     _lib = lib
@@ -158,6 +159,12 @@ class Handle:
             self._check(self.lib.mms_gemm_timing(self._h, int(enable), int(reset), C.byref(ms), C.byref(n), C.byref(fl)), "mms_gemm_timing")
         else:
             self._check(self.lib.mms_gemm_timing(self._h, int(enable), int(reset), None, None, None), "mms_gemm_timing")
+        return ms.value, n.value, fl.value
+
+    def fused_timing(self):
+        """(ms, launches, projection flops) of the fused QKV + attention launches timed since the last gemm_timing reset."""
+        ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+        self._check(self.lib.mms_fused_timing(self._h, C.byref(ms), C.byref(n), C.byref(fl)), "mms_fused_timing")
         return ms.value, n.value, fl.value
 
     def counter(self, which: int) -> int:

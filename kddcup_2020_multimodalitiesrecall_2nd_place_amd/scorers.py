@@ -30,7 +30,7 @@ def _is_np(x):
 
 class _Base:
     def __init__(self, cfg, weights: dict, precision="auto", device: int = 0, chunk_pairs: int = 0,
-                 stop_after: int = -1, dedup_labels: bool = True, pack_tokens: bool = True, fuse_layernorm: bool = False, fuse_attention: int = 0):
+                 stop_after: int = -1, dedup_labels: bool = True, pack_tokens: bool = True, fuse_layernorm: bool = False, fuse_attention="auto"):
         """precision: 1 / 2 / 3 / 4 (4 = fp8 weights and activations on the big encoder GEMMs, outside the
         1e-3 contract) or "auto" = ``weights.auto_precision``: 2 for bf16-representable matrices, 3 for a real fp32 checkpoint."""
         if not torch.cuda.is_available():
@@ -38,6 +38,10 @@ class _Base:
         if precision == "auto":
             from .weights import auto_precision
             precision = auto_precision(weights)
+        if fuse_attention == "auto":
+            # mms_config.fuse_attention = 1 (QKV projection + self-attention in one kernel, bit-identical results) wherever it is faster:
+            # zk / lds +3 %, lxmert -0.4 % (profiles/r03q_*); 2 (split-bf16 attention MFMAs, another +2 %) is opt-in
+            fuse_attention = 0 if cfg.name == "lxmert" else 1
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         self.dedup_labels = dedup_labels

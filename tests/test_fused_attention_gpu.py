@@ -7,6 +7,7 @@ import torch
 
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd import scorers, synth, weights
 from kddcup_2020_multimodalitiesrecall_2nd_place_amd.config import LdsConfig, LxmertConfig, ZkConfig
+from oracle import np_models as O
 
 pytestmark = pytest.mark.gpu
 
@@ -32,8 +33,8 @@ CFGS = {"zk": lambda: ZkConfig(layers=3), "lds": lambda: LdsConfig(layers=3), "l
 def test_fused_attention_is_bit_identical_to_the_two_kernel_route(name, pack):
     cfg = CFGS[name]()
     w = weights.make_weights(cfg)
-    ps, b = _feed(cfg, 100, 30, "/fuseattn")          # 3000 pairs: 30 000 .. 120 000 padded rows per stream (>= 16 384: the fused route runs)
-    s0 = scorers.make_scorer(cfg, w, precision=2, pack_tokens=pack)
+    ps, b = _feed(cfg, 100, 30, "/fuseattn")          # 3000 pairs: 69 000 .. 120 000 padded rows in every fused stream (>= 16 384)
+    s0 = scorers.make_scorer(cfg, w, precision=2, pack_tokens=pack, fuse_attention=0)
     s1 = scorers.make_scorer(cfg, w, precision=2, pack_tokens=pack, fuse_attention=1)
     s2 = scorers.make_scorer(cfg, w, precision=2, pack_tokens=pack, fuse_attention=2)
     l0 = scorers.score_batch(s0, b)[0].cpu().numpy()
@@ -48,6 +49,13 @@ def test_fused_attention_is_bit_identical_to_the_two_kernel_route(name, pack):
     d = np.linalg.norm(l2 - l0, axis=1) / np.maximum(np.linalg.norm(l0, axis=1), 0.1)
     print("fuse_attention=2 vs two-kernel route: median %.2e max %.2e" % (np.median(d), d.max()))
     assert np.median(d) < 2e-5 and d.max() < 5e-4, (np.median(d), d.max())
+    # ... and against the fp64 oracle itself, on the pairs that moved most and a few random ones (same bound as the parity tests)
+    idx = np.sort(np.unique(np.concatenate([np.argsort(-d)[:3], np.random.RandomState(3).choice(ps.n, 5, replace=False)])))
+    ti = torch.as_tensor(idx, device="cuda")
+    sub = {k: (v[ti].cpu().numpy() if torch.is_tensor(v) else (v[idx] if hasattr(v, "__len__") and len(v) == ps.n else v)) for k, v in b.items()}
+    ref, _ = O.forward(cfg, w, sub, np.float64)
+    err = np.linalg.norm(l2[idx] - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 0.1)
+    assert err.max() < 1e-3, err
 
 
 def test_fused_attention_ragged_extremes():
@@ -61,7 +69,7 @@ def test_fused_attention_ragged_extremes():
     lq[rs.rand(ps2.n) < 0.3] = 1
     b["len_query_"] = lq
     for chunk in (0, 1000):
-        s0 = scorers.make_scorer(cfg, w, precision=2, chunk_pairs=chunk)
+        s0 = scorers.make_scorer(cfg, w, precision=2, chunk_pairs=chunk, fuse_attention=0)
         s1 = scorers.make_scorer(cfg, w, precision=2, chunk_pairs=chunk, fuse_attention=1)
         l0 = scorers.score_batch(s0, b)[0].cpu().numpy()
         l1 = scorers.score_batch(s1, b)[0].cpu().numpy()
@@ -69,6 +77,19 @@ def test_fused_attention_ragged_extremes():
         s0.close(); s1.close()
         assert n1 > 0
         assert np.array_equal(l0, l1), (chunk, np.abs(l0 - l1).max())
+
+
+def test_default_is_the_bit_identical_fused_route_except_for_lxmert():
+    """scorers' fuse_attention="auto": 1 for zk / lds (faster, same bits), 0 for lxmert (not faster there)."""
+    for name, want in (("zk", True), ("lds", True), ("lxmert", False)):
+        cfg = CFGS[name]()
+        w = weights.make_weights(cfg)
+        ps, b = _feed(cfg, 100, 30, "/fuseattn4")
+        s = scorers.make_scorer(cfg, w, precision=2)
+        scorers.score_batch(s, b)
+        n = s.handle.counter(0)
+        s.close()
+        assert (n > 0) == want, (name, n)
 
 
 def test_fused_attention_other_precisions_keep_the_two_kernel_route():

@@ -15,7 +15,7 @@ out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open("$R/gpurun_out/pmc/${tag}_%s_counter_collection.csv" % c)):
-        k = "gemm" if "gemm" in r["Kernel_Name"] else ("attn" if "attn" in r["Kernel_Name"] else ("ln" if "k_ln" in r["Kernel_Name"] else "other"))
+        k = "qkv_attn" if "qkv_attn" in r["Kernel_Name"] else "gemm" if "gemm" in r["Kernel_Name"] else ("attn" if "attn" in r["Kernel_Name"] else ("ln" if "k_ln" in r["Kernel_Name"] else "other"))
         agg[k] += float(r["Counter_Value"]); n[k] += 1
     out[c] = {k: {"sum_kb": agg[k], "dispatches": n[k]} for k in agg}
 g_f, g_w = out["FETCH_SIZE"]["gemm"], out["WRITE_SIZE"]["gemm"]
@@ -25,6 +25,13 @@ res = {"tag": "$tag", "gemm_launches": g_f["dispatches"],
        "write_bytes_per_launch_uncalibrated": g_w["sum_kb"] * 1024 / g_w["dispatches"],
        "all": out}
 res["hbm_bytes_per_launch"] = res["fetch_bytes_per_launch_x2_corrected"] + res["write_bytes_per_launch_uncalibrated"]
+if "qkv_attn" in out["FETCH_SIZE"]:     # the fused QKV + attention launches (mms_config.fuse_attention), same corrections
+    q_f, q_w = out["FETCH_SIZE"]["qkv_attn"], out["WRITE_SIZE"]["qkv_attn"]
+    res["fused_launches"] = q_f["dispatches"]
+    res["fused_hbm_bytes_per_launch"] = 2 * q_f["sum_kb"] * 1024 / q_f["dispatches"] + q_w["sum_kb"] * 1024 / q_w["dispatches"]
+for line in open("$R/gpurun_out/pmc/${tag}_FETCH_SIZE.log"):     # which route the measured pass took (bench.py's own line)
+    if line.startswith("{"):
+        res["fuse_attention"] = json.loads(line)["config"].get("fuse_attention", 0)
 json.dump(res, open("$R/gpurun_out/pmc/${tag}_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "all"}))
 PY

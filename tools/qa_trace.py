@@ -33,7 +33,7 @@ if __name__ == "__main__":
     feats *= (torch.arange(10, device=dev)[None, :] < torch.as_tensor(ps.num_boxes, device=dev)[:, None])[:, :, None]
     ps.feats = feats
     b = synth.batch_for(cfg, ps)
-    s = scorers.make_scorer(cfg, w, precision=2, fuse_attention=True)
+    s = scorers.make_scorer(cfg, w, precision=2, fuse_attention=int(os.environ.get("QA_FUSE", 1)))
     scorers.score_batch(s, b)
     torch.cuda.synchronize()
     s.close()
