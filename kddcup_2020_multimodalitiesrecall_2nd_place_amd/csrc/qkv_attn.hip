@@ -79,7 +79,7 @@ __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __
         int rows = 0, row0 = 0, pair0 = p0, ns = 0;
         for (int b = p0; b < p1; ++b) {
             const int c = cnt ? cnt[b] : S;
-            if (rows + c > QA_SUB) {
+            if (rows + c > QA_SUB || (rows > 0 && b - pair0 >= QA_SUB)) {      // (the kernel keeps at most 128 pair records per sub-tile)
                 if (out >= 0) sub[out + ns] = make_int4(row0, rows, pair0, b - pair0);
                 ++ns;
                 rows = 0;

@@ -15,6 +15,10 @@ python $R/bench.py --precision 4 --no-cpu --no-secondary > $O/bench_zk_fp8.json 
 python $R/bench.py --model ensemble --precision 4 --no-cpu --no-secondary > $O/bench_ensemble_fp8.json 2> $O/bench_ensemble_fp8.err
 python $R/bench.py --workload valid --no-cpu --no-secondary > $O/bench_zk_valid.json 2> $O/bench_zk_valid.err
 python $R/bench.py --fuse-ln --no-cpu --no-secondary > $O/bench_zk_fuseln.json 2> $O/bench_zk_fuseln.err
+for f in 0 1; do   # mms_config.fuse_attention off / exact-fp32 attention (the default line above runs 2: split-bf16 attention MFMAs)
+  python $R/bench.py --fuse-attn $f --no-cpu --no-secondary > $O/bench_zk_fuseattn$f.json 2> $O/bench_zk_fuseattn$f.err
+done
+python $R/bench.py --precision 3 --fp32-weights --no-cpu --no-secondary > $O/bench_zk_mode3.json 2> $O/bench_zk_mode3.err
 MMS_BENCH_SHARE_GPU=1 MMS_BENCH_BACKEND=gloo python $R/bench.py --gpus 2 --no-cpu > $O/bench_zk_2ranks_shared_gpu.json 2> $O/bench_zk_2ranks_shared_gpu.err
 python $R/bench.py --workload testB --no-cpu --no-secondary > $O/bench_zk_testB.json 2> $O/bench_zk_testB.err
 for m in zk ensemble; do
