@@ -62,7 +62,16 @@ constexpr int QA_SEG = 8192;
 __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __restrict__ off, const int* __restrict__ cnt, int n, int S,
                                                                    const int* __restrict__ rows_dev, int4* __restrict__ sub, int* __restrict__ n_sub) {
     __shared__ int sh[QA_PLAN_THREADS];
+    // the per-pair token counts (<= 48) as bytes in LDS: each thread then walks its ~500 pairs twice without a global access in the loop
+    // (530 us -> ~60 us per plan); streams of more pairs than fit read them from memory
+    constexpr int QA_PLAN_CACHE = 96 * 1024;
+    __shared__ unsigned char cnt8[QA_PLAN_CACHE];
     const int tid = threadIdx.x;
+    const bool cached = cnt && n <= QA_PLAN_CACHE;
+    if (cached) {
+        for (int b = tid; b < n; b += QA_PLAN_THREADS) cnt8[b] = (unsigned char)cnt[b];
+        __syncthreads();
+    }
     const long long total = off ? (rows_dev ? (long long)*rows_dev : (long long)off[n - 1] + cnt[n - 1]) : (long long)n * S;
     long long seg = QA_SEG;
     if (total > seg * QA_PLAN_THREADS) seg = ((total + QA_PLAN_THREADS - 1) / QA_PLAN_THREADS + 127) / 128 * 128;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __
     auto pack = [&](int out) {       // out < 0: count only
         int rows = 0, row0 = 0, pair0 = p0, ns = 0;
         for (int b = p0; b < p1; ++b) {
-            const int c = cnt ? cnt[b] : S;
+            const int c = cached ? (int)cnt8[b] : cnt ? cnt[b] : S;
             if (rows + c > QA_SUB || (rows > 0 && b - pair0 >= QA_SUB)) {      // (the kernel keeps at most 128 pair records per sub-tile)
                 if (out >= 0) sub[out + ns] = make_int4(row0, rows, pair0, b - pair0);
                 ++ns;
