@@ -436,10 +436,29 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                         for (int jt = 0; jt < MAXT; ++jt)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) sc[jt][r] *= inv;
-                        // O = P V, contraction over 32 key slots per MFMA: slot (fk, e) = key 16 (e >> 2) + 4 fk + (e & 3) of key-tile pair kp2 --
-                        // exactly the lane's own probabilities as first operand; second operand = V[key][d = 4 fr + dt], one MFMA triple per dt
 #pragma unroll
                         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (MAXT > 2) {
+                        // pairs of 33 .. 48 tokens: O = P V on the exact-fp32 MFMAs (attn.hip's form) -- the eight V rows a lane would hold for the
+                        // split-bf16 form do not fit beside three score tiles.  (For MAXT = 2 this form measured 1 % SLOWER than the split-bf16 one
+                        // although it needs no operand conversion: profiles/r03v_bench_pv.txt)
+#pragma unroll
+                        for (int jt = 0; jt < MAXT; ++jt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if (jt * 16 >= S || (QA_FLAGS & 1)) continue;
+                                int j = jt * 16 + fk * 4 + r;
+                                j = j < S ? j : S - 1;       // P is exactly 0 there
+                                const float4 vf = *reinterpret_cast<const float4*>(base + j * QA_LDROW + 128 + fr * 4);
+                                const float pv = sc[jt][r];
+                                o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.x, o[0], 0, 0, 0);
+                                o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.y, o[1], 0, 0, 0);
+                                o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.z, o[2], 0, 0, 0);
+                                o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.w, o[3], 0, 0, 0);
+                            }
+                        } else {
+                        // O = P V, contraction over 32 key slots per MFMA: slot (fk, e) = key 16 (e >> 2) + 4 fk + (e & 3) of key-tile pair kp2 --
+                        // exactly the lane's own probabilities as first operand; second operand = V[key][d = 4 fr + dt], one MFMA triple per dt
 #pragma unroll
                         for (int kp2 = 0; kp2 < (MAXT + 1) / 2; ++kp2) {
                             if (kp2 * 32 >= S || (QA_FLAGS & 1)) continue;
@@ -467,6 +486,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl, o[dt], 0, 0, 0);
                                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh, o[dt], 0, 0, 0);
                             }
+                        }
                         }
                     } else {
                     float4 qf[4];
@@ -605,9 +625,10 @@ bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st) {
     const long long max_sub = p.M / (QA_SUB - p.S + 1) + 2, max_blk = (max_sub + 1) / 2 * MMS_HEADS;
     const dim3 grid((unsigned)(max_blk < n_cu ? max_blk : n_cu)), block(512);
     auto go = [&](const QkvAttnParams& q) {
-        // (pairs of 33 .. 48 tokens keep the exact-fp32 attention: the <3, true> instantiation does not fit the register file without scratch)
-        if (q.fast && q.S <= 32) hipLaunchKernelGGL((qkv_attn_kernel<2, true>), grid, block, 0, st, q);
-        else if (q.S <= 32) hipLaunchKernelGGL((qkv_attn_kernel<2, false>), grid, block, 0, st, q);
+        if (q.fast) {
+            if (q.S <= 32) hipLaunchKernelGGL((qkv_attn_kernel<2, true>), grid, block, 0, st, q);
+            else hipLaunchKernelGGL((qkv_attn_kernel<3, true>), grid, block, 0, st, q);
+        } else if (q.S <= 32) hipLaunchKernelGGL((qkv_attn_kernel<2, false>), grid, block, 0, st, q);
         else hipLaunchKernelGGL((qkv_attn_kernel<3, false>), grid, block, 0, st, q);
     };
 #ifdef MMS_LAB
