@@ -385,6 +385,10 @@ def main():
             res["strong"] = strong
         if world == 1 and not a.no_secondary and a.workload == "bench":
             res["secondary"] = secondary(a, local, dev, ps, feats, members, scorer, feed, value)
+            if "precision3" in res["secondary"]:
+                # the real-checkpoint mode as a top-level value of the line: the same batch scored by a zk handle whose
+                # weights are NOT bf16-rounded (precision "auto" -> mode 3), with its parity against the oracle's fp32 port on the timed batch
+                res["value_fp32_checkpoint"] = res["secondary"]["precision3"]
         if world == 1 and not a.no_cpu:
             n0 = "zk" if a.model == "ensemble" else a.model
             cfg0, w0, s0 = members[n0]

@@ -37,6 +37,7 @@ def test_bench_prints_one_contract_line():
     p3 = sec["precision3"]
     assert p3["precision_mode"] == 3 and p3["value"] > 0 and p3["parity_max_vecrel_vs_fp32_port"] < 1e-3
     assert sec["lds"]["value"] > 0 and sec["lxmert"]["value"] > 0
+    assert d["value_fp32_checkpoint"] == p3 and d["config"]["fuse_attention"] == 2     # mode 3 also as a top-level value; the route the line ran
 
 
 @pytest.mark.gpu
