@@ -42,7 +42,7 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         variant = 99;
     }
 #endif
-    if (variant != 1 && variant != 4 && variant != 16 && variant != 20 && variant != 26
+    if (variant != 1 && variant != 4 && variant != 16 && variant != 20 && variant != 26 && variant != 28
 #ifdef MMS_LAB
         && variant != 3
 #endif
@@ -52,6 +52,7 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         if (p.N % 256 == 0 && p.M >= 16384) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)
         else variant = (p.N >= 1536 && p.N % 256 == 0 && p.M >= 8192) ? 16 : 4;
     }
+    if (variant == 28) { if (launch_gemm_dw(p, nsplit, st)) return; variant = 26; }
     if (variant == 26) { if (launch_gemm_pp(p, nsplit, 0, st, true)) return; variant = 4; }
     if (variant == 20) { if (launch_gemm_pp(p, nsplit, 0, st)) return; variant = 4; }
     if (launch_gemm_tile(p, nsplit, variant, st)) return;

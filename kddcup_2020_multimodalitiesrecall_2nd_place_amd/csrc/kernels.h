@@ -51,6 +51,7 @@ struct GemmParams {
 };
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
+bool launch_gemm_dw(const GemmParams& p, int nsplit, hipStream_t st);                                                       // gemm_dw.hip (variant 28: 128x256 tiles, two 4-wave workgroups per CU)
 bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist = false);                     // gemm_pp.hip (variant 20: 256x256 ping-pong phases)
 bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm_pp.hip + gemm_pp_ln.h: N = 768 with the fused residual + LayerNorm epilogue (nsplit 2)
 #ifdef MMS_LAB

@@ -45,7 +45,7 @@ GEMM_CASES = [
 
 
 # the tile engines a forward can launch (gemm_dispatch.hip): 128x128, 128x256, 256x256/16 waves, 256x256 persistent ping-pong
-GEMM_VARIANTS = [1, 4, 16, 26]
+GEMM_VARIANTS = [1, 4, 16, 26, 28]
 
 
 @pytest.fixture
