@@ -342,7 +342,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "ms_per_step_median_hipevent": round(med, 3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": DTYPES[a.precision], "data": "synthetic",
+            "dtype": DTYPES[a.precision] + ("; fused self-attention: Q K^T / P V on split-bf16 MFMAs (hi + lo operands, 3 products)" if a.fuse_attn == 2 and a.precision == 2 else ""),
+            "data": "synthetic",
             "config": {"workload": ("imagebert_%s 12-layer, " % a.model if a.model in ("zk", "lds") else
                                     "lxmert 9/5/5, " if a.model == "lxmert" else
                                     "3-model ensemble (imagebert_zk on the query and on its sen2forest rewrite + imagebert_lds + lxmert, fused entry point), ")
