@@ -208,13 +208,13 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (precision 3 on fp32 weights, lds, lxmert, H2D-inclusive)")
     ap.add_argument("--fp32-weights", action="store_true", help="seeded weights NOT rounded to bf16 (what a real checkpoint looks like)")
-    ap.add_argument("--fuse-attn", type=int, default=-1, help="mms_config.fuse_attention (default: 2 in precision mode 2, else 0): QKV projection + self-attention in one kernel; 1 = exact-fp32 attention MFMAs (bit-identical to the two-kernel route), 2 = split-bf16 MFMAs")
+    ap.add_argument("--fuse-attn", type=int, default=-1, help="mms_config.fuse_attention (default: 2 in precision modes 2 / 3, else 0): QKV projection + self-attention in one kernel; 1 = exact-fp32 attention MFMAs (bit-identical to the two-kernel route), 2 = split-bf16 MFMAs")
     ap.add_argument("--fuse-ln", action="store_true", help="LayerNorm fused into the N = 768 GEMM epilogues (mms_config.fuse_layernorm)")
     ap.add_argument("--dense", action="store_true", help="keep padded tokens (reference layout) instead of packing live tokens")
     ap.add_argument("--all-boxes", action="store_true", help="worst case: every pair has 10 boxes")
     a = ap.parse_args()
     if a.fuse_attn < 0:
-        a.fuse_attn = 2 if a.precision == 2 else 0
+        a.fuse_attn = 2 if a.precision in (2, 3) else 0
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a.gpus, sys.argv[1:])
@@ -342,7 +342,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "ms_per_step_median_hipevent": round(med, 3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": DTYPES[a.precision] + ("; fused self-attention: Q K^T / P V on split-bf16 MFMAs (hi + lo operands, 3 products)" if a.fuse_attn == 2 and a.precision == 2 else ""),
+            "dtype": DTYPES[a.precision] + ("; fused self-attention: Q K^T / P V on split-bf16 MFMAs (hi + lo operands, 3 products)" if a.fuse_attn == 2 and a.precision in (2, 3) else ""),
             "data": "synthetic",
             "config": {"workload": ("imagebert_%s 12-layer, " % a.model if a.model in ("zk", "lds") else
                                     "lxmert 9/5/5, " if a.model == "lxmert" else
@@ -468,7 +468,7 @@ def secondary(a, local, dev, ps, feats, members, scorer, feed, value):
     def quick(name, precision, fp32_weights, parity):
         cfg = CFGS[name]()
         w = weights.make_weights(cfg, bf16_matrices=not fp32_weights)
-        s = scorers.make_scorer(cfg, w, precision=precision, device=local, chunk_pairs=a.chunk)
+        s = scorers.make_scorer(cfg, w, precision=precision, device=local, chunk_pairs=a.chunk, fuse_attention=a.fuse_attn)
         fd = device_feed(name, {name: cfg}, ps, feats, dev)
         def st(first=False):
             s.score_prepared(prepare(s, name, fd))

@@ -91,7 +91,8 @@ typedef struct mms_config {
     int32_t fuse_attention;   /* 1: the self-attention sub-layers of launches with >= 16384 rows run the Q / K / V projection and the
                                  attention in ONE kernel (qkv_attn.hip: a workgroup projects one head of a 256-row tile, keeps the 192
                                  result columns in LDS and attends from there), so the fp32 [rows][2304] Q | K | V tensor never goes
-                                 through HBM.  Precision mode 2 only; context rows bit-identical to the two-kernel route.
+                                 through HBM.  Precision modes 2 and 3 (mode 3: a 192-row tile variant with the weights' lo plane in the ring); context
+                                 rows bit-identical to the two-kernel route.
                                  2: the same with the attention's Q K^T and P V on split-bf16 MFMAs (hi + lo operands, three products,
                                  v_exp_f32 / v_rcp_f32 softmax) instead of exact-fp32 MFMAs: ~2^-16 relative on the scores */
 } mms_config;

@@ -299,7 +299,7 @@ int load_att(mms_handle* h, bool tf, const std::string& self_scope, const std::s
         if (int rc = mat_f8(h, out_scope + (tf ? "/dense/kernel" : ".dense.weight"), H, H, tf, &w->wo8, &w->wos)) return rc;
     }
     if (int rc = cat_vec(h, bnames, H, &w->bqkv)) return rc;
-    if (h->fuse_attn && h->nsplit == 2) {
+    if (h->fuse_attn && (h->nsplit == 2 || h->nsplit == 3) && !h->f8) {
         std::vector<MatSrc> hm;
         std::vector<float> bhm;
         for (int hd = 0; hd < MMS_HEADS; ++hd)
@@ -704,8 +704,8 @@ struct Pack { const int* off = nullptr; const int* cnt = nullptr; const int* row
 
 // sub-tile table of one token stream (n pairs of at most S tokens; packed or dense) for qkv_attn.hip, in table slot `slot`
 void plan_tiles(mms_handle* h, hipStream_t st, Pack& pk, int64_t n, int S, int slot) {
-    if (!h->fuse_attn || h->nsplit != 2 || h->f8 || S > 48) return;
-    launch_qkv_tile_plan(pk.off, pk.cnt, pk.rows, (int)n, S, h->qa_sub[slot], h->qa_nsub + slot, st);
+    if (!h->fuse_attn || (h->nsplit != 2 && h->nsplit != 3) || h->f8 || S > 48) return;
+    launch_qkv_tile_plan(pk.off, pk.cnt, pk.rows, (int)n, S, h->qa_sub[slot], h->qa_nsub + slot, h->nsplit, st);
     pk.sub = h->qa_sub[slot]; pk.n_sub = h->qa_nsub + slot;
 }
 
@@ -725,11 +725,12 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     // one kernel for projection + attention (qkv_attn.hip) when the launch is big enough for a persistent grid and runs two-pass bf16
     // (streams of very short pairs -- lxmert's 10 box tokens -- stay on the two-kernel route: a dozen attention items per sub-tile make the
     // fused epilogue cost more than the attention launch it replaces, profiles/r03q_*)
-    const bool fused_attn = pk.sub && w.wqkv_hm && !f8 && M >= 16384 && S >= 16 && h->nsplit == 2 && !(h->x1_mask & 1);
+    const bool fused_attn = pk.sub && w.wqkv_hm && !f8 && M >= 16384 && S >= 16 && ((h->nsplit == 2 && !(h->x1_mask & 1)) || h->nsplit == 3);
     if (fused_attn) {
         QkvAttnParams q{};
         const Planes a_in = in.at(row0 * H), c_out = h->ctx.at(row0 * H);
         q.a_hi = a_in.hi; q.lda = H; q.w = w.wqkv_hm; q.bias = w.bqkv_hm; q.K = H;
+        if (h->nsplit == 3) q.w_lo = w.wqkv_hm + (long long)3 * H * H;       // upload_mat keeps the lo plane right behind the hi plane
         q.sub = pk.sub; q.n_sub = pk.n_sub; q.pair_off = pk.off; q.pair_cnt = pk.cnt; q.S = S;
         q.key_add = key_add; q.o_hi = c_out.hi; q.o_lo = c_out.lo; q.ldo = H;
         q.M = (int)M; q.m_dev = pk.rows; q.fast = h->fuse_attn == 2;

@@ -91,6 +91,7 @@ bool launch_attention(const AttnParams& p, hipStream_t st);   // false: (Sq, Sk)
 struct QkvAttnParams {
     const bf16* a_hi; int lda;               // hidden-state planes (hl32), row stride in elements
     const bf16* w; const float* bias; int K; // head-major tiled [2304][K] weights, head-major bias
+    const bf16* w_lo;                        // precision mode 3: the weights' lo plane (same tiling), else nullptr
     const int4* sub; const int* n_sub;       // sub-tile table {first row, rows, first pair, pairs} and its device-side length
     const int* pair_off; const int* pair_cnt; int S;   // packed: first row / live tokens per pair; dense (nullptr): S tokens per pair.  S = maximum tokens
     const float* key_add;                    // additive key mask by stream row, or nullptr
@@ -102,7 +103,7 @@ struct QkvAttnParams {
     unsigned long long* trace;               // lab builds: per-tile timeline (qkv_attn.hip), nullptr otherwise
     int lab_flags;                           // lab builds: timing-only knock-outs
 };
-void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, hipStream_t st);   // rows_dev: device-side row total of a packed stream (or nullptr)
+void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, int passes, hipStream_t st);   // rows_dev: device-side row total of a packed stream (or nullptr)
 bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st);   // false: shape not supported (S > 48, K % 64)
 
 // ---------------------------------------------------------------------------------------------

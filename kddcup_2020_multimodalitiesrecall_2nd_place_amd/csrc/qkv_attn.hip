@@ -46,7 +46,8 @@ __device__ __forceinline__ void qa_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-constexpr int QA_SUB = 128;          // rows of a sub-tile
+constexpr int QA_SUB = 128;          // rows of a sub-tile: two-pass kernel (96 in the three-pass one: QA_SUB3)
+constexpr int QA_SUB3 = 96;
 constexpr int QA_LDROW = 196;        // floats per staged row: 192 + 4 (784 B = 16 B mod 256 B)
 
 }  // namespace
@@ -60,7 +61,7 @@ constexpr int QA_PLAN_THREADS = 1024;
 constexpr int QA_SEG = 8192;
 
 __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __restrict__ off, const int* __restrict__ cnt, int n, int S,
-                                                                   const int* __restrict__ rows_dev, int4* __restrict__ sub, int* __restrict__ n_sub) {
+                                                                   const int* __restrict__ rows_dev, int4* __restrict__ sub, int* __restrict__ n_sub, int sub_rows) {
     __shared__ int sh[QA_PLAN_THREADS];
     // the per-pair token counts (<= 48) as bytes in LDS: each thread then walks its ~500 pairs twice without a global access in the loop
     // (530 us -> ~60 us per plan); streams of more pairs than fit read them from memory
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __
         int rows = 0, row0 = 0, pair0 = p0, ns = 0;
         for (int b = p0; b < p1; ++b) {
             const int c = cached ? (int)cnt8[b] : cnt ? cnt[b] : S;
-            if (rows + c > QA_SUB || (rows > 0 && b - pair0 >= QA_SUB)) {      // (the kernel keeps at most 128 pair records per sub-tile)
+            if (rows + c > sub_rows || (rows > 0 && b - pair0 >= QA_SUB3)) {      // (the kernel keeps at most 128 pair records per sub-tile)
                 if (out >= 0) sub[out + ns] = make_int4(row0, rows, pair0, b - pair0);
                 ++ns;
                 rows = 0;
@@ -114,23 +115,28 @@ __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __
     if (mine > 0) pack(sh[tid] - mine);
     if (tid == QA_PLAN_THREADS - 1) *n_sub = sh[tid];
 }
-void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(k_qkv_tile_plan, dim3(1), dim3(QA_PLAN_THREADS), 0, st, off, cnt, n, S, rows_dev, sub, n_sub);
+void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, int passes, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_qkv_tile_plan, dim3(1), dim3(QA_PLAN_THREADS), 0, st, off, cnt, n, S, rows_dev, sub, n_sub, passes == 3 ? QA_SUB3 : QA_SUB);
 }
 
 // MAXT: 16-token tiles per side of the attention (2: pairs of <= 32 tokens, 3: <= 48)
-template <int MAXT, bool FAST>
+// WPL: weight planes.  1 = precision mode 2 (bf16 weights; a_hi w + a_lo w), sub-tiles of 128 rows, 64 x 96 per wave;
+//      2 = precision mode 3 (w = w_hi + w_lo; a_hi w_hi + a_lo w_hi + a_hi w_lo in gemm_ppw.hip's order), sub-tiles of 96 rows (192-row tile,
+//      48 x 96 per wave) so that A [192][128 B] + W_hi + W_lo [192][64 B] of a stage are 48 KiB and three slots still fit
+template <int MAXT, bool FAST, int WPL>
 __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
-    constexpr int NW = 8, WAVES_N = 2, TM = 64, TN = 96, FM = TM / 16, FN = TN / 16, BN = 192;
-    constexpr int PLANE = 256 * 64;                 // 16 KiB: one 64-byte-per-row operand plane of 256 rows
-    constexpr int SLOT = 3 * PLANE;                 // A [256][128 B] + W [192][64 B] (+ 4 KiB unused)
-    constexpr int NSLOT = 3, D = 2, P = 6;          // pieces per wave and stage: 4 A + 2 W (waves 4-7 repeat waves 0-3's second W piece)
-    static_assert(QA_SUB * QA_LDROW * 4 <= NSLOT * SLOT, "Q | K | V staging overlays the ring");
+    constexpr int SUB = WPL == 1 ? QA_SUB : QA_SUB3, BM = 2 * SUB;
+    constexpr int NW = 8, WAVES_N = 2, TM = BM / 4, TN = 96, FM = TM / 16, FN = TN / 16, BN = 192;
+    constexpr int AREG = BM * 128, WREG = BN * 64;  // A [BM][hi 64 B | lo 64 B], one W plane [192][64 B] of a stage
+    constexpr int SLOT = 48 * 1024;                 // AREG + WPL * WREG = 44 / 48 KiB
+    constexpr int NAP = BM / 64;                    // A pieces (8 rows x 128 B per wave) per wave and stage
+    constexpr int NSLOT = 3, D = 2, P = NAP + 2 * WPL;   // + 2 W pieces per plane (waves 4-7 repeat waves 0-3's second one)
+    static_assert(AREG + WPL * WREG <= SLOT && SUB * QA_LDROW * 4 <= NSLOT * SLOT, "stage fits a slot; Q | K | V staging overlays the ring");
     __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * SLOT];
     // per-tile metadata of the epilogue, fetched with the tile's addresses (setup) and parked here after the main loop: a dependent
     // global load inside the attention phase costs a full memory latency with only eight waves on the CU (the phase took 16 k cycles per
     // sub-tile with the pair offsets / key mask / bias read from memory where they are used: profiles/r03n_qa_trace.txt)
-    __shared__ __attribute__((aligned(16))) float m_keyadd[256];     // additive key mask by tile row
+    __shared__ __attribute__((aligned(16))) float m_keyadd[256];     // additive key mask by tile row (BM <= 256)
     __shared__ __attribute__((aligned(16))) float m_bias[192];       // this head's [Q | K | V] bias
     __shared__ int2 m_pair[256 + 64];                                // [sub-tile][pair]: first stream row, live tokens (+ 64: whole-wave reads)
 
@@ -148,8 +154,8 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     if (vb >= nblk) return;
 
     const int gr_l = lane >> 2, gc = lane & 3;
-    const bf16* a_src[4];
-    const bf16* w_src[2];
+    const bf16* a_src[NAP];
+    const bf16* w_src[WPL][2];
     int head;
     int4 sub0, sub1;
     int meta_a = 0, meta_b = 0;          // thread < 256: key mask of tile row tid, bias[tid]; else pair (tid - 256): first row, tokens
@@ -175,18 +181,19 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     auto setup = [&]() {
         head = nhead; sub0 = nsub0; sub1 = nsub1;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const int r = q4 * 64 + wave * 8 + (lane >> 3);          // tile row: sub-tile r >> 7, its row r & 127 (clamped to the last live one)
-            const int4 sb = (r >> 7) ? sub1 : sub0;
-            int lr = r & 127;
+        for (int q4 = 0; q4 < NAP; ++q4) {
+            const int r = q4 * 64 + wave * 8 + (lane >> 3);          // tile row: sub-tile r / SUB, its row r % SUB (clamped to the last live one)
+            const int4 sb = (r / SUB) ? sub1 : sub0;
+            int lr = r % SUB;
             lr = lr < sb.y ? lr : (sb.y > 0 ? sb.y - 1 : 0);
             a_src[q4] = p.a_hi + 2 * ((long long)(sb.x + lr) * (long long)p.lda) + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
         }
         {
-            const int t = tid & 255, i = t & 127;
-            const int4 sb = (t >> 7) ? sub1 : sub0;
+            const int t = tid & 255;
+            const int u = tid < 256 ? (t >= SUB) : (t >> 7), i = tid < 256 ? t - u * SUB : (t & 127);   // key-mask rows by tile row, pair records [sub-tile][128]
+            const int4 sb = u ? sub1 : sub0;
             if (tid < 256) {
-                meta_a = (p.key_add && i < sb.y) ? __float_as_int(p.key_add[sb.x + i]) : 0;
+                meta_a = (p.key_add && t < BM && i < sb.y) ? __float_as_int(p.key_add[sb.x + i]) : 0;
                 meta_b = tid < BN ? __float_as_int(p.bias[head * BN + tid]) : 0;
             } else if (i < sb.w) {
                 const int b = sb.z + i;
@@ -197,7 +204,8 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             const int r = h2 ? 128 + (wave & 3) * 16 + gr_l : wave * 16 + gr_l;
-            w_src[h2] = p.w + wtile_off(head * BN + r, 0, p.K) + (gc ^ qa_swz(r)) * 8;
+            w_src[0][h2] = p.w + wtile_off(head * BN + r, 0, p.K) + (gc ^ qa_swz(r)) * 8;
+            if constexpr (WPL == 2) w_src[1][h2] = w_src[0][h2] + (p.w_lo - p.w);
         }
     };
     locate(vb);
@@ -205,9 +213,12 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     auto issue = [&](int q, int st, int slot) {
         unsigned char* d;
         const bf16* s;
-        if (q < 4) { d = smem + slot * SLOT + q * 8192 + wave * 1024; s = a_src[q] + st * 64; }
-        else if (q == 4) { d = smem + slot * SLOT + 2 * PLANE + wave * 1024; s = w_src[0] + st * 512; }
-        else { d = smem + slot * SLOT + 2 * PLANE + 8192 + (wave & 3) * 1024; s = w_src[1] + st * 512; }
+        if (q < NAP) { d = smem + slot * SLOT + q * 8192 + wave * 1024; s = a_src[q] + st * 64; }
+        else {
+            const int pl = (q - NAP) >> 1, h2 = (q - NAP) & 1;
+            d = smem + slot * SLOT + AREG + pl * WREG + (h2 ? 8192 + (wave & 3) * 1024 : wave * 1024);
+            s = w_src[pl][h2] + st * 512;
+        }
         __builtin_amdgcn_global_load_lds((glb_void*)s, (lds_void*)d, 16, 0, 0);
     };
 
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     const int ns = p.K / 32;
     const int fr = lane & 15, fk = lane >> 4;
     const int laneA = (wm * TM + fr) * 128 + ((fk ^ ((fr >> 1) & 7)) << 4);          // hi fragment; lo: chunk ^ 4
-    const int laneB = 2 * PLANE + (wn * TN + fr) * 64 + ((fk ^ qa_swz(fr)) << 4);
+    const int laneB = AREG + (wn * TN + fr) * 64 + ((fk ^ qa_swz(fr)) << 4);                 // W_hi fragment; W_lo: + WREG
 
     // one phase per stage: all fragment reads (+ the six LDS-DMA pieces of stage s+2), counted wait, reads retired, barrier, 48 MFMAs,
     // barrier.  Hazards as in gemm_pp.hip / gemm_ppw.hip: a slot's reads are retired before the first barrier of its stage, its refill is
@@ -225,9 +236,11 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
         constexpr int WAITN = decltype(wait_tag)::value;
         const unsigned char* sb = smem + slot * SLOT;
         const int nslot = slot == 0 ? NSLOT - 1 : slot - 1;
-        bf16x8 a[2][FM], b[FN];
+        bf16x8 a[2][FM], b[WPL][FN];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + laneB + j * 16 * 64);
+        for (int wp = 0; wp < WPL; ++wp)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[wp][j] = *reinterpret_cast<const bf16x8*>(sb + laneB + wp * WREG + j * 16 * 64);
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
@@ -240,13 +253,15 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         qa_barrier();
         __builtin_amdgcn_s_setprio(1);
+        // per accumulator and stage: a_hi w_hi, a_lo w_hi (, a_hi w_lo) -- the order of gemm_pp.hip / gemm_ppw.hip, so the projection is bit-identical
+        // to the two-kernel route's
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int pass = 0; pass < WPL + 1; ++pass)
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[pl][i], acc[i][j], 0, 0, 0);   // swapped operands: C^T fragment
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[pass == 2 ? WPL - 1 : 0][j], a[pass == 1 ? 1 : 0][i], acc[i][j], 0, 0, 0);   // swapped operands: C^T fragment
         __builtin_amdgcn_s_setprio(0);
         qa_barrier();
     };
@@ -264,8 +279,8 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
 
     // the staging area sits at the TOP of the ring, above the 44 KiB that a stage occupies in slot 0: the next tile's first stage is
     // fetched into slot 0 while this tile's epilogue runs
-    float* stg = reinterpret_cast<float*>(smem + NSLOT * SLOT - QA_SUB * QA_LDROW * 4);
-    static_assert(NSLOT * SLOT - QA_SUB * QA_LDROW * 4 >= 2 * PLANE + 12 * 1024, "slot 0's stage must lie below the staging area");
+    float* stg = reinterpret_cast<float*>(smem + NSLOT * SLOT - SUB * QA_LDROW * 4);
+    static_assert(NSLOT * SLOT - SUB * QA_LDROW * 4 >= AREG + WPL * WREG, "slot 0's stage must lie below the staging area");
 #ifdef MMS_LAB
     // lab (timing only, results WRONG): p.lab_flags bit 0 drops the P V MFMAs, 1 the Q K^T MFMAs, 3 the context stores, 4 all attention work
     const int QA_FLAGS = p.lab_flags;
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                 item += nqt;
                 // does any of this pair's query tiles fall to this wave?  tile qt belongs to wave (first + qt) % 8
                 if (S <= 0 || (((wave - first) & (NW - 1)) >= nqt) || (QA_FLAGS & 16)) continue;
-                const float* kadd = m_keyadd + half * 128 + (g0 - sb.x);
+                const float* kadd = m_keyadd + half * SUB + (g0 - sb.x);
                 const float* base = stg + (g0 - sb.x) * QA_LDROW;           // staged rows of the pair: [Q 0..63 | K 64..127 | V 128..191]
                 float add[MAXT][4];
 #pragma unroll
@@ -622,14 +637,17 @@ bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st) {
                    ? prop.multiProcessorCount / 8 * 8 : 8;
     }
     // an upper bound of the tile count (the live count is on the device): every sub-tile but the last of a stream holds > 128 - S rows
-    const long long max_sub = p.M / (QA_SUB - p.S + 1) + 2, max_blk = (max_sub + 1) / 2 * MMS_HEADS;
+    const long long max_sub = p.M / ((p.w_lo ? QA_SUB3 : QA_SUB) - p.S + 1) + p.M / QA_SEG + 3, max_blk = (max_sub + 1) / 2 * MMS_HEADS;
     const dim3 grid((unsigned)(max_blk < n_cu ? max_blk : n_cu)), block(512);
     auto go = [&](const QkvAttnParams& q) {
-        if (q.fast) {
-            if (q.S <= 32) hipLaunchKernelGGL((qkv_attn_kernel<2, true>), grid, block, 0, st, q);
-            else hipLaunchKernelGGL((qkv_attn_kernel<3, true>), grid, block, 0, st, q);
-        } else if (q.S <= 32) hipLaunchKernelGGL((qkv_attn_kernel<2, false>), grid, block, 0, st, q);
-        else hipLaunchKernelGGL((qkv_attn_kernel<3, false>), grid, block, 0, st, q);
+        const bool fast = q.fast != 0, big = q.S > 32;
+        if (q.w_lo) {      // three-pass projection (precision mode 3)
+            if (fast) { if (big) hipLaunchKernelGGL((qkv_attn_kernel<3, true, 2>), grid, block, 0, st, q); else hipLaunchKernelGGL((qkv_attn_kernel<2, true, 2>), grid, block, 0, st, q); }
+            else if (big) hipLaunchKernelGGL((qkv_attn_kernel<3, false, 2>), grid, block, 0, st, q);
+            else hipLaunchKernelGGL((qkv_attn_kernel<2, false, 2>), grid, block, 0, st, q);
+        } else if (fast) { if (big) hipLaunchKernelGGL((qkv_attn_kernel<3, true, 1>), grid, block, 0, st, q); else hipLaunchKernelGGL((qkv_attn_kernel<2, true, 1>), grid, block, 0, st, q); }
+        else if (big) hipLaunchKernelGGL((qkv_attn_kernel<3, false, 1>), grid, block, 0, st, q);
+        else hipLaunchKernelGGL((qkv_attn_kernel<2, false, 1>), grid, block, 0, st, q);
     };
 #ifdef MMS_LAB
     static const bool want_trace = getenv("MMS_QA_TRACE") != nullptr;      // first launch only: /tmp/qa_trace.bin = [workgroup][8 tiles][8] u64

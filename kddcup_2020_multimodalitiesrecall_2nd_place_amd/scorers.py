@@ -40,7 +40,7 @@ class _Base:
             precision = auto_precision(weights)
         if fuse_attention == "auto":
             # mms_config.fuse_attention = 1 (QKV projection + self-attention in one kernel, bit-identical results) wherever it is faster:
-            # zk / lds +3 %, lxmert -0.4 % (profiles/r03q_*); 2 (split-bf16 attention MFMAs, another +2 %) is opt-in
+            # zk / lds +3 % in precision modes 2 and 3, lxmert -0.4 % (profiles/r03q_*, r04a_*); 2 (split-bf16 attention MFMAs, another +1 .. 2 %) is opt-in
             fuse_attention = 0 if cfg.name == "lxmert" else 1
         self.cfg = cfg
         self.device = torch.device("cuda", device)
