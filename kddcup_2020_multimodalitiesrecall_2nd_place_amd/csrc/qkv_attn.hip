@@ -1,4 +1,4 @@
-// Fused QKV projection + self-attention (precision mode 2): one workgroup computes [Q_h | K_h | V_h] = X W_h^T + b_h of ONE head for a
+// Fused QKV projection + self-attention (precision modes 2 and 3): one workgroup computes [Q_h | K_h | V_h] = X W_h^T + b_h of ONE head for a
 // 256-row tile of the token stream with the ping-pong engine of gemm_pp.hip, leaves the 192 result columns in LDS and runs the
 // attention of the tile's pairs for that head straight from there -- the fp32 Q / K / V tensor ([rows][2304], 9.2 KB per row written
 // by the projection and read back by attn.hip) never exists in HBM, and the attention launch disappears.
@@ -19,6 +19,11 @@
 // v_mfma_f32_16x16x4_f32 sequence, same softmax: the context rows are BIT-IDENTICAL to the two-kernel route) -> split-bf16 context rows
 // to HBM -> barrier.  The staging area overlays ring slots 1-2 (and the unused top of slot 0): the next tile's stage 0 is fetched into
 // slot 0 during the epilogue, its stage 1 after the last barrier.
+// FAST (mms_config.fuse_attention = 2): Q K^T and P V on split-bf16 MFMAs (hi + lo operands, three v_mfma_f32_16x16x32_bf16 products),
+// v_exp_f32 / v_rcp_f32 softmax -- a fifth of the matrix-pipe time of the exact-fp32 form, ~2^-16 relative on the scores.
+//
+// Precision mode 3 (WPL = 2: the weights have a lo plane): the same kernel on a 192-row tile (sub-tiles of 96 rows, 48 x 96 per wave), so
+// that A + W_hi + W_lo of a stage are 48 KiB and three slots still fit; passes a_hi w_hi, a_lo w_hi, a_hi w_lo in gemm_ppw.hip's order.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
