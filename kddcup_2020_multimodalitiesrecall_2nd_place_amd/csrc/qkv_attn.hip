@@ -92,6 +92,9 @@ __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __
     if (tid < nseg) { p0 = first_pair((long long)tid * seg); p1 = tid + 1 < nseg ? first_pair((long long)(tid + 1) * seg) : n; }
     auto pack = [&](int out) {       // out < 0: count only
         int rows = 0, row0 = 0, pair0 = p0, ns = 0;
+        // first row of pair b: the offsets are the running sum of the counts, so one load per thread replaces a dependent global load
+        // at every sub-tile start (those loads, not the walk, were most of the plan's 360 us)
+        int cursor = p0 < p1 ? (off ? off[p0] : p0 * S) : 0;
         for (int b = p0; b < p1; ++b) {
             const int c = cached ? (int)cnt8[b] : cnt ? cnt[b] : S;
             if (rows + c > sub_rows || (rows > 0 && b - pair0 >= QA_SUB3)) {      // (the kernel keeps at most 128 pair records per sub-tile)
@@ -99,8 +102,9 @@ __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __
                 ++ns;
                 rows = 0;
             }
-            if (rows == 0) { row0 = off ? off[b] : b * S; pair0 = b; }
+            if (rows == 0) { row0 = cursor; pair0 = b; }
             rows += c;
+            cursor += c;
         }
         if (rows > 0) {
             if (out >= 0) sub[out + ns] = make_int4(row0, rows, pair0, p1 - pair0);
