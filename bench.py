@@ -355,7 +355,7 @@ def main():
             # kernels EXECUTE fewer FLOPs than that (padded tokens are skipped), so this is an equivalent rate, not
             # a utilisation; roofline.achieved below counts executed FLOPs only.
             "reference_graph_tflops_per_gpu": round(value / world * fpp / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": kern + " (all dense contractions; small GEMMs: gemm_tile_kernel)",
+            "roofline": {"bound": "mfma", "kernel": kern + (" (all dense contractions" if not a.fuse_attn else " (attention-output / FFN / box and label projections; Q|K|V projections: fused_qkv_attention below") + "; small GEMMs: gemm_tile_kernel)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          # the second resource of the same launches: traffic / 6.3 TB/s (achievable HBM rate, MI355X_MICROARCH.md) over the
