@@ -38,6 +38,9 @@ def test_bench_prints_one_contract_line():
     assert p3["precision_mode"] == 3 and p3["value"] > 0 and p3["parity_max_vecrel_vs_fp32_port"] < 1e-3
     assert sec["lds"]["value"] > 0 and sec["lxmert"]["value"] > 0
     assert d["value_fp32_checkpoint"] == p3 and d["config"]["fuse_attention"] == 2     # mode 3 also as a top-level value; the route the line ran
+    fq = r["fused_qkv_attention"]          # the Q|K|V projections ran inside the fused kernel, timed apart from the plain GEMM launches
+    assert fq["launches"] > 0 and fq["achieved"] > 0 and abs(fq["frac"] - fq["achieved"] / r["peak"]) < 1e-3
+    assert r["achieved_incl_fused"] > 0 and min(r["achieved"], fq["achieved"]) <= r["achieved_incl_fused"] <= max(r["achieved"], fq["achieved"])
 
 
 @pytest.mark.gpu
