@@ -94,6 +94,23 @@ def prepare(scorer, name, b):
                           b["visual_attention_mask"])
 
 
+def live_fraction(name, cfgs, ps, dense):
+    """Token rows the kernels execute / rows of the reference's padded graph (1.0 when token packing is off)."""
+    if dense or name == "ensemble":
+        return 1.0 if dense else None
+    b0 = synth.batch_for(cfgs[name], ps)
+    if name == "zk":
+        live = (np.minimum(b0["len_query_"], cfgs["zk"].text_len) + np.minimum(b0["num_boxes"], N_BOX)).sum()
+        return round(float(live) / (ps.n * cfgs["zk"].seq), 4)
+    if name == "lxmert":
+        return round(float(b0["input_mask"].sum() + b0["visual_attention_mask"].sum()) / (ps.n * (cfgs["lxmert"].text_len + N_BOX)), 4)
+    # lds: rows kept after merging a pair's identical feature / label tokens (rowops.hip k_lds_plan_*)
+    lab = b0["labelfeat"]
+    nb = np.minimum(ps.num_boxes, N_BOX)
+    distinct = np.array([len({tuple(t) for t in lab[i]}) for i in range(ps.n)])
+    return round(float((cfgs["lds"].text_len + nb + (nb < N_BOX) + distinct).sum()) / (ps.n * cfgs["lds"].seq), 4)
+
+
 def cpu_baseline(cfg, w, hip_logits_fn=None, budget_s=20.0):
     """the oracle's torch-fp32 port of the same forward on this box's host cores, on BASELINE.json config 1's
     shape (100 queries x 30 candidates, batch 256), bounded to ~budget_s of CPU work: whole batches of 256 pairs are timed until the
@@ -126,7 +143,7 @@ def cpu_baseline(cfg, w, hip_logits_fn=None, budget_s=20.0):
 
 def make_members(name, a, local):
     """-> (scorer, {member name: (cfg, weights, member scorer)})"""
-    kw = dict(device=local, chunk_pairs=a.chunk, fuse_layernorm=a.fuse_ln, fuse_attention=a.fuse_attn)
+    kw = dict(device=local, chunk_pairs=a.chunk, **({} if a.fuse_ln < 0 else {"fuse_layernorm": a.fuse_ln}), fuse_attention="auto" if a.fuse_attn < 0 else a.fuse_attn)
     if name != "ensemble":
         cfg = CFGS[name]()
         w = weights.make_weights(cfg, bf16_matrices=not a.fp32_weights)
@@ -164,16 +181,20 @@ def run_timed(step, steps, warmup, world, dev, handles):
     med = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
     gms = gn = gfl = 0.0
     fused = [0.0, 0.0, 0.0]
+    cls = [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]           # GEMM launches by epilogue class: plain / fused LayerNorm
     for h in handles:
         for i, v in enumerate(h.fused_timing()):       # before the reset below
             fused[i] += v
+        for c in (0, 1):
+            for i, v in enumerate(h.gemm_timing_class(c)):
+                cls[c][i] += v
         ms, n, fl = h.gemm_timing(False, True, read=True)
         gms += ms; gn += n; gfl += fl
     if world > 1:
         t = torch.tensor([dt, med], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, med = float(t[0].item()), float(t[1].item())
-    return dt, med, gms, gn, gfl, fused
+    return dt, med, gms, gn, gfl, fused + [cls]
 
 
 def spawn_ranks(n, argv):
@@ -194,6 +215,56 @@ def spawn_ranks(n, argv):
     sys.exit(rc)
 
 
+def batch_sweep(a, local, dev):
+    """the three drop-in call surfaces at the reference's own call sizes -- zk 1 pair per sess.run
+    (evaluate_normal.py:15,216), lds 5 (run_pretraining_predict_score.py:523), lxmert 256 (lxmert/src/param.py:46) -- and upwards.
+    Inputs are device tensors (what a caller that keeps its candidate store in HBM passes); every call is followed by a stream
+    synchronisation, so ms_per_call is the latency a caller sees, pairs/s = B / that."""
+    out = {}
+    sizes = (1, 5, 256, 1024, 4096, 30000)
+    for name in ("zk", "lds", "lxmert"):
+        cfg = CFGS[name]()
+        w = weights.make_weights(cfg)
+        s = scorers.make_scorer(cfg, w, precision=a.precision, device=local)
+        whole = synth.make_pairs(1000, 30, tag="/bench0", with_feats=False)
+        feats = device_feats(whole, dev, 20200823)
+        rows = []
+        for B in sizes:
+            ps = whole.take(slice(0, B))
+            fd = device_feed(name, {name: cfg}, ps, feats[:B], dev)
+
+            def call():
+                if name == "zk":
+                    return s(fd["num_boxes"], fd["np_boxes_5"], fd["np_images_features"], fd["np_idx_class_labels"], None, fd["np_idx_query_"],
+                             fd["len_query_"], fd["labels"], fd["segment_ids"])
+                if name == "lds":
+                    return s(fd)
+                return s.forward(fd["input_ids"], fd["boxes_label_input_ids"], None, fd["input_mask"], None, None, fd["feats"], fd["boxes"],
+                                 fd["visual_attention_mask"])
+            for _ in range(2):
+                call()
+            torch.cuda.synchronize()
+            n, t0 = 0, time.perf_counter()
+            while True:
+                call()
+                torch.cuda.synchronize()
+                n += 1
+                dt = time.perf_counter() - t0
+                if (dt > 0.5 and n >= 3) or n >= 200:
+                    break
+            rows.append({"pairs_per_call": B, "calls": n, "ms_per_call": round(dt / n * 1e3, 4), "pairs_per_s": round(B * n / dt, 1)})
+        big = rows[-1]["pairs_per_s"]
+        for r in rows:
+            r["of_large_batch_rate"] = round(r["pairs_per_s"] / big, 4)
+        out[name] = rows
+        s.close()
+        del feats
+    print(json.dumps({"metric": "per-call latency and pairs/s of the drop-in call surfaces by batch size", "unit": "pairs/s", "n_gpus": 1,
+                      "precision_mode": a.precision, "data": "synthetic", "call_surface": {"zk": "ZkScorer.__call__ (13-argument model_attention_channel_e order)",
+                      "lds": "LdsScorer.__call__(features)", "lxmert": "LxmertScorer.forward (KDDModel.forward order)"},
+                      "reference_call_sizes": {"zk": 1, "lds": 5, "lxmert": 256}, "sweep": out}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,14 +279,19 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (precision 3 on fp32 weights, lds, lxmert, H2D-inclusive)")
     ap.add_argument("--fp32-weights", action="store_true", help="seeded weights NOT rounded to bf16 (what a real checkpoint looks like)")
-    ap.add_argument("--fuse-attn", type=int, default=-1, help="mms_config.fuse_attention (default: 2 in precision modes 2 / 3, else 0): QKV projection + self-attention in one kernel; 1 = exact-fp32 attention MFMAs (bit-identical to the two-kernel route), 2 = split-bf16 MFMAs")
-    ap.add_argument("--fuse-ln", action="store_true", help="LayerNorm fused into the N = 768 GEMM epilogues (mms_config.fuse_layernorm)")
+    ap.add_argument("--fuse-attn", type=int, default=-1, help="mms_config.fuse_attention (default: the LIBRARY default, scorers.make_scorer's \"auto\": 2 for zk / lds, 0 for lxmert): QKV projection + self-attention in one kernel; 1 = exact-fp32 attention MFMAs (bit-identical to the two-kernel route), 2 = split-bf16 MFMAs")
+    ap.add_argument("--box-mu", type=float, default=1.1, help="location of the lognormal box count of the synthetic pairs (1.1 = the documented workload, mean 3.5 boxes)")
+    ap.add_argument("--batch-sweep", action="store_true", help="instead of the headline run: pairs/s and per-call latency of the three drop-in call surfaces at the reference's own call sizes")
+    ap.add_argument("--fuse-ln", type=int, nargs="?", const=3, default=-1, help="LayerNorm fused into the N = 768 GEMM epilogues (mms_config.fuse_layernorm mask: 1 attention output, 2 FFN down, 3 both; default: the library default)")
     ap.add_argument("--dense", action="store_true", help="keep padded tokens (reference layout) instead of packing live tokens")
     ap.add_argument("--all-boxes", action="store_true", help="worst case: every pair has 10 boxes")
     a = ap.parse_args()
-    if a.fuse_attn < 0:
-        a.fuse_attn = 2 if a.precision in (2, 3) else 0
+    a.fuse_attn_arg = a.fuse_attn
 
+    if a.batch_sweep:
+        torch.cuda.set_device(0)
+        batch_sweep(a, 0, torch.device("cuda", 0))
+        return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", 0))
@@ -223,7 +299,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
         sys.exit("bench.py: --gpus %d contradicts WORLD_SIZE=%d" % (a.gpus, world))
-    if os.environ.get("MMS_BENCH_SHARE_GPU"):      # N ranks on ONE device: exercises the N > 1 path on a single-GPU box (tests)
+    if os.environ.get("MMS_BENCH_SHARE_GPU") or os.environ.get("MMS_BENCH_FORCE_LOCAL0"):
+        # N ranks on ONE device: SHARE_GPU exercises the N > 1 path on a single-GPU box (tests); FORCE_LOCAL0 alone imitates a launcher
+        # that failed to give each rank its own GPU -- the device check below must refuse it
         local = 0
     torch.cuda.set_device(local)
     if world > 1:
@@ -241,16 +319,35 @@ def main():
             os.dup2(keep, 1)
             os.close(keep)
     dev = torch.device("cuda", local)
-    gather_dev = dev if os.environ.get("MMS_BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")
+    backend = os.environ.get("MMS_BENCH_BACKEND", "nccl")
+    gather_dev = dev if backend == "nccl" else torch.device("cpu")
+    # N > 1: the line proves where its ranks ran -- every rank reports the device it holds; two "nccl" ranks on one device is an error
+    # (only the single-GPU test mode, MMS_BENCH_SHARE_GPU + gloo, may share), not a silently meaningless scaling number
+    rank_devices = None
+    if world > 1:
+        pr = torch.cuda.get_device_properties(local)
+        me = {"rank": rank, "hip_device": local, "name": pr.name,
+              "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0xff), getattr(pr, "pci_device_id", 0xff)),
+              "uuid": str(getattr(pr, "uuid", "")), "host": socket.gethostname(), "pid": os.getpid()}
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, me)
+        distinct = len({(d["host"], d["pci_bus_id"], d["uuid"]) for d in rank_devices})
+        if distinct < world and not os.environ.get("MMS_BENCH_SHARE_GPU"):
+            if rank == 0:
+                print("bench.py: %d ranks resolved to %d distinct devices: %s" % (world, distinct, json.dumps(rank_devices)), file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(3)
 
     scorer, members = make_members(a.model, a, local)
+    fa_members = {n: (m[2].fuse_attention if a.precision in (2, 3) else 0) for n, m in members.items()}     # what the library default resolved to
+    a.fuse_attn = fa_members["zk" if a.model == "ensemble" else a.model]
     cfgs = {n: m[0] for n, m in members.items()}
     handles = [m[2].handle for m in members.values()]
     def one_job(kind):
         """ONE job cut into contiguous query blocks per rank (strong scaling): testB 994 queries x 8..30 candidates, valid 496 x 9..30
         (prediction_result/*.txt / validscore_imagebert.txt; ragged shards), bench-strong = the metric's own 1000 x 30 set."""
         NQ, cr = {"testB": (994, (8, 30)), "valid": (496, (9, 30)), "bench-strong": (a.queries, a.cands)}[kind]
-        whole = synth.make_pairs(NQ, cr, tag="/bench0" if kind == "bench-strong" else "/" + kind, with_feats=False, all_boxes=a.all_boxes)
+        whole = synth.make_pairs(NQ, cr, tag="/bench0" if kind == "bench-strong" else "/" + kind, with_feats=False, all_boxes=a.all_boxes, box_mu=a.box_mu)
         qop = whole.query_id - whole.query_id.min()
         lo, hi = sharding.query_block(NQ, world, rank)
         s, e = sharding.pair_slice_for_queries(qop, lo, hi)
@@ -264,7 +361,7 @@ def main():
     else:
         # rank r owns queries [r*Q, (r+1)*Q) of the logical N*Q-query job (weak scaling)
         ps = synth.make_pairs(a.queries, a.cands, tag="/bench%d" % rank, with_feats=False, query_offset=rank * a.queries,
-                              all_boxes=a.all_boxes)
+                              all_boxes=a.all_boxes, box_mu=a.box_mu)
         counts = [ps.n] * world
         total_pairs = ps.n * world
         scaling = "weak"
@@ -310,20 +407,7 @@ def main():
         fpp = sum(BASELINE_FLOPS[n] * (2 if n == "zk" and a.model == "ensemble" else 1) for n in members)
         for n, (cfg, _, _) in members.items():
             assert abs(flops_per_pair(cfg) / BASELINE_FLOPS[n] - 1) < 5e-3
-        live_frac = None
-        if a.model in ("zk", "lxmert"):
-            b0 = synth.batch_for(cfgs[a.model], ps)
-            if a.model == "zk":
-                live = (np.minimum(b0["len_query_"], cfgs["zk"].text_len) + np.minimum(b0["num_boxes"], N_BOX)).sum()
-                live_frac = round(float(live) / (ps.n * cfgs["zk"].seq), 4)
-            else:
-                live_frac = round(float(b0["input_mask"].sum() + b0["visual_attention_mask"].sum()) / (ps.n * (cfgs["lxmert"].text_len + N_BOX)), 4)
-        elif a.model == "lds":        # rows kept after merging a pair's identical feature / label tokens (rowops.hip k_lds_plan_*)
-            b0 = synth.batch_for(cfgs["lds"], ps)
-            lab = b0["labelfeat"]
-            nb = np.minimum(ps.num_boxes, N_BOX)
-            distinct = np.array([len({tuple(t) for t in lab[i]}) for i in range(ps.n)])
-            live_frac = 1.0 if a.dense else round(float((cfgs["lds"].text_len + nb + (nb < N_BOX) + distinct).sum()) / (ps.n * cfgs["lds"].seq), 4)
+        live_frac = live_fraction(a.model, cfgs, ps, a.dense)
         # HBM bytes per GEMM launch: NOT measured in this run (PMC passes need rocprofv3 around the process) -- the committed result of
         # tools/pmc_traffic.sh on this very workload, labelled as such
         traffic = traffic_src = fused_traffic = None
@@ -369,7 +453,8 @@ def main():
                          "note": "achieved = sum over GEMM launches of executed 2*M_live*N*K (device-counted) / sum of hipEvent "
                                  "launch durations in the timed region (rank 0); traffic = PMC HBM bytes per launch from profiles/"},
         }
-        res["config"]["fuse_attention"] = a.fuse_attn
+        res["config"]["fuse_attention"] = a.fuse_attn if a.model != "ensemble" else fa_members
+        res["config"]["fuse_layernorm"] = next(iter(members.values()))[2].fuse_layernorm if a.precision == 2 else 0
         if fused[1] > 0:
             # mms_config.fuse_attention: the QKV projections run inside qkv_attn_kernel, whose launches also do the attention of their
             # pairs -- timed apart from the GEMM launches above, priced on the projection FLOPs alone
@@ -382,8 +467,33 @@ def main():
                 "note": "projection FLOPs (2*M_live*2304*768) / launch duration INCLUDING the attention of the tile's pairs"}
             res["roofline"]["achieved_incl_fused"] = round((gemm_fl + fused[2]) / ((gemm_ms + fused[0]) * 1e-3) / 1e12, 2)
             res["roofline"]["frac_incl_fused"] = round(res["roofline"]["achieved_incl_fused"] / peak, 4)
+        cls = fused[3]
+        if cls[1][1] > 0:
+            # mms_config.fuse_layernorm: the attention-output / FFN-down projections run with the bias + residual + LayerNorm epilogue; those
+            # launches' duration includes the eight residual K stages and the LayerNorm (work the two-kernel route does in k_ln_to_planes),
+            # their FLOP count the projection alone -- reported apart so that `plain_epilogue` stays comparable with earlier rounds
+            for key, c, what in (("plain_epilogue", cls[0], "gemm_pp_kernel<2,ACT,0,true,false>: FFN-up (+GELU), box / label projections, small launches"),
+                                 ("layernorm_fused", cls[1], "gemm_pp_kernel<2,0,0,true,true>: attention-output and FFN-down projections + residual + LayerNorm in one launch")):
+                if c[1] > 0:
+                    t = c[2] / (c[0] * 1e-3) / 1e12
+                    res["roofline"][key] = {"kernel": what, "launches": int(c[1]), "avg_launch_ms": round(c[0] / c[1], 4), "achieved": round(t, 2), "frac": round(t / peak, 4)}
+        # the whole step on the same terms: every executed dense-contraction FLOP (device-counted) over the barrier-bracketed step time
+        step_fl = (gemm_fl + fused[2]) / max(a.steps, 1)
+        res["roofline"]["whole_step"] = {"executed_flops": round(step_fl, 1), "ms_per_step": round(dt / a.steps * 1e3, 3),
+                                         "achieved": round(step_fl / (dt / a.steps) / 1e12, 2), "frac": round(step_fl / (dt / a.steps) / 1e12 / peak, 4),
+                                         "note": "all kernels of the step (GEMMs, fused QKV + attention, row kernels, bookkeeping) in the denominator"}
         if strong is not None:
             res["strong"] = strong
+        if world > 1:
+            try:
+                ccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+            except Exception:        # noqa: BLE001 -- a version string is not worth a failed bench
+                ccl = None
+            res["ranks"] = rank_devices
+            res["distributed"] = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_version": ccl,
+                                  "distinct_devices": len({(d["host"], d["pci_bus_id"], d["uuid"]) for d in rank_devices}),
+                                  "shared_device_test_mode": bool(os.environ.get("MMS_BENCH_SHARE_GPU")),
+                                  "gather": "one all_gather_into_tensor of fp32 scores per step on %s tensors" % ("device" if backend == "nccl" else "host")}
         if world == 1 and not a.no_secondary and a.workload == "bench":
             res["secondary"] = secondary(a, local, dev, ps, feats, members, scorer, feed, value)
             if "precision3" in res["secondary"]:
@@ -465,32 +575,79 @@ def secondary(a, local, dev, ps, feats, members, scorer, feed, value):
         return out
     out["tsv_to_scores_overlapped"] = tsv_pipeline_rate(scorer)
 
-    def quick(name, precision, fp32_weights, parity):
-        cfg = CFGS[name]()
-        w = weights.make_weights(cfg, bf16_matrices=not fp32_weights)
-        s = scorers.make_scorer(cfg, w, precision=precision, device=local, chunk_pairs=a.chunk, fuse_attention=a.fuse_attn)
-        fd = device_feed(name, {name: cfg}, ps, feats, dev)
+    def oracle_parity(cfg, w, s, fd, n):
+        """checker: the oracle's fp32 port on 64 pairs OF THE TIMED BATCH ITSELF (the logits the big-M engines just produced -- a separate
+        small batch would run the small-tile engines instead)"""
+        from oracle import np_models, torch_models
+        sel = np.linspace(0, n - 1, 64).astype(np.int64)
+        tsel = torch.as_tensor(sel, device=dev)
+        sub = {k: (v[tsel].cpu().numpy() if torch.is_tensor(v) and v.shape[:1] == (n,) else v) for k, v in fd.items()}
+        if cfg.name == "lxmert":
+            ref = np.asarray(np_models.forward(cfg, w, sub, np.float32)[0], np.float64)
+        else:
+            ref = np.asarray(torch_models.forward(cfg, w, sub)[0], np.float64)
+        got = s.logits[tsel].double().cpu().numpy()
+        return float((np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)).max())
+
+    def timed(s, name, cfg, ps_, feats_, steps=3):
+        fd = device_feed(name, {name: cfg}, ps_, feats_, dev)
         def st(first=False):
             s.score_prepared(prepare(s, name, fd))
-        dt, med, gms, gn, gfl, _fu = run_timed(st, 3, 1, 1, dev, [s.handle])
-        r = {"value": round(ps.n * 3 / dt, 1), "unit": "pairs/s", "precision_mode": s.precision,
-             "gemm_tflops": round(gfl / (gms * 1e-3) / 1e12, 1), "frac": round(gfl / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
-        if parity:   # checker: the oracle's fp32 port on the same (unrounded) weights, on 64 pairs OF THE TIMED BATCH ITSELF (the logits
-            # the big-M engine just produced -- a separate small batch would run the small-tile engine instead)
-            from oracle import torch_models
-            sel = np.linspace(0, ps.n - 1, 64).astype(np.int64)
-            tsel = torch.as_tensor(sel, device=dev)
-            sub = {k: (v[tsel].cpu().numpy() if torch.is_tensor(v) and v.shape[:1] == (ps.n,) else v) for k, v in fd.items()}
-            ref = np.asarray(torch_models.forward(cfg, w, sub)[0], np.float64)
-            got = s.logits[tsel].double().cpu().numpy()
-            r["parity_max_vecrel_vs_fp32_port"] = float((np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)).max())
-            r["parity_sample"] = "64 pairs of the timed %d-pair launch (its own logits)" % ps.n
-            r["weights"] = "seeded fp32, NOT bf16-rounded (a real checkpoint's situation); precision auto -> mode 3"
+        dt, med, gms, gn, gfl, _fu = run_timed(st, steps, 1, 1, dev, [s.handle])
+        return fd, {"value": round(ps_.n * steps / dt, 1), "unit": "pairs/s", "precision_mode": s.precision, "fuse_attention": s.fuse_attention,
+                    "gemm_tflops": round(gfl / (gms * 1e-3) / 1e12, 1), "frac": round(gfl / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+
+    def quick(name, precision, fp32_weights, note=None, **skw):
+        cfg = CFGS[name]()
+        w = weights.make_weights(cfg, bf16_matrices=not fp32_weights)
+        s = scorers.make_scorer(cfg, w, precision=precision, device=local, chunk_pairs=a.chunk,
+                                fuse_attention="auto" if a.fuse_attn_arg < 0 else a.fuse_attn_arg, **skw)
+        fd, r = timed(s, name, cfg, ps, feats)
+        r["parity_max_vecrel_vs_fp32_port"] = oracle_parity(cfg, w, s, fd, ps.n)
+        r["parity_sample"] = "64 pairs of the timed %d-pair launch (its own logits)" % ps.n
+        if note:
+            r["weights"] = note
         s.close()
         return r
-    out["precision3"] = quick("zk", "auto", True, True)
-    out["lds"] = quick("lds", 2, False, False)
-    out["lxmert"] = quick("lxmert", 2, False, False)
+    out["precision3"] = quick("zk", "auto", True, "seeded fp32, NOT bf16-rounded (a real checkpoint's situation); precision auto -> mode 3")
+    out["lds"] = quick("lds", 2, False)
+    out["lxmert"] = quick("lxmert", 2, False)
+    # ---- SURVEY.md section 8(d)'s other workload shapes on the same code: the reference's padded layout, the all-10-boxes worst case, and
+    # how the rate moves with the box count (live_token_fraction is a property of the synthetic distribution, not of the kernels) ----
+    zcfg, zw, zs = members["zk"]
+    out["dense"] = quick("zk", 2, False, pack_tokens=False)
+    out["dense"]["live_token_fraction"] = 1.0
+    sweep = []
+    for mu in (0.3, 1.1, 1.8, 2.2, None):          # None: every pair has 10 boxes
+        if mu == 1.1:
+            ps_, f_ = ps, feats
+        else:
+            ps_ = synth.make_pairs(a.queries, a.cands, tag="/bench0", with_feats=False, all_boxes=mu is None, box_mu=mu or 1.1)
+            f_ = device_feats(ps_, dev, 20200823)
+        fd, r = timed(zs, "zk", zcfg, ps_, f_)
+        r.update({"box_mu": mu, "mean_boxes_per_pair": round(float(np.minimum(ps_.num_boxes, N_BOX).mean()), 2),
+                  "live_token_fraction": live_fraction("zk", {"zk": zcfg}, ps_, False)})
+        if mu is None:
+            r["parity_max_vecrel_vs_fp32_port"] = oracle_parity(zcfg, zw, zs, fd, ps_.n)
+            out["all_boxes"] = r
+        sweep.append(r)
+        del fd, f_
+    out["box_sweep"] = sweep
+    # ---- one GPU's share of the strong-scaling jobs at N = 8 (the metric's 1000 x 30 set: 125 queries = 3750 pairs; testB: 994 queries /
+    # 8 ranks): what a rank of the 8-GPU run does per step, so that the SCALE line has a stated expectation ----
+    shard = {}
+    for kind, NQ, cr in (("bench_strong_n8", a.queries, a.cands), ("testB_n8", 994, (8, 30))):
+        whole = synth.make_pairs(NQ, cr, tag="/bench0" if kind.startswith("bench") else "/testB", with_feats=False)
+        qop = whole.query_id - whole.query_id.min()
+        lo, hi = sharding.query_block(NQ, 8, 0)
+        s0, e0 = sharding.pair_slice_for_queries(qop, lo, hi)
+        ps_ = whole.take(slice(s0, e0))
+        f_ = device_feats(ps_, dev, 20200823)
+        fd, r = timed(zs, "zk", zcfg, ps_, f_, steps=10)
+        shard[kind] = {"pairs_rank0": ps_.n, "value_one_gpu": r["value"], "predicted_strong_8": round(8 * r["value"], 1), "unit": "pairs/s",
+                       "note": "rank 0's query block of the N = 8 job scored alone on this GPU; 8 x that = the 8-GPU rate if ranks do not disturb each other (the gather is 15 KB per rank)"}
+        del fd, f_
+    out["shard_rates"] = shard
     return out
 
 

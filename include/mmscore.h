@@ -82,12 +82,14 @@ typedef struct mms_config {
                                  no position embedding, so identical rows of a pair (the zero-padded boxes, boxes of one class) stay
                                  identical through every layer: one representative is kept and its key carries log(multiplicity) --
                                  the same softmax and the same P V up to fp32 round-off */
-    int32_t fuse_layernorm;   /* 1: the N = 768 projections (attention output, FFN down) of launches with >= 16384 rows add the
-                                 residual and apply the LayerNorm in their GEMM epilogue (gemm_pp_ln.h: the three column tiles of
-                                 a row panel exchange row statistics across workgroups; precision mode 2 only), instead of
-                                 writing the fp32 sum for a separate LayerNorm kernel.  Same results to fp32 round-off; 12 -> 6 KB
-                                 of HBM traffic per row and LayerNorm, but measured NOT faster on MI355X, so the
-                                 default is 0 */
+    int32_t fuse_layernorm;   /* mask -- bit 0: the attention-output projections, bit 1: the FFN-down projections of launches with
+                                 >= 16384 rows add bias + residual and apply the LayerNorm in their GEMM epilogue (gemm_pp_ln.h: the
+                                 residual rides in as eight extra K stages against an identity built in registers, the three column
+                                 tiles of a row panel exchange row statistics across workgroups; precision mode 2 only), instead of
+                                 writing the fp32 sum for a separate LayerNorm kernel.  Same results to fp32 round-off (one-pass
+                                 variance); 12 -> 6 KB of HBM traffic per row and LayerNorm, no LayerNorm launches; +1.5 % on the
+                                 bench batch.  scorers.py passes 3; a launch whose workgroups are not all
+                                 resident (GPU shared with another process) falls back to the two-kernel route by itself */
     int32_t fuse_attention;   /* 1: the self-attention sub-layers of launches with >= 16384 rows run the Q / K / V projection and the
                                  attention in ONE kernel (qkv_attn.hip: a workgroup projects one head of a 256-row tile, keeps the 192
                                  result columns in LDS and attends from there), so the fp32 [rows][2304] Q | K | V tensor never goes
@@ -165,9 +167,10 @@ typedef struct mms_ensemble_batch {
 
 /* ABI revision of the structs and entry points declared in this header.  It changes whenever a struct gains a field or an entry
  * point changes its signature (r1: 1; r2 added mms_config.fuse_layernorm, mms_zk_batch.label_ids, mms_lxmert_batch.label_ids / x_norm
- * without bumping it; r3: 3, then 4 with mms_config.fuse_attention).  A caller built against another revision would make the library read past its structs, so compare
+ * without bumping it; r3: 3, then 4 with mms_config.fuse_attention; r4: 5 -- mms_dbg_gemm takes the tile engine per call,
+ * the process-global mms_set_gemm_variant and the lab engines' hooks left the product library, fuse_layernorm became a mask).  A caller built against another revision would make the library read past its structs, so compare
  * BEFORE the first mms_create:  if (mms_version() != MMS_ABI_VERSION) abort();   (lib.py's load() does) */
-#define MMS_ABI_VERSION 4
+#define MMS_ABI_VERSION 5
 int mms_version(void);
 const char* mms_global_error(void);              /* message of the last failing mms_create */
 
@@ -193,6 +196,9 @@ int mms_score_ensemble(mms_handle* zk, mms_handle* lds, mms_handle* lxmert, cons
 /* accumulated hipEvent time (ms) and launch count of the GEMM kernels since the last reset;
  * enable = 1 brackets every GEMM launch with events on its stream (bench / roofline only) */
 int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out, int64_t* launches_out, double* flops_out);
+/* the same, for one class of the timed GEMM launches: cls 0 = plain epilogue, 1 = fused bias + residual + LayerNorm epilogue
+ * (mms_config.fuse_layernorm; their duration includes the residual stages and the LayerNorm work, their FLOP count the projection alone) */
+int mms_gemm_timing_class(mms_handle* h, int32_t cls, double* ms_out, int64_t* launches_out, double* flops_out);
 /* The fused QKV + attention launches (mms_config.fuse_attention) of the calls timed through mms_gemm_timing (enabled / reset there),
  * reported apart from the GEMM launches because their duration includes the attention of their pairs: total ms, launches, executed
  * projection FLOPs. */
@@ -202,23 +208,20 @@ int mms_fused_timing(mms_handle* h, double* ms_out, int64_t* launches_out, doubl
 int mms_debug_read_x(mms_handle* h, float* dst_dev, int64_t rows, void* stream); /* current hidden state -> fp32 [rows,768] */
 int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const float* w_f32_nk, int64_t N,
                  const float* bias, const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes,
+                 int32_t variant /* 0: the forward's per-shape engine choice; 1, 4, 16: register-staged tiles; 20 / 26: ping-pong
+                                    (one tile per workgroup / persistent); 27: three-pass ping-pong -- per CALL, no global state */,
                  float* c_f32, void* stream);
 /* fp8 GEMM (precision 4, MX-scaled fp8 MFMA) on fp32 operands: A and W are quantised exactly as the forward does it (A: e4m3 RNE of the
  * value; W: per output channel the smallest POWER OF TWO scale with max|w| / scale <= 448, e4m3 RNE of w / scale; the scale is applied
  * by the MFMA instruction itself as the weight operand's e8m0 hardware scale).  N % 256 == 0, K % 128 == 0 */
 int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, int64_t N, const float* bias, int32_t act,
                     int32_t out_f8, float* c_f32, void* stream);
-/* precision-5 GEMM (gemm_mx.hip: fp16 high pass + MX-scaled e4m3 low pass) on fp32 operands, N % 256 == 0, K % 256 == 0; A is split into
- * h3 planes and W prepared exactly as the forward does it; out_h3 != 0: the output leaves as h3 planes and is converted back */
-int mms_dbg_gemm_mx(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, int64_t N, const float* bias, int32_t act,
-                    int32_t out_h3, float* c_f32, void* stream);
 /* out = LayerNorm(A W^T + bias + resid) over N = 768 through the GEMM with the fused LayerNorm epilogue (gemm_pp_ln.h) and the
  * LayerNorm kernel queued behind it; *mode_out = 1 when the launch ran fused, 2 when it took the plain two-kernel route */
 int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, const float* bias, const float* resid_f32,
                     const float* gamma, const float* beta, int32_t f8, float* c_f32, int32_t* mode_out, void* stream);
-/* test hook: force one of the PRODUCT tile engines for every GEMM (1, 4, 16: register-staged tiles; 26: persistent ping-pong;
- * 27: three-pass ping-pong; anything else = per-shape default) / time one GEMM shape on random data */
-int mms_set_gemm_variant(int32_t variant);
+/* time one GEMM shape on random data (variant as in mms_dbg_gemm; 52: the MX-fp8 engine; 60 / 61: the LayerNorm kernel with / without
+ * residual; 62 / 63: N = 768 projection + residual + LayerNorm as two kernels / as one launch with the fused epilogue) */
 int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t act, int32_t out_planes, int32_t resid,
                        int32_t variant, int32_t iters, float* ms_out);
 int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B, int32_t Sq, int32_t Sk,

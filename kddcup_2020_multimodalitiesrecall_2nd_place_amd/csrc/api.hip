@@ -1,5 +1,6 @@
 // libmmscore C ABI: handle, weight container, workspace and the launch plans of the three forwards.
 // See include/mmscore.h for the contract and the reference call sites each entry point replaces.
+#include <cassert>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -28,7 +29,10 @@ struct Planes {
     unsigned char* f8 = nullptr;   // precision mode 4: the same activation as e4m3 bytes (the fp8 GEMMs' A operand)
     // hl32 layout (common.h): hi and lo are ONE buffer of alternating 32-element blocks (lo == hi + 32); a LOGICAL element offset that is
     // a multiple of 32 (row offsets: every leading dimension is) is twice as far in the buffer
-    Planes at(long long elem_off) const { Planes p; p.hi = hi + 2 * elem_off; p.lo = lo + 2 * elem_off; p.f8 = f8 ? f8 + elem_off : nullptr; return p; }
+    Planes at(long long elem_off) const {
+        assert((elem_off & 31) == 0 && "hl32 planes: a view must start on a 32-element block");     // every caller passes row * 768
+        Planes p; p.hi = hi + 2 * elem_off; p.lo = lo + 2 * elem_off; p.f8 = f8 ? f8 + elem_off : nullptr; return p;
+    }
 };
 
 // *8 / *s: e4m3 copy of the matrix (8 x 128-byte tiles) and its per-output-channel scales as packed e8m0 bytes (precision mode 4 only)
@@ -93,6 +97,7 @@ struct mms_handle {
     // fused residual + LayerNorm epilogue (gemm_pp_ln.h): per-row statistics granules, per-launch control words (check-in count,
     // fused / plain decision), launch tag.  ln_slot counts the fused launches of the current call.
     float* ln_stats = nullptr; int* ln_ctl = nullptr; int ln_slot = 0; unsigned ln_tag = 0;
+
     static constexpr int LN_SLOTS = 2048;
     int fuse_ln = 0;       // mms_config.fuse_layernorm (lab build: env MMS_FUSE_LN overrides)
     int fuse_attn = 0;     // mms_config.fuse_attention: QKV projection + self-attention in one kernel (qkv_attn.hip; precision mode 2)
@@ -128,6 +133,7 @@ struct mms_handle {
     // ---- gemm timing ----
     bool timing = false;
     std::vector<hipEvent_t> ev;
+    std::vector<unsigned char> ev_cls;   // per timed launch (event pair): 0 plain GEMM epilogue, 1 fused bias + residual + LayerNorm epilogue
     size_t ev_used = 0;
     int64_t gemm_launches = 0;
     int64_t fused_attn_launches = 0;     // qkv_attn.hip launches since mms_create (mms_dbg_counter)
@@ -144,6 +150,17 @@ namespace {
         if (e_ != hipSuccess)                                                                             \
             return (h)->fail(MMS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
     } while (0)
+
+
+// two more events at the end of `v` (nothing is appended unless both were created: mms_destroy destroys every element)
+int grow_event_pair(mms_handle* h, std::vector<hipEvent_t>& v) {
+    hipEvent_t a, b;
+    HIP_TRY(h, hipEventCreate(&a));
+    hipError_t e = hipEventCreate(&b);
+    if (e != hipSuccess) { (void)hipEventDestroy(a); return h->fail(MMS_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+    v.push_back(a); v.push_back(b);
+    return MMS_OK;
+}
 
 int dev_alloc(mms_handle* h, std::vector<void*>& pool, void** out, size_t bytes) {
     void* p = nullptr;
@@ -568,15 +585,12 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     p.m_dev = m_dev; p.a_index = a_index; p.rmap = rmap; p.r_index = r_index;
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
     if (h->timing) {
-        if (h->ev_used + 2 > h->ev.size()) {
-            h->ev.resize(h->ev_used + 2);
-            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used]));
-            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used + 1]));
-        }
+        if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
         p.flop_counter = h->flop_counter;   // executed algorithmic FLOPs (2*M_live*N*K), counted on the device
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
         launch_gemm(p, nsplit, st);
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
+        h->ev_cls.resize(h->ev_used / 2 + 1); h->ev_cls[h->ev_used / 2] = 0;
         h->ev_used += 2;
         h->gemm_launches += 1;
     } else {
@@ -602,15 +616,12 @@ int gemm_f8(mms_handle* h, hipStream_t st, const unsigned char* a8, int lda, con
     p.m_dev = m_dev;
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
     if (h->timing) {
-        if (h->ev_used + 2 > h->ev.size()) {
-            h->ev.resize(h->ev_used + 2);
-            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used]));
-            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used + 1]));
-        }
+        if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
         p.flop_counter = h->flop_counter;
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
         if (!launch_gemm_mx8(p, st)) return h->fail(MMS_ERR_ARG, "gemm_f8: shape not supported");
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
+        h->ev_cls.resize(h->ev_used / 2 + 1); h->ev_cls[h->ev_used / 2] = 0;
         h->ev_used += 2;
         h->gemm_launches += 1;
     } else if (!launch_gemm_mx8(p, st)) return h->fail(MMS_ERR_ARG, "gemm_f8: shape not supported");
@@ -627,7 +638,8 @@ int gemm_ln(mms_handle* h, hipStream_t st, bool f8, const Planes& a, int lda, co
             const float* bias, int64_t M, int K, const Planes& resid, const float* g, const float* b, const Planes& out, float* t,
             const int* m_dev, bool* fused) {
     *fused = false;
-    if (!h->fuse_ln || f8 || M < 16384 || h->nsplit != 2 || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
+    // mms_config.fuse_layernorm is a mask: bit 0 the attention-output projections (K = 768), bit 1 the FFN-down projections (K = inter)
+    if (!(h->fuse_ln & (K == H ? 1 : 2)) || f8 || M < 16384 || h->nsplit != 2 || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
     if (K % 64 != 0) return MMS_OK;
     (void)w8; (void)wscale;          // the fp8 mode always takes the two-kernel route (f8 returned above)
     GemmParams p{};
@@ -644,15 +656,12 @@ int gemm_ln(mms_handle* h, hipStream_t st, bool f8, const Planes& a, int lda, co
     const int* skip = p.ln_ctl + 1;
     h->ln_slot += 1;
     if (h->timing) {
-        if (h->ev_used + 2 > h->ev.size()) {
-            h->ev.resize(h->ev_used + 2);
-            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used]));
-            HIP_TRY(h, hipEventCreate(&h->ev[h->ev_used + 1]));
-        }
-        p.flop_counter = h->flop_counter;
+        if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
+        p.flop_counter = h->flop_counter + 2;     // slot 2: the LayerNorm-fused launches (mms_gemm_timing adds it to the GEMM total)
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
         if (!launch_gemm_pp_ln(p, h->nsplit, st)) return h->fail(MMS_ERR_ARG, "gemm_ln: shape not supported");
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
+        h->ev_cls.resize(h->ev_used / 2 + 1); h->ev_cls[h->ev_used / 2] = 1;
         h->ev_used += 2;
         h->gemm_launches += 1;
     } else if (!launch_gemm_pp_ln(p, h->nsplit, st)) return h->fail(MMS_ERR_ARG, "gemm_ln: shape not supported");
@@ -736,11 +745,7 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
         q.M = (int)M; q.m_dev = pk.rows; q.fast = h->fuse_attn == 2;
         if (h->alternate) { q.reverse = h->flip; h->flip ^= 1; }
         if (h->timing) {      // timed apart from the GEMM launches: this launch's duration includes the attention of its pairs
-            if (h->ev_fused_used + 2 > h->ev_fused.size()) {
-                h->ev_fused.resize(h->ev_fused_used + 2);
-                HIP_TRY(h, hipEventCreate(&h->ev_fused[h->ev_fused_used]));
-                HIP_TRY(h, hipEventCreate(&h->ev_fused[h->ev_fused_used + 1]));
-            }
+            if (h->ev_fused_used + 2 > h->ev_fused.size()) { if (int rc = grow_event_pair(h, h->ev_fused)) return rc; }
             q.flop_counter = h->flop_counter + 1;
             HIP_TRY(h, hipEventRecord(h->ev_fused[h->ev_fused_used], st));
             if (!launch_qkv_attn(q, st)) return h->fail(MMS_ERR_ARG, "qkv_attn: shape not supported");
@@ -1274,6 +1279,8 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
     if (cfg->model < 0 || cfg->model > 2) { g_err = "bad model id"; return MMS_ERR_ARG; }
     if (cfg->inter <= 0 || cfg->inter % 128) { g_err = "inter must be a positive multiple of 128"; return MMS_ERR_ARG; }
     if (cfg->precision < 1 || cfg->precision > 4) { g_err = "precision must be 1, 2, 3 or 4"; return MMS_ERR_ARG; }
+    if (cfg->fuse_attention < 0 || cfg->fuse_attention > 2) { g_err = "fuse_attention must be 0, 1 or 2"; return MMS_ERR_ARG; }
+    if (cfg->fuse_layernorm < 0 || cfg->fuse_layernorm > 3) { g_err = "fuse_layernorm must be a mask in 0..3 (1: attention output, 2: FFN down)"; return MMS_ERR_ARG; }
     if (cfg->text_len <= 0 || cfg->text_len > 32 || cfg->text_len + 1 > cfg->max_pos) { g_err = "bad text_len"; return MMS_ERR_ARG; }
     if (cfg->layers < 0 || cfg->vocab <= 0 || cfg->type_vocab < 2) { g_err = "bad layer/vocab config (type_vocab must be >= 2: segment ids 0 / 1)"; return MMS_ERR_ARG; }
     {   // the attention kernels cover sequences of up to 48 tokens (3 x 3 tiles of 16): zk text+10 boxes, lds text+10+10, lxmert text | 10
@@ -1287,7 +1294,7 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
     mms_handle* h = new mms_handle();
     h->cfg = *cfg;
     h->f8 = cfg->precision == 4;
-    h->fuse_ln = cfg->fuse_layernorm != 0;
+    h->fuse_ln = cfg->fuse_layernorm;
     h->fuse_attn = cfg->fuse_attention;
     h->nsplit = h->f8 ? 2 : cfg->precision;
 #ifdef MMS_LAB   // A/B knobs exist in libmmscore_lab.so only; the product library reads no environment variable
@@ -1584,9 +1591,9 @@ int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out
     DeviceScope dev(h->cfg.device);
     if (!h->flop_counter) {
         void* p;
-        if (int rc = dev_alloc(h, h->w_allocs, &p, 16)) return rc;      // [0]: GEMM launches, [1]: fused QKV + attention launches
+        if (int rc = dev_alloc(h, h->w_allocs, &p, 32)) return rc;      // [0]: GEMM launches, [1]: fused QKV + attention launches, [2]: LayerNorm-fused GEMM launches
         h->flop_counter = (unsigned long long*)p;
-        HIP_TRY(h, hipMemset(p, 0, 16));
+        HIP_TRY(h, hipMemset(p, 0, 32));
     }
     if (ms_out || launches_out || flops_out) {
         double ms = 0;
@@ -1596,14 +1603,36 @@ int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out
             HIP_TRY(h, hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
             ms += t;
         }
-        unsigned long long fl = 0;
-        HIP_TRY(h, hipMemcpy(&fl, h->flop_counter, 8, hipMemcpyDeviceToHost));
+        unsigned long long fl[3] = {0, 0, 0};
+        HIP_TRY(h, hipMemcpy(fl, h->flop_counter, 24, hipMemcpyDeviceToHost));
         if (ms_out) *ms_out = ms;
         if (launches_out) *launches_out = h->gemm_launches;
-        if (flops_out) *flops_out = (double)fl;
+        if (flops_out) *flops_out = (double)fl[0] + (double)fl[2];
     }
-    if (reset) { h->ev_used = 0; h->gemm_launches = 0; h->ev_fused_used = 0; h->fused_timed = 0; HIP_TRY(h, hipMemset(h->flop_counter, 0, 16)); }
+    if (reset) { h->ev_used = 0; h->gemm_launches = 0; h->ev_fused_used = 0; h->fused_timed = 0; HIP_TRY(h, hipMemset(h->flop_counter, 0, 32)); }
     h->timing = enable != 0;
+    return MMS_OK;
+}
+
+// the LayerNorm-fused share of what mms_gemm_timing reports (those launches' duration includes the residual stages and the LayerNorm work):
+// duration, launches and executed FLOPs of the timed launches of class `cls` (0: plain epilogue, 1: fused LayerNorm epilogue)
+int mms_gemm_timing_class(mms_handle* h, int32_t cls, double* ms_out, int64_t* launches_out, double* flops_out) {
+    if (!h || cls < 0 || cls > 1) return MMS_ERR_ARG;
+    DeviceScope dev(h->cfg.device);
+    double ms = 0;
+    int64_t n = 0;
+    if (h->ev_used) HIP_TRY(h, hipEventSynchronize(h->ev[h->ev_used - 1]));
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        if (h->ev_cls[i / 2] != cls) continue;
+        float t = 0;
+        HIP_TRY(h, hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
+        ms += t; n += 1;
+    }
+    unsigned long long fl = 0;
+    if (h->flop_counter) HIP_TRY(h, hipMemcpy(&fl, h->flop_counter + (cls ? 2 : 0), 8, hipMemcpyDeviceToHost));
+    if (ms_out) *ms_out = ms;
+    if (launches_out) *launches_out = n;
+    if (flops_out) *flops_out = (double)fl;
     return MMS_OK;
 }
 
@@ -1640,8 +1669,8 @@ static int dbg_fail(const char* m) { g_err = m; return MMS_ERR_HIP; }
 #define DBG_TRY(expr) do { if ((expr) != hipSuccess) return dbg_fail(#expr); } while (0)
 
 int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const float* w_f32_nk, int64_t N, const float* bias,
-                 const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes, float* c_f32, void* stream) {
-    if (!a_f32 || !w_f32_nk || !c_f32 || M <= 0 || N % 128 || K % 64 || lda < K || lda % 32) { g_err = "mms_dbg_gemm: bad argument"; return MMS_ERR_ARG; }
+                 const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes, int32_t variant, float* c_f32, void* stream) {
+    if (!a_f32 || !w_f32_nk || !c_f32 || M <= 0 || N % 128 || K % 64 || lda < K || lda % 32 || variant < 0) { g_err = "mms_dbg_gemm: bad argument"; return MMS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     bf16 *ap = nullptr, *wp = nullptr, *rp = nullptr, *cp = nullptr;
     float* wtmp = nullptr;
@@ -1652,6 +1681,7 @@ int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const fl
     GemmParams p{};
     p.a_hi = ap; p.a_lo = ap + MMS_PLANE_LO; p.lda = (int)lda; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
     p.w = wp; p.w_lo = wp + N * K; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
+    p.variant = variant;      // 0: the per-shape choice of the forward; else ONE named tile engine (gemm_dispatch.hip)
     if (resid_f32) {
         DBG_TRY(hipMalloc((void**)&rp, (size_t)M * N * 4));
         launch_split_f32(resid_f32, rp, rp + MMS_PLANE_LO, M * N, st);
@@ -1699,6 +1729,7 @@ int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32
     return MMS_OK;
 }
 
+#ifdef MMS_LAB
 // precision mode 5 GEMM (gemm_mx.hip) on fp32 operands: A goes through the h3 split (fp16 + e4m3 residual), W through the weight
 // preparation of the forward (fp16 copy + e4m3 copy + per-channel scales); out_h3: the result leaves as h3 planes (and is converted back)
 int mms_dbg_gemm_mx(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, int64_t N, const float* bias, int32_t act,
@@ -1730,6 +1761,8 @@ int mms_dbg_gemm_mx(const float* a_f32, int64_t M, int64_t K, const float* w_f32
     for (void* q : {(void*)a16, (void*)a8, (void*)w16, (void*)w8, (void*)ws4, (void*)cs, (void*)c16, (void*)c8}) (void)hipFree(q);
     return MMS_OK;
 }
+
+#endif  // MMS_LAB
 
 #ifdef MMS_LAB
 unsigned long long* g_ln_dbg = nullptr;   // lab: device buffer for the per-tile phase stamps of the next mms_dbg_gemm_ln (tools/ln_trace.py)
@@ -1791,8 +1824,6 @@ int64_t mms_dbg_counter(mms_handle* h, int32_t which) {
     return which == 0 ? h->fused_attn_launches : -1;
 }
 
-int mms_set_gemm_variant(int32_t v) { set_gemm_variant(v); return MMS_OK; }
-
 // GEMM micro-benchmark on random operands: returns the average kernel time (ms) over `iters` launches.
 int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t act, int32_t out_planes, int32_t resid,
                        int32_t variant, int32_t iters, float* ms_out) {
@@ -1824,8 +1855,7 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     if (resid) { p.r_hi = rp; p.r_lo = rp + MMS_PLANE_LO; p.ldr = (int)N; }
     if (out_planes) { p.out_kind = OUT_PLANES; p.c_hi = cp; p.c_lo = cp + MMS_PLANE_LO; p.ldp = (int)N; }
     else { p.out_kind = OUT_F32; p.c_f32 = cf; p.ldc = (int)N; }
-    const int saved = get_gemm_variant();
-    set_gemm_variant(variant);
+    p.variant = variant < 50 ? variant : 0;
     hipEvent_t e0, e1;
     DBG_TRY(hipEventCreate(&e0)); DBG_TRY(hipEventCreate(&e1));
     // variants 50 / 51: the precision-5 engine (gemm_mx.hip) / its high pass alone (lab) on the same random operands
@@ -1859,7 +1889,33 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
         pm.a_hi = (const bf16*)a16; pm.a8 = a8; pm.w = (const bf16*)w16; pm.w8 = w8; pm.w8_scale4 = ws4; pm.col_scale = cs; pm.w_lo = nullptr;
         if (out_planes) { pm.out_kind = OUT_H3; pm.c_h16 = c16; pm.c_l8 = c8; pm.ldh = (int)N; }
     }
+    // variants 62 / 63: the N = 768 projection + residual + LayerNorm as two kernels (fp32 tensor in between) / as ONE launch with the
+    // fused epilogue (gemm_pp_ln.h); both leave split planes
+    float* ln_stats = nullptr; int* ln_ctl = nullptr; unsigned ln_tag = 0x1000u;
+    if (variant == 62 || variant == 63) {
+        if (N != H || nsplit != 2) { g_err = "mms_dbg_gemm_bench: variants 62 / 63 need N == 768, nsplit == 2"; return MMS_ERR_ARG; }
+        DBG_TRY(hipMalloc((void**)&ln_stats, (size_t)(M + 256) * 48)); DBG_TRY(hipMemset(ln_stats, 0, (size_t)(M + 256) * 48));
+        DBG_TRY(hipMalloc((void**)&ln_ctl, 8));
+    }
     auto run = [&]() {
+        if (variant == 62 || variant == 63) {
+            GemmParams q = p;
+            q.out_kind = OUT_F32; q.c_f32 = cf; q.ldc = H; q.r_hi = nullptr; q.r_lo = nullptr;
+            LnResid res;
+            res.hi = rp; res.lo = rp + MMS_PLANE_LO; res.ld = H;
+            if (variant == 62) {
+                launch_gemm(q, 2, 0);
+                launch_ln_to_planes(cf, H, bias, bias, cp, cp + MMS_PLANE_LO, H, (int)M, 0, nullptr, res);
+                return true;
+            }
+            q.r_hi = rp; q.r_lo = rp + MMS_PLANE_LO; q.ldr = H; q.c_hi = cp; q.c_lo = cp + MMS_PLANE_LO; q.ldp = H;
+            q.ln_gamma = bias; q.ln_beta = bias; q.ln_stats = ln_stats; q.ln_tag = ++ln_tag; q.ln_ctl = ln_ctl;
+            if (hipMemsetAsync(ln_ctl, 0, 8, 0) != hipSuccess) return false;
+            if (!launch_gemm_pp_ln(q, 2, 0)) return false;
+            res.skip = ln_ctl + 1;
+            launch_ln_to_planes(cf, H, bias, bias, cp, cp + MMS_PLANE_LO, H, (int)M, 0, nullptr, res);
+            return true;
+        }
         if (variant == 60 || variant == 61) {     // the LayerNorm kernel (with / without the residual planes) on M rows: HBM-bound, 9 / 6 KB per row
             if (N != H) return false;
             LnResid res;
@@ -1872,7 +1928,11 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
         if (variant == 51) return launch_gemm_mx_hi_only(pm, 0);
 #endif
         if (variant == 52) return launch_gemm_mx8(pm, 0);
+#ifdef MMS_LAB
         return launch_gemm_mx(pm, 0);
+#else
+        return false;     // 50 / 51: lab build only
+#endif
     };
     if (!run()) { g_err = "mms_dbg_gemm_bench: variant not available"; return MMS_ERR_ARG; }
     run();
@@ -1883,11 +1943,10 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     float ms = 0;
     DBG_TRY(hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / iters;
-    set_gemm_variant(saved);
     DBG_TRY(hipGetLastError());
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     for (void* q : {(void*)af, (void*)wf, (void*)rf, (void*)bias, (void*)cf, (void*)ap, (void*)wp, (void*)rp, (void*)cp, (void*)a16, (void*)a8,
-                    (void*)w16, (void*)w8, (void*)ws4, (void*)cs, (void*)c16, (void*)c8}) (void)hipFree(q);
+                    (void*)w16, (void*)w8, (void*)ws4, (void*)cs, (void*)c16, (void*)c8, (void*)ln_stats, (void*)ln_ctl}) (void)hipFree(q);
     return MMS_OK;
 }
 

@@ -3,33 +3,36 @@
 // Product library (libmmscore.so): per-shape choice between the kernels a forward can launch -- the 256x256 persistent ping-pong
 // engine (gemm_pp.hip) for the big encoder GEMMs, its 256x128 three-pass cut (gemm_ppw.hip) for precision mode 3, and the
 // register-staged tiles of gemm_tile.hip for the small ones (CLS-only last block, poolers, heads, label text).  No environment
-// variable is read here.  `set_gemm_variant` is a TEST hook (mms_set_gemm_variant): it can only select among these product kernels.
+// variable is read here and there is no process-global state: a caller that wants ONE engine names it per launch (GemmParams::variant;
+// the kernel tests do, through mms_dbg_gemm).
 //
 // Lab library (libmmscore_lab.so, `make lab`, -DMMS_LAB): additionally honours MMS_GEMM_VARIANT, reaches the LDS-DMA double-buffer
-// tile of gemm_tile.hip and -- with MMS_GEMM_DIAG -- the timing-only DIAG instantiations of gemm_pp.hip, which compute WRONG results
-// by design.  None of that code is in the product binary.  (The round-1 A/B kernels gemm.hip / gemm_ring.hip were removed in round 3:
+// tile of gemm_tile.hip, the measured-and-shelved engines (gemm_dw.hip: variant 28; gemm_mx.hip's fp16 + MX-fp8 "1.5 pass" kernel) and
+// -- with MMS_GEMM_DIAG -- the timing-only DIAG instantiations of gemm_pp.hip, which compute WRONG results by design.  None of that code is in the product binary.  (The round-1 A/B kernels gemm.hip / gemm_ring.hip were removed in round 3:
 // their measurements stay in profiles/r01c_gemm_variants.txt.)
+#include <atomic>
 #include <cstdlib>
 
 #include "kernels.h"
 
-static int g_variant = -1;
-void set_gemm_variant(int v) { g_variant = v; }
-int get_gemm_variant() {
-    if (g_variant < 0) {
-#ifdef MMS_LAB
-        const char* e = getenv("MMS_GEMM_VARIANT");
-        g_variant = e ? atoi(e) : 99;
-#else
-        g_variant = 99;  // auto: per-shape choice between the best measured tiles (profiles/r01c_gemm_variants.txt)
-#endif
-    }
-    return g_variant;
+int device_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 8;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v) return v;
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) ? prop.multiProcessorCount / 8 * 8 : 8;
+    cache[dev].store(v, std::memory_order_relaxed);      // idempotent: every thread computes the same value
+    return v;
 }
 
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return;
-    int variant = get_gemm_variant();
+    int variant = p.variant ? p.variant : 99;
+#ifdef MMS_LAB
+    if (!p.variant) { static const int env_variant = getenv("MMS_GEMM_VARIANT") ? atoi(getenv("MMS_GEMM_VARIANT")) : 99; variant = env_variant; }
+#endif
     if (nsplit == 3) {   // three passes: 256x128 ping-pong phases for large M (variant 27 forces it), 128x128 tile otherwise
         if ((variant == 27 || (variant == 99 && p.M >= 16384)) && launch_gemm_ppw(p, st)) return;
         launch_gemm_tile(p, 3, 1, st);
@@ -42,9 +45,9 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         variant = 99;
     }
 #endif
-    if (variant != 1 && variant != 4 && variant != 16 && variant != 20 && variant != 26 && variant != 28
+    if (variant != 1 && variant != 4 && variant != 16 && variant != 20 && variant != 26
 #ifdef MMS_LAB
-        && variant != 3
+        && variant != 3 && variant != 28
 #endif
     ) variant = 99;
     if (variant == 99) {  // auto (profiles/r01c_gemm_variants.txt): 256x256 ping-pong phases for large M; for the small GEMMs
@@ -52,7 +55,9 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         if (p.N % 256 == 0 && p.M >= 16384) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)
         else variant = (p.N >= 1536 && p.N % 256 == 0 && p.M >= 8192) ? 16 : 4;
     }
+#ifdef MMS_LAB
     if (variant == 28) { if (launch_gemm_dw(p, nsplit, st)) return; variant = 26; }
+#endif
     if (variant == 26) { if (launch_gemm_pp(p, nsplit, 0, st, true)) return; variant = 4; }
     if (variant == 20) { if (launch_gemm_pp(p, nsplit, 0, st)) return; variant = 4; }
     if (launch_gemm_tile(p, nsplit, variant, st)) return;

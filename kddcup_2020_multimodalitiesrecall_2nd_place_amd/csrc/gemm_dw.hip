@@ -137,16 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const GemmParams p) {
     }
 }
 
-static int dw_cu_count() {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
-                   ? prop.multiProcessorCount / 8 * 8 : 8;
-    }
-    return n_cu;
-}
+static int dw_cu_count() { return device_cu_count(); }
 
 // false: shape not supported (N % 256, K % 64, not two-pass)
 bool launch_gemm_dw(const GemmParams& p, int nsplit, hipStream_t st) {

@@ -51,6 +51,7 @@ __device__ __forceinline__ void mx_barrier() {
 
 }  // namespace
 
+#ifdef MMS_LAB      // the fp16 + MX-scaled-e4m3 "1.5 pass" engine: kernel-tested, measured at parity with two bf16 passes (LABBOOK R3.4), not on any product path
 // LOW = false: the high pass alone (timing reference of the lab bench; results are those of a single fp16 pass)
 template <int ACT, bool LOW = true>
 __global__ __launch_bounds__(512) void gemm_mx_kernel(const GemmParams p) {
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(const GemmParams p) {
         if (wave >= NW / 2) mx_barrier();     // stagger again
     }
 }
+#endif  // MMS_LAB
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Precision mode 4 GEMM: e4m3 x e4m3 on the MX-scaled instruction alone -- v_mfma_scale_f32_16x16x128_f8f6f4 runs at TWICE the rate of
@@ -429,17 +431,9 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(const GemmParams p) {
     }
 }
 
-static int mx_cu_count() {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
-                   ? prop.multiProcessorCount / 8 * 8 : 8;
-    }
-    return n_cu;
-}
+static int mx_cu_count() { return device_cu_count(); }
 
+#ifdef MMS_LAB
 template <bool LOW>
 static void launch_mx(const GemmParams& p, hipStream_t st) {
     const int nblk = ((p.M + 255) / 256) * (p.N / 256);
@@ -460,6 +454,7 @@ bool launch_gemm_mx(const GemmParams& p, hipStream_t st) {
     launch_mx<true>(p, st);
     return true;
 }
+#endif  // MMS_LAB
 // precision mode 4 on the MX-scaled instruction: any M (A8 rows allocated up to a multiple of 256), N % 256 == 0, K % 128 == 0 (bytes)
 bool launch_gemm_mx8(const GemmParams& p, hipStream_t st) {
     if (p.M <= 0) return true;

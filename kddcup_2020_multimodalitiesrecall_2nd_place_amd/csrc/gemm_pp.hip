@@ -66,6 +66,7 @@ template <int N> __device__ __forceinline__ void pp_wait_vmcnt() {
 #define MMS_PP_PHASES 2
 #endif
 
+
 __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
@@ -117,15 +118,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
     if (LNF && tid == 0) atomicAdd(&p.ln_ctl[0], 1);     // check-in: "this workgroup is resident" (gemm_pp_ln.h)
     const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM;
-    // LNF: whole row panels per XCD (the three tiles of a panel exchange row statistics), so the virtual index space is
-    // 8 XCDs x 3 tiles x (panels of the fullest XCD) and a few virtual indices name no tile
-    const int pan_q = nbm >> 3, pan_r = nbm & 7;
-    const int nblk = LNF ? 24 * (pan_q + (pan_r ? 1 : 0)) : nbm * nbn;
-    auto valid = [&](int v) { return !LNF || (v >> 3) < 3 * (pan_q + ((v & 7) < pan_r ? 1 : 0)); };
-    int vb = blockIdx.x;                 // virtual block id; PERSIST: the workgroup walks vb, vb + gridDim.x, ... (gridDim.x % 8 == 0)
-    while (vb < nblk && !valid(vb)) vb += gridDim.x;
+    // LNF: the three tiles of a row panel exchange row statistics, so they must run in the SAME persistent round, and should share an
+    // XCD's L2 (one fetch of the A panel).  A workgroup keeps ONE seat for the whole launch: with c = gridDim.x / 8 workgroups per XCD,
+    // seats loc = blockIdx.x / 8 < 3 (c / 3) of XCD blockIdx.x % 8 form c / 3 triples inside the XCD; the c % 3 seats left over per XCD
+    // are pooled into triples that span XCDs (32 CUs per XCD: 80 + 5 panels per round on 255 of the 256 CUs; round 2 gave the left-over
+    // seats no work at all: 6 % of the chip).  Round r of seat (panel pir, tile bn) is panel r * PR + pir.
+    const int ln_c = (int)gridDim.x >> 3, ln_t = ln_c / 3, ln_l = ln_c - 3 * ln_t;
+    const int PR = LNF ? 8 * ln_t + (8 * ln_l) / 3 : 1;      // panels per round
+    int ln_pir = 0, ln_bn = 0;
+    if constexpr (LNF) {
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        if (loc < 3 * ln_t) { ln_pir = xcd * ln_t + loc / 3; ln_bn = loc % 3; }
+        else { const int e = xcd * ln_l + (loc - 3 * ln_t); ln_pir = e < 3 * ((8 * ln_l) / 3) ? 8 * ln_t + e / 3 : nbm; ln_bn = e % 3; }     // pir = nbm: a seat without work
+    }
+    const int nblk = LNF ? (nbm + PR - 1) / PR : nbm * nbn;     // LNF: rounds
+    auto valid = [&](int v) { return !LNF || v * PR + ln_pir < nbm; };
+    const int vstep = LNF ? 1 : (int)gridDim.x;
+    int vb = LNF ? 0 : (int)blockIdx.x;  // virtual block id; PERSIST: the workgroup walks vb, vb + gridDim.x, ... (gridDim.x % 8 == 0).  LNF: the round
+    while (vb < nblk && !valid(vb)) vb += vstep;
     if (vb >= nblk) return;
-    // fused or plain is settled BEFORE the first tile (the fused route preloads residual + bias into the accumulators): normally every
+    // fused or plain is settled BEFORE the first tile (the fused route appends the residual stages to its K loop): normally every
     // workgroup has checked in within a few microseconds of the first one
     int ln_decided = 0;
     if constexpr (LNF) ln_decided = ln_decide(p.ln_ctl, (int)gridDim.x, lane);
@@ -137,15 +149,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     constexpr int ASTEP = 64;                       // elements between two K stages of an A row (hl32: a hi and a lo block per stage)
     constexpr int WSTEP = 512;                      // ... of a W row (one 1-KiB tile per stage)
     const int gr_l = lane >> 2, gc = lane & 3;
-    const bf16* a_src[NAP];
-    const bf16* w_src[2];
+    const bf16* a_src[LNF ? 1 : NAP];
+    const bf16* w_src[LNF ? 1 : 2];
+    // LNF: the residual rides in as EIGHT extra K stages -- A = the residual planes' columns [bn*256, bn*256 + 256) of the tile's rows,
+    // W = the 256 x 256 identity (built in registers, never fetched): acc += r_hi * I + r_lo * I = r_hi + r_lo, exact products, and the
+    // bytes arrive through the LDS-DMA ring under the MFMAs like every other operand (fetched straight into the accumulators at the tile
+    // boundary they cost 23 us per persistent round with nothing to overlap them: profiles/r02c_ln_fused_trace.txt)
+    constexpr int NRES = LNF ? BN / 32 : 0;
+    int r_row[LNF ? NAP : 1];      // residual row of each of the lane's A pieces (the address is formed at issue time: 4 registers, not 8)
     int bm, bn;
     auto setup = [&](int v) {
         // bijective XCD remap over the live tiles (virtual block v runs on XCD v % 8)
         if constexpr (LNF) {
-            const int xcd = v & 7, loc = v >> 3;
-            bm = xcd * pan_q + (xcd < pan_r ? xcd : pan_r) + loc / 3;
-            bn = loc % 3;
+            bm = v * PR + ln_pir;
+            bn = ln_bn;
             if (p.reverse) bm = nbm - 1 - bm;
         } else {
         const int q = nblk >> 3, r8 = nblk & 7, xcd = v & 7, loc = v >> 3;
@@ -159,7 +176,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
             const long long lrow = (p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda;
             return p.a_hi + 2 * lrow;
         };
-        if constexpr (A2) {
+        if constexpr (LNF) {
+            // rows only (the launcher guarantees identity row maps): both the A and the residual address of a piece are formed from
+            // r_row[q] at issue time -- 4 registers instead of 16
+        } else if constexpr (A2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = q * 64 + wave * 8 + (lane >> 3);
@@ -172,31 +192,55 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
                 a_src[h] = a_row(r) + (gc ^ pp_swz(r)) * 8;
             }
         }
+        if constexpr (!LNF) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = h * 128 + wave * 16 + gr_l;
             w_src[h] = p.w + wtile_off(bn * BN + r, 0, p.K) + (gc ^ pp_swz(r)) * 8;
         }
+        }
+        if constexpr (LNF) {
+#pragma unroll
+            for (int q = 0; q < NAP; ++q) {
+                const int r = q * 64 + wave * 8 + (lane >> 3);
+                const int gr = bm * BM + r;
+                r_row[q] = gr < Meff ? gr : Meff - 1;
+            }
+        }
     };
     setup(vb);
     // piece q of stage `st` into ring slot `slot`: the NAP A pieces first, then the two W halves; every piece is 1 KiB per wave
+    const int nk_main = p.K / 32;      // stages of the product proper
     auto issue = [&](int q, int st, int slot) {
         const int kst = (DIAG & 8) ? (st & 1) : st;       // DIAG 8: L2-resident source
         unsigned char* d;
         const bf16* s;
         if (q < NAP) {
             d = smem + slot * SLOT + q * 8192 + wave * 1024;        // A2: rows q*64 + wave*8 .. of 128 B; else rows q*128 + wave*16 .. of 64 B
-            s = a_src[q] + kst * ASTEP;
+            if constexpr (LNF) {
+                const int r = q * 64 + wave * 8 + (lane >> 3);
+                int chunk = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+                int rr = r_row[q];
+                asm volatile("" : "+v"(rr), "+v"(chunk));      // formed HERE, every time (one 64-bit multiply-add): hoisted, the eight row products cost 16 registers
+                if (kst >= nk_main) s = p.r_hi + 2 * ((long long)rr * p.ldr + bn * BN) + chunk + (kst - nk_main) * ASTEP;
+                else s = p.a_hi + 2 * ((long long)rr * p.lda) + chunk + kst * ASTEP;
+            } else s = a_src[q] + kst * ASTEP;
         } else {
             const int h = q - NAP;
             d = smem + slot * SLOT + NSPLIT * PLANE + h * 8192 + wave * 1024;
-            s = w_src[h] + kst * WSTEP;
+            if constexpr (LNF) {
+                // tile row (bn * 16 + h * 8 + wave) of the tiled weights is wave-uniform; the lane's part of the address is one register.
+                // Residual stages: the W region is not read (any valid source keeps the piece count uniform)
+                int w_lane = (gr_l << 5) + (gc ^ pp_swz(gr_l)) * 8;
+                asm volatile("" : "+v"(w_lane));      // a seat's bn never changes: without this the W addresses of every piece are hoisted out of the tile loop (10 registers)
+                s = p.w + (((long long)(bn * 16 + h * 8 + wave) * (p.K >> 5) + (kst >= nk_main ? 0 : kst)) << 9) + w_lane;
+            } else s = w_src[h] + kst * WSTEP;
         }
         __builtin_amdgcn_global_load_lds((glb_void*)s, (lds_void*)d, 16, 0, 0);
     };
 
     f32x4 acc[FM][FN];
-    const int ns = p.K / 32;   // >= 2 (K % 64 == 0)
+    const int ns = nk_main + (LNF && ln_decided == 1 ? NRES : 0);      // K stages (>= 2: K % 64 == 0); fused LayerNorm route: + the residual stages
 
     // fragment read offsets inside a slot (lane part; the rest are immediates)
     const int fr = lane & 15, fk = lane >> 4;
@@ -233,9 +277,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     };
 
     // PRE: stage s+2 exists and is issued during this stage; WAITN: outstanding pieces allowed at the phase-4 wait
-    auto stage = [&](auto pre_tag, auto wait_tag, int s, int slot) {
+    // RES (LNF): a residual stage -- W is the identity, so only the wave column that owns the stage's 32 output columns (stage j of the
+    // eight: columns 32 j .. 32 j + 31 = half nh = j & 1 of wave column j >> 1) has anything to add: it runs the two quadrants (A0, B_nh),
+    // (A1, B_nh) = 16 + 16 MFMAs; the other waves only keep the ring and the barriers going
+    auto stage = [&](auto pre_tag, auto wait_tag, auto res_tag, int s, int slot) {
         constexpr bool PRE = decltype(pre_tag)::value;
         constexpr int WAITN = decltype(wait_tag)::value;
+        constexpr bool RES = decltype(res_tag)::value;
+        const int rj = RES ? s - nk_main : 0;
+        const bool own = !RES || wn == (rj >> 1);
+        const bool rh1 = RES && (rj & 1);      // owner of a residual stage: which half of its columns
         const unsigned char* sb = smem + slot * SLOT;
         const int nslot = slot == 0 ? NSLOT - 1 : slot - 1;     // (slot + D) % NSLOT: the slot stage s-1 just left
         constexpr bool DMA = PRE && !(DIAG & 2), RD = !(DIAG & 4);
@@ -245,19 +296,36 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         // (profiles/r03h_pp_phase_stamps.txt), so 32 MFMAs per hand-over instead of 16 is worth ~5 % of a launch
         // (profiles/r03g_two_phases.txt; round 1 had measured "no difference" on an earlier engine).
         // phase A: quadrants (A0, B0), (A0, B1) -- 12 fragment reads at two passes, three LDS-DMA pieces of stage s+D
-        if (RD) { read_b(sb, 0, b0); read_b(sb, 1, b1); read_a(sb, 0); }
+        if constexpr (RES) {
+            // identity fragment j of the stage's 32 columns: lane (fr, fk) holds W[16 j + fr][8 fk + e], e = 0..7 -> 1.0 where 16 j + fr == 8 fk + e
+            if (own) {
+                int e0 = fr - 8 * fk;
+                asm volatile("" : "+v"(e0));      // rebuilt per stage (a dozen VALU ops): hoisted out of the loop the two fragments cost 8 registers the kernel does not have
+#pragma unroll
+                for (int j = 0; j < HN; ++j) {
+                    const int e = 16 * j + e0;
+                    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                    const unsigned one = (e & 1) ? 0x3F800000u : 0x00003F80u;
+                    if (e >= 0 && e < 8) { v[0] = (e >> 1) == 0 ? one : 0u; v[1] = (e >> 1) == 1 ? one : 0u; v[2] = (e >> 1) == 2 ? one : 0u; v[3] = (e >> 1) == 3 ? one : 0u; }
+                    b0[j] = __builtin_bit_cast(bf16x8, v);
+                }
+                if (RD) read_a(sb, 0);
+            }
+        } else if (RD) { read_b(sb, 0, b0); read_b(sb, 1, b1); read_a(sb, 0); }
         if (DMA) {
 #pragma unroll
             for (int q = 0; q < P / 2; ++q) issue(q, s + D, nslot);
         }
         bar();
-        mma(0, 0, b0); mma(0, 1, b1);
+        if constexpr (RES) {
+            if (own) { if (rh1) mma(0, 1, b0); else mma(0, 0, b0); }
+        } else { mma(0, 0, b0); mma(0, 1, b1); }
         bar();
         // phase B: quadrants (A1, B1), (A1, B0) -- 8 reads, the other pieces; my pieces of stage s+1 have landed before the first barrier
         // -> readable next phase.  The reads are RETIRED before that barrier too (lgkmcnt(0)): they are the last reads of this slot, and the
         // first piece that refills it is issued one phase later (phase A of the next stage) -- by then every wave of either row has passed a
         // barrier behind its reads.
-        if (RD) read_a(sb, 1);
+        if (RD && own) read_a(sb, 1);
         if (DMA) {
 #pragma unroll
             for (int q = P / 2; q < P; ++q) issue(q, s + D, nslot);
@@ -265,7 +333,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         if (WAITN >= 0) pp_wait_vmcnt<(WAITN >= 0 && !(DIAG & 2) ? WAITN : 0)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         bar();
-        mma(1, 1, b1); mma(1, 0, b0);
+        if constexpr (RES) {
+            if (own) { if (rh1) mma(1, 1, b0); else mma(1, 0, b0); }
+        } else { mma(1, 1, b1); mma(1, 0, b0); }
         bar();
 #else
         // LDS-DMA pieces of stage s+D: two per phase in phases 1-3 (other placements measured no better, profiles/r01c_gemm_variants.txt)
@@ -324,81 +394,47 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     const unsigned long long tr1 = (DIAG & 32) ? wall_clock64() : 0;
 
     if (DIAG & 4) { read_b(smem, 0, b0); read_b(smem, 1, b1); read_a(smem, 0); }
-    // LNF: the accumulators START at the residual tile (C = resid + A W^T), so the epilogue has no dependent global reads left:
-    // fetched as an 8-row hi burst and an 8-row lo burst per lane while the previous tile's stores drain / the first K stages
-    // are in flight (a residual read inside the epilogue was a serial latency chain of ~50 us per tile, measured).  fp8 operands:
-    // the accumulator is in units of the weight row's power-of-two scale, so the residual goes in divided by it (exact).
-    auto load_resid = [&]() {
-        const int mrow = lane & 15, nq = lane >> 4;
-        const int rbase = bm * BM + wm * TM, cbase = bn * BN + wn * TN + nq * 4;
-        // bias rides along (acc = (resid + bias) / scale): the epilogue then only scales.  Four bursts of 4 rows x 4 fragments
-        // (32 registers of bf16 in flight): with two bursts in flight the kernel spills, and ANY scratch use costs far more than it
-        // saves (ROCr hands out scratch of this size per dispatch: the first persistent round took 450 us instead of 66).  The read is
-        // bandwidth-bound anyway: all CUs reach the tile boundary together and pull 63 MB of residual per round.
-        constexpr int RB = 16 / FN;
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            const bf16* src = pl ? p.r_lo : p.r_hi;
-#pragma unroll
-            for (int ih = 0; ih < FM; ih += RB) {
-                bf16x4 t[RB][FN];
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    int row = rbase + 16 * (ih + i) + mrow;
-                    row = row < Meff ? row : Meff - 1;
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)     // hl32 planes: the wave's 64 columns are two 32-blocks, fragment j in block j / 2
-                        t[i][j] = *reinterpret_cast<const bf16x4*>(src + 2 * ((long long)row * p.ldr + cbase - nq * 4) + 64 * (j >> 1) + 16 * (j & 1) + nq * 4);
-                }
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    f32x4 add = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (pl == 0 && p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + cbase + 16 * j);
-#pragma unroll
-                    for (int i = 0; i < RB; ++i)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = (float)t[i][j][e] + add[e];
-                            acc[ih + i][j][e] = pl ? acc[ih + i][j][e] + v : v;
-                        }
-                }
-                asm volatile("" ::: "memory");
-            }
-        }
-    };
-    if constexpr (LNF) {
-        if (ln_decided == 1) load_resid();
-    }
     for (;;) {
 #ifdef MMS_LAB
         const unsigned long long tr_loop = (LNF && p.ln_dbg) ? wall_clock64() : 0;
 #else
         const unsigned long long tr_loop = 0; (void)tr_loop;
 #endif
-        if (!LNF || ln_decided != 1) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
         int slot = 0, s = 0;
-        for (; s + D < ns; ++s) {
-            stage(std::true_type{}, std::integral_constant<int, (D - 1) * P>{}, s, slot);
-            slot = slot == NSLOT - 1 ? 0 : slot + 1;
-        }
+        auto run_stages = [&](auto res_tag, int s_end) {      // stages [s, s_end) of this kind, every one followed by at least D more
+            for (; s < s_end; ++s) {
+                stage(std::true_type{}, std::integral_constant<int, (D - 1) * P>{}, res_tag, s, slot);
+                slot = slot == NSLOT - 1 ? 0 : slot + 1;
+            }
+        };
         // tail: R stages still to come after this one -> R-1 of them may stay in flight; the last stage waits for nothing
-        auto tail = [&](auto r_tag) {
+        auto tail = [&](auto r_tag, auto res_tag) {
             constexpr int R = decltype(r_tag)::value;
             if (ns - 1 - s == R) {
-                stage(std::false_type{}, std::integral_constant<int, R >= 1 ? (R - 1) * P : -1>{}, s, slot);
+                stage(std::false_type{}, std::integral_constant<int, R >= 1 ? (R - 1) * P : -1>{}, res_tag, s, slot);
                 slot = slot == NSLOT - 1 ? 0 : slot + 1;
                 ++s;
             }
         };
-        if constexpr (D >= 4) tail(std::integral_constant<int, 3>{});
-        if constexpr (D >= 3) tail(std::integral_constant<int, 2>{});
-        tail(std::integral_constant<int, 1>{});
-        tail(std::integral_constant<int, 0>{});
+        auto tails = [&](auto res_tag) {
+            if constexpr (D >= 4) tail(std::integral_constant<int, 3>{}, res_tag);
+            if constexpr (D >= 3) tail(std::integral_constant<int, 2>{}, res_tag);
+            tail(std::integral_constant<int, 1>{}, res_tag);
+            tail(std::integral_constant<int, 0>{}, res_tag);
+        };
+        if (LNF && ns > nk_main) {      // the product's stages, then the residual stages (NRES > D: the tail lies inside them)
+            static_assert(!LNF || NRES > D, "the K loop's tail must lie inside the residual stages");
+            run_stages(std::false_type{}, nk_main);
+            run_stages(std::integral_constant<bool, LNF>{}, ns - D);
+            tails(std::integral_constant<bool, LNF>{});
+        } else {
+            run_stages(std::false_type{}, ns - D);
+            tails(std::false_type{});
+        }
         if (wave < NW / 2) pp_barrier();     // re-align the two halves: nobody reads the ring any more
         const unsigned long long tr2 = (DIAG & 32) ? wall_clock64() : 0;
 
@@ -415,9 +451,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         // their round trip -- the whole prologue of a fresh workgroup -- runs under the store drain; one full `vmcnt(0)` then covers
         // both, and neither a workgroup retirement nor a dispatch (~4.6 us) sits between two tiles.
         const int row0 = bm * BM + wm * TM, col0 = bn * BN + wn * TN;
-        const int ebm = bm, ebn = bn, evb = vb;      // this tile (setup() below moves bm / bn / vb on to the next one)
-        int nvb = vb + (int)gridDim.x;
-        while (nvb < nblk && !valid(nvb)) nvb += gridDim.x;
+        const int ebm = bm, ebn = bn, evb = LNF ? bm * 3 + bn : vb;      // this tile (setup() below moves bm / bn / vb on to the next one)
+        int nvb = vb + vstep;
+        while (nvb < nblk && !valid(nvb)) nvb += vstep;
         const bool more = PERSIST && nvb < nblk;
         if (more) {
             vb = nvb;
@@ -443,7 +479,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
             t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = wall_clock64(); t[4] = ((unsigned long long)bm << 32) | (unsigned)bn;
         }
         if (!more) break;
-        if constexpr (LNF) { if (ln_decided == 1) load_resid(); }
         pp_wait_vmcnt<0>();
         pp_barrier();
         if (wave >= NW / 2) pp_barrier();     // stagger again
@@ -451,17 +486,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
 }
 
 static int pp_cu_count() {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
-                   ? prop.multiProcessorCount / 8 * 8 : 8;
 #ifdef MMS_LAB
-        if (const char* e = getenv("MMS_PP_GRID")) n_cu = atoi(e) / 8 * 8;   // lab: persistent GEMMs on part of the chip (tools/dual_stream.py)
+    static const int lab_grid = getenv("MMS_PP_GRID") ? atoi(getenv("MMS_PP_GRID")) / 8 * 8 : 0;   // lab: persistent GEMMs on part of the chip (tools/dual_stream.py)
+    if (lab_grid) return lab_grid;
 #endif
-    }
-    return n_cu;
+    return device_cu_count();
 }
 
 template <int NSPLIT, int DIAG, bool PERSIST = false>
@@ -481,14 +510,9 @@ static void launch_pp_ns(const GemmParams& p, hipStream_t st) {
 bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st) {
     if (p.M <= 0) return true;
     if (p.N != 768 || p.K % 64 || !p.ln_gamma || !p.ln_beta || !p.ln_stats || !p.ln_ctl || !p.r_hi || p.act != ACT_NONE) return false;
-    const int nbm = (p.M + 255) / 256;
-    const int nvirt = 24 * ((nbm >> 3) + ((nbm & 7) ? 1 : 0));
-    // workgroups per XCD: a multiple of 3, so that the three tiles of a row panel always fall into the SAME persistent round (with
-    // 32 per XCD every eleventh panel straddled two rounds: two workgroups idled a whole tile time waiting for the third tile, and
-    // the delay rippled through every later round -- measured -8 % end to end; 30 of 32 CUs per XCD costs 6 % of these launches)
-    const int per_xcd = (pp_cu_count() / 8) / 3 * 3;
-    const int full = per_xcd > 0 ? 8 * per_xcd : 24;
-    const dim3 grid(nvirt > full ? full : nvirt), block(512);
+    if (p.a_index || p.amap.grp || p.r_index || p.rmap.grp || p.cmap.grp) return false;     // identity row maps only (the kernel forms A / residual addresses from the row number)
+    // one workgroup per CU, every one a seat of a panel triple (gemm_pp_kernel); all of them check in, seats without work leave at once
+    const dim3 grid(pp_cu_count()), block(512);
     if (nsplit != 2) return false;      // two-pass bf16 planes only
     hipLaunchKernelGGL((gemm_pp_kernel<2, ACT_NONE, 0, true, true>), grid, block, 0, st, p);
     return true;

@@ -71,20 +71,30 @@ __device__ __forceinline__ void pp_epilogue_plain_f32(const GemmParams& p, f32x4
 template <int FM, int FN>
 __device__ __forceinline__ void pp_epilogue_ln(const GemmParams& p, f32x4 (&acc)[FM][FN], int bm, int bn, int wm, int wn, int lane, int tid,
                                                int Meff, unsigned char* lds, int dbg_tile = 0) {
+    // every address of this epilogue is re-derived per tile: hoisted out of the persistent loop they sit in registers (or scratch: the kernel
+    // has none to spare) across the whole K loop
+    asm volatile("" : "+v"(lane), "+v"(tid));
     LN_STAMP(1);
     const int mrow = lane & 15, nq = lane >> 4;
     const int row0 = bm * 256 + wm * 128, col = bn * 256 + wn * 64 + nq * 4;
-    // ---- v = acc (* weight scale): bias and residual are already in the accumulator (gemm_pp.hip load_resid) ----
+    // ---- v = acc + bias: the residual is already in the accumulator (the residual stages of gemm_pp.hip's K loop) ----
     // row sums go to LDS row by row (no 16-register array of partial sums kept across the loop)
     float2* red = reinterpret_cast<float2*>(lds);                 // [4][256]
     float2* part = reinterpret_cast<float2*>(lds + 8192);         // [512]: the two partner tiles' sums per row
     float2* stat = reinterpret_cast<float2*>(lds + 8192 + 4096);  // [256]: mean, rstd
+    if (p.bias) {      // column fragment outermost: four bias registers live at a time
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col + 16 * j);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) acc[i][j] += b4;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         float ss = 0.f, qq = 0.f;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            if (p.col_scale) acc[i][j] *= *reinterpret_cast<const f32x4*>(p.col_scale + col + 16 * j);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { ss += acc[i][j][e]; qq += acc[i][j][e] * acc[i][j][e]; }
         }

@@ -224,13 +224,7 @@ __global__ __launch_bounds__(512) void gemm_ppw_kernel(const GemmParams p) {
 bool launch_gemm_ppw(const GemmParams& p, hipStream_t st) {
     if (p.M <= 0) return true;
     if (p.N % 128 || p.K % 64 || !p.w_lo) return false;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
-                   ? prop.multiProcessorCount / 8 * 8 : 8;
-    }
+    const int n_cu = device_cu_count();
     const int nblk = ((p.M + 255) / 256) * (p.N / 128);
     const dim3 grid(nblk > n_cu ? n_cu : nblk), block(512);
     switch (p.act) {

@@ -47,21 +47,27 @@ struct GemmParams {
     float* ln_stats;             // [rows][3 tiles][2] 8-byte {value, tag} granules
     unsigned ln_tag;             // unique per launch
     int* ln_ctl;                 // [0] workgroups checked in, [1] 0 undecided / 1 fused / 2 plain -- zeroed before the launch
+    int variant;                 // 0: per-shape choice (gemm_dispatch.hip); tests name ONE tile engine per call (mms_dbg_gemm): 1, 4, 16 register-staged
+                                 // tiles, 20 / 26 ping-pong (one tile per workgroup / persistent), 27 three-pass ping-pong; lab build: 3, 28
     unsigned long long* ln_dbg;  // lab build only: per-tile phase stamps [virtual tile][6] of wall_clock64 (tools/ln_trace.py); nullptr otherwise
 };
+// CUs of the CURRENT device rounded down to a multiple of 8 (one per XCD-slot), cached per device ordinal; thread-safe (gemm_dispatch.hip)
+int device_cu_count();
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
-bool launch_gemm_dw(const GemmParams& p, int nsplit, hipStream_t st);                                                       // gemm_dw.hip (variant 28: 128x256 tiles, two 4-wave workgroups per CU)
+#ifdef MMS_LAB
+bool launch_gemm_dw(const GemmParams& p, int nsplit, hipStream_t st);                                                       // lab: gemm_dw.hip (variant 28: 128x256 tiles, two 4-wave workgroups per CU)
+#endif
 bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist = false);                     // gemm_pp.hip (variant 20: 256x256 ping-pong phases)
 bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm_pp.hip + gemm_pp_ln.h: N = 768 with the fused residual + LayerNorm epilogue (nsplit 2)
 #ifdef MMS_LAB
 bool launch_gemm_mx_hi_only(const GemmParams& p, hipStream_t st);                        // lab: timing reference, the high pass alone
 #endif
 bool launch_gemm_mx8(const GemmParams& p, hipStream_t st);                               // gemm_mx.hip: precision mode 4 on the MX-scaled fp8 instruction
-bool launch_gemm_mx(const GemmParams& p, hipStream_t st);                                // gemm_mx.hip: precision mode 5, fp16 high pass + MX-scaled e4m3 low pass
+#ifdef MMS_LAB
+bool launch_gemm_mx(const GemmParams& p, hipStream_t st);                                // lab: gemm_mx.hip: fp16 high pass + MX-scaled e4m3 low pass ("precision 5", measured and shelved)
+#endif
 bool launch_gemm_ppw(const GemmParams& p, hipStream_t st);                               // gemm_ppw.hip: precision mode 3 (A and W split), 256x128 ping-pong phases
-void set_gemm_variant(int v);   // test hook, see gemm_dispatch.hip
-int get_gemm_variant();
 
 // ---------------------------------------------------------------------------------------------
 // Attention for one (pair, head) per wavefront, S <= 48               (attn.hip)

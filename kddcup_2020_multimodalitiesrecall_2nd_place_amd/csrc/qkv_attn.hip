@@ -638,13 +638,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
 bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st) {
     if (p.M <= 0) return true;
     if (p.K % 64 || p.K < 128 || p.S > 48 || p.S <= 0 || !p.sub || !p.n_sub) return false;
-    int dev = 0;
-    static int n_cu = 0;
-    if (!n_cu) {
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
-                   ? prop.multiProcessorCount / 8 * 8 : 8;
-    }
+    const int n_cu = device_cu_count();
     // an upper bound of the tile count (the live count is on the device): every sub-tile but the last of a stream holds > 128 - S rows
     const long long max_sub = p.M / ((p.w_lo ? QA_SUB3 : QA_SUB) - p.S + 1) + p.M / QA_SEG + 3, max_blk = (max_sub + 1) / 2 * MMS_HEADS;
     const dim3 grid((unsigned)(max_blk < n_cu ? max_blk : n_cu)), block(512);

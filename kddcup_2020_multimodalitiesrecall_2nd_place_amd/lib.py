@@ -58,12 +58,13 @@ class EnsembleBatch(C.Structure):
                 ("lx_input_ids", C.c_void_p), ("lx_input_mask", C.c_void_p)]
 
 
-ABI_VERSION = 4     # include/mmscore.h MMS_ABI_VERSION
+ABI_VERSION = 5     # include/mmscore.h MMS_ABI_VERSION
 
 EXPORTS = ("mms_version", "mms_global_error", "mms_create", "mms_destroy", "mms_last_error", "mms_load_weight",
-           "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_score_ensemble", "mms_gemm_timing",
-           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_mx", "mms_dbg_gemm_ln", "mms_dbg_attention", "mms_dbg_layernorm", "mms_set_gemm_variant",
+           "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_score_ensemble", "mms_gemm_timing", "mms_gemm_timing_class",
+           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_ln", "mms_dbg_attention", "mms_dbg_layernorm",
            "mms_dbg_gemm_bench", "mms_dbg_counter", "mms_fused_timing")
+LAB_EXPORTS = ("mms_dbg_gemm_mx", "mms_lab_ln_trace")      # libmmscore_lab.so only
 
 _lib = None
 
@@ -98,14 +99,15 @@ def load(path=None):
     lib.mms_score_lxmert.argtypes = [vp, C.POINTER(LxmertBatch), vp, vp, vp]
     lib.mms_score_ensemble.argtypes = [vp, vp, vp, C.POINTER(EnsembleBatch), C.POINTER(C.c_float), vp, vp, vp]
     lib.mms_dbg_gemm_f8.argtypes = [vp, i64, i64, vp, i64, vp, i32, i32, vp, vp]
-    lib.mms_dbg_gemm_mx.argtypes = [vp, i64, i64, vp, i64, vp, i32, i32, vp, vp]
+    if hasattr(lib, "mms_dbg_gemm_mx"):      # lab build
+        lib.mms_dbg_gemm_mx.argtypes = [vp, i64, i64, vp, i64, vp, i32, i32, vp, vp]
     lib.mms_dbg_gemm_ln.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, i32, vp, C.POINTER(i32), vp]
     lib.mms_gemm_timing.argtypes = [vp, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
+    lib.mms_gemm_timing_class.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.mms_debug_read_x.argtypes = [vp, vp, i64, vp]
-    lib.mms_dbg_gemm.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, i32, i32, i32, vp, vp]
+    lib.mms_dbg_gemm.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.mms_dbg_attention.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     lib.mms_dbg_layernorm.argtypes = [vp, vp, vp, i64, vp, vp]
-    lib.mms_set_gemm_variant.argtypes = [i32]
     lib.mms_dbg_counter.argtypes = [vp, i32]
     lib.mms_fused_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.mms_dbg_counter.restype = i64
@@ -118,7 +120,7 @@ class Handle:
     """Owns one ``mms_handle`` (one model on one GPU)."""
 
     def __init__(self, cfg, precision: int = 2, device: int = 0, chunk_pairs: int = 0, stop_after: int = -1,
-                 pack_tokens: bool = True, fuse_layernorm: bool = False, fuse_attention: int = 0):
+                 pack_tokens: bool = True, fuse_layernorm=0, fuse_attention: int = 0):
         self.lib = load()
         self.cfg = cfg
         c = Config()
@@ -130,7 +132,7 @@ class Handle:
         c.vocab, c.inter, c.max_pos, c.type_vocab, c.text_len = cfg.vocab, cfg.inter, cfg.max_pos, cfg.type_vocab, cfg.text_len
         c.precision, c.chunk_pairs, c.stop_after, c.device = precision, chunk_pairs, stop_after, device
         c.pack_tokens = int(bool(pack_tokens))
-        c.fuse_layernorm = int(bool(fuse_layernorm))
+        c.fuse_layernorm = 3 if fuse_layernorm is True else int(fuse_layernorm)      # mask: 1 attention-output, 2 FFN-down (True: both)
         c.fuse_attention = int(fuse_attention)
         self._h = C.c_void_p()
         rc = self.lib.mms_create(C.byref(c), C.byref(self._h))
@@ -159,6 +161,12 @@ class Handle:
             self._check(self.lib.mms_gemm_timing(self._h, int(enable), int(reset), C.byref(ms), C.byref(n), C.byref(fl)), "mms_gemm_timing")
         else:
             self._check(self.lib.mms_gemm_timing(self._h, int(enable), int(reset), None, None, None), "mms_gemm_timing")
+        return ms.value, n.value, fl.value
+
+    def gemm_timing_class(self, cls: int):
+        """(ms, launches, flops) of the timed GEMM launches with the plain (0) / the fused LayerNorm (1) epilogue."""
+        ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+        self._check(self.lib.mms_gemm_timing_class(self._h, cls, C.byref(ms), C.byref(n), C.byref(fl)), "mms_gemm_timing_class")
         return ms.value, n.value, fl.value
 
     def fused_timing(self):

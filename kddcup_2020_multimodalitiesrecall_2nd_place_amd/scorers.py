@@ -30,7 +30,7 @@ def _is_np(x):
 
 class _Base:
     def __init__(self, cfg, weights: dict, precision="auto", device: int = 0, chunk_pairs: int = 0,
-                 stop_after: int = -1, dedup_labels: bool = True, pack_tokens: bool = True, fuse_layernorm: bool = False, fuse_attention="auto"):
+                 stop_after: int = -1, dedup_labels: bool = True, pack_tokens: bool = True, fuse_layernorm="auto", fuse_attention="auto"):
         """precision: 1 / 2 / 3 / 4 (4 = fp8 weights and activations on the big encoder GEMMs, outside the
         1e-3 contract) or "auto" = ``weights.auto_precision``: 2 for bf16-representable matrices, 3 for a real fp32 checkpoint."""
         if not torch.cuda.is_available():
@@ -39,13 +39,22 @@ class _Base:
             from .weights import auto_precision
             precision = auto_precision(weights)
         if fuse_attention == "auto":
-            # mms_config.fuse_attention = 1 (QKV projection + self-attention in one kernel, bit-identical results) wherever it is faster:
-            # zk / lds +3 % in precision modes 2 and 3, lxmert -0.4 % (profiles/r03q_*, r04a_*); 2 (split-bf16 attention MFMAs, another +1 .. 2 %) is opt-in
-            fuse_attention = 0 if cfg.name == "lxmert" else 1
+            # mms_config.fuse_attention = 2 (QKV projection + self-attention in one kernel, Q K^T / P V on split-bf16 MFMAs: the configuration
+            # bench.py measures; <= 4e-5 from the exact-fp32 attention at full depth, held to the oracle by tests/test_parity_gpu.py) wherever
+            # it is faster: zk / lds +5 % in precision modes 2 and 3, lxmert +-0.5 % (profiles/r03q_*, r04a_*) -> the two-kernel route there.
+            # 1 = the same kernel with exact-fp32 attention MFMAs (bit-identical to the two-kernel route), opt-in.
+            fuse_attention = 0 if cfg.name == "lxmert" else 2
+        if fuse_layernorm == "auto":
+            # mms_config.fuse_layernorm mask 3: bias + residual + LayerNorm in the epilogue of the attention-output and FFN-down projections of
+            # the big launches (precision mode 2; gemm_pp_ln.h) -- no LayerNorm launches, no fp32 round trip of the pre-LayerNorm tensor;
+            # +1.5 % on the bench batch (profiles/r04d_*).  Other precision modes ignore it.
+            fuse_layernorm = 3
+        self.fuse_layernorm = 3 if fuse_layernorm is True else int(fuse_layernorm)
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         self.dedup_labels = dedup_labels
         self.precision = precision
+        self.fuse_attention = int(fuse_attention)      # what "auto" resolved to (bench.py reports it)
         self.handle = _lib.Handle(cfg, precision=precision, device=device, chunk_pairs=chunk_pairs, stop_after=stop_after,
                                   pack_tokens=pack_tokens, fuse_layernorm=fuse_layernorm, fuse_attention=fuse_attention)
         self.handle.load_weights(weights)

@@ -58,10 +58,11 @@ def make_class_table(n_classes: int = 33, vocab: int = 21128, seed: int = SEED) 
 
 def make_pairs(n_queries: int, cands, *, seed: int = SEED, vocab: int = 21128, n_classes: int = 33,
                max_query_body: int = 18, all_boxes: bool = False, tag: str = "", with_feats: bool = True,
-               query_offset: int = 0) -> PairSet:
+               query_offset: int = 0, box_mu: float = 1.1) -> PairSet:
     """``cands``: int (fixed candidates/query) or (lo, hi) for ragged candidate sets.
     ``with_feats=False`` leaves ``feats`` None (bench generates the 2.4 GB feature block on the GPU).
-    ``query_offset`` shifts query ids (per-rank shards of one logical job)."""
+    ``query_offset`` shifts query ids (per-rank shards of one logical job).  ``box_mu``: location of the lognormal box count
+    (1.1: the documented workload; bench.py sweeps it to show how the rate depends on the live-token fraction)."""
     t = "pairs%s/" % tag
     if isinstance(cands, int):
         per_q = np.full(n_queries, cands, dtype=np.int64)
@@ -83,7 +84,7 @@ def make_pairs(n_queries: int, cands, *, seed: int = SEED, vocab: int = 21128, n
         num_boxes = np.full(B, N_BOX, dtype=np.int32)
     else:
         z = normal(t + "nbox", (B,), seed).astype(np.float64)
-        num_boxes = np.clip(np.rint(np.exp(1.1 + 0.6 * z)), 1, N_BOX).astype(np.int32)  # mean ~3.8
+        num_boxes = np.clip(np.rint(np.exp(box_mu + 0.6 * z)), 1, N_BOX).astype(np.int32)  # box_mu 1.1: mean ~3.5 .. 3.8
     live = np.arange(N_BOX)[None, :] < num_boxes[:, None]
 
     feats = None

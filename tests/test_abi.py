@@ -3,6 +3,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -35,6 +36,25 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(so, n), n
     assert sorted(lib.EXPORTS) == _declared()
     assert so.mms_version() == lib.ABI_VERSION == _header_abi_version()
+
+
+def test_product_library_carries_no_lab_engines_or_global_switches():
+    """the shelved engines and the process-global GEMM-variant switch live in libmmscore_lab.so only."""
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for n in lib.LAB_EXPORTS + ("mms_set_gemm_variant",):
+        assert not hasattr(so, n), n
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gemm_dw" not in syms and "launch_gemm_mxRK" not in syms and "set_gemm_variant" not in syms
+
+
+def test_create_rejects_out_of_range_route_options():
+    l = lib.load()
+    for field, bad in (("fuse_attention", 3), ("fuse_attention", -1), ("fuse_layernorm", 4), ("fuse_layernorm", -2)):
+        c = lib.Config()
+        c.model, c.layers, c.vocab, c.inter, c.max_pos, c.type_vocab, c.text_len, c.precision = 0, 1, 100, 128, 64, 2, 20, 2
+        setattr(c, field, bad)
+        h = ctypes.c_void_p()
+        assert l.mms_create(ctypes.byref(c), ctypes.byref(h)) == 1 and field.encode() in l.mms_global_error(), field
 
 
 def test_create_rejects_bad_config_without_touching_a_device():

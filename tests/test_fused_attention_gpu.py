@@ -100,8 +100,8 @@ def test_fused_attention_ragged_extremes():
         assert np.array_equal(l0, l1), (chunk, np.abs(l0 - l1).max())
 
 
-def test_default_is_the_bit_identical_fused_route_except_for_lxmert():
-    """scorers' fuse_attention="auto": 1 for zk / lds (faster, same bits), 0 for lxmert (not faster there)."""
+def test_default_is_the_fused_route_except_for_lxmert():
+    """scorers' fuse_attention="auto": 2 for zk / lds (the configuration bench.py measures), 0 for lxmert (not faster there)."""
     for name, want in (("zk", True), ("lds", True), ("lxmert", False)):
         cfg = CFGS[name]()
         w = weights.make_weights(cfg)

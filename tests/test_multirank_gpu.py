@@ -65,6 +65,23 @@ def test_bench_gpus8_reports_weak_and_strong_in_one_line():
     st = d["strong"]
     assert st["scaling"] == "strong" and st["pairs_total"] == 24 * 10 and sum(st["pairs_per_gpu"]) == 240 and len(st["pairs_per_gpu"]) == 8
     assert st["value"] > 0 and abs(st["value"] - 240 * d["steps"] / (st["ms_per_step"] * 1e-3 * d["steps"])) / st["value"] < 1e-3
+    # the line says where its ranks ran: 8 entries, here all on device 0 (test mode, declared as such)
+    rk = d["ranks"]
+    assert [r["rank"] for r in rk] == list(range(8)) and all(r["hip_device"] == 0 and r["pci_bus_id"] and r["name"] for r in rk)
+    assert len({r["pid"] for r in rk}) == 8
+    di = d["distributed"]
+    assert di["backend"] == "gloo" and di["shared_device_test_mode"] is True and di["distinct_devices"] == 1
+
+
+def test_bench_refuses_nccl_ranks_on_one_device():
+    """Two RCCL ranks that resolve to ONE device (a launcher that did not give each rank its own GPU) must fail loudly, not print a
+    scaling number.  Here: 2 self-spawned ranks whose HIP_VISIBLE_DEVICES shows both the same single GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MMS_BENCH_SHARE_GPU")}
+    env.update(MMS_BENCH_BACKEND="gloo", MMS_BENCH_FORCE_LOCAL0="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--queries", "4",
+                          "--cands", "4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode != 0 and "distinct devices" in out.stderr, (out.returncode, out.stderr[-1500:])
+    assert not [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
 
 
 def test_bench_gpus2_spawns_two_ranks_itself():

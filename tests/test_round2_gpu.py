@@ -438,7 +438,7 @@ def test_fused_layernorm_forward_matches_the_two_kernel_route(name, precision):
     feats *= (torch.arange(10, device=dev)[None, :] < torch.as_tensor(ps.num_boxes, device=dev)[:, None])[:, :, None]
     ps.feats = feats
     b = synth.batch_for(cfg, ps)
-    s0 = scorers.make_scorer(cfg, w, precision=precision)
+    s0 = scorers.make_scorer(cfg, w, precision=precision, fuse_layernorm=0)
     s1 = scorers.make_scorer(cfg, w, precision=precision, fuse_layernorm=True)
     l0 = scorers.score_batch(s0, b)[0].cpu().numpy()
     l1 = scorers.score_batch(s1, b)[0].cpu().numpy()

@@ -23,21 +23,24 @@ def _hip_logits(cfg, w, b, **kw):
 
 @pytest.mark.parametrize("name", ["zk", "lxmert", "lds"])
 @pytest.mark.parametrize("precision", [2, 3])
-@pytest.mark.parametrize("pack", [True, False])
-def test_large_launch_equals_small_chunks(name, precision, pack):
+@pytest.mark.parametrize("pack,exact", [(True, False), (False, False), (True, True)])
+def test_large_launch_equals_small_chunks(name, precision, pack, exact):
     """A launch of >= 16384 token rows runs the persistent ping-pong engines (gemm_pp.hip, and gemm_ppw.hip in mode 3, whose
     32-column wave tiles store the head-major Q/K/V blocks from two waves per head), a 48-pair chunk the register-staged tiles.
     Same pairs, same weights: the two routes may differ by fp32 summation order only.  (the mode-3 big-M route had
-    never been compared with anything.)"""
+    never been compared with anything.)  `exact`: the big launch on the exact-fp32 attention MFMAs and the two-kernel LayerNorm -- then the
+    two sides differ by summation order alone (1e-4); the DEFAULT big-launch route (round 4: split-bf16 attention MFMAs, LayerNorm with a
+    one-pass variance in the GEMM epilogue) adds its own 2^-16-class terms, bounded at 5e-4 here and against the oracle below."""
     cfg = small_cfg(name)
     w = weights.make_weights(cfg, bf16_matrices=(precision != 3))
     ps = synth.make_pairs(48, (24, 30), vocab=cfg.vocab, tag="/big%d" % precision)     # ~1080 pairs: >= 16384 rows even when packed
     b = synth.batch_for(cfg, ps)
-    big, _ = _hip_logits(cfg, w, b, precision=precision, pack_tokens=pack)
-    small, _ = _hip_logits(cfg, w, b, precision=precision, pack_tokens=pack, chunk_pairs=48)
+    routes = dict(fuse_attention=0 if name == "lxmert" else 1, fuse_layernorm=0) if exact else {}
+    big, _ = _hip_logits(cfg, w, b, precision=precision, pack_tokens=pack, **routes)
+    small, _ = _hip_logits(cfg, w, b, precision=precision, pack_tokens=pack, chunk_pairs=48, **routes)
     e = vecrel(big, small)
     print("\n[%s p%d pack=%d] %d pairs: one launch vs 48-pair chunks, vec-rel max %.2e" % (name, precision, pack, len(big), e.max()))
-    assert e.max() < (3e-4 if name == "lxmert" else 1e-4), e.max()       # lxmert amplifies fp32 round-off most (DESIGN.md section 4)
+    assert e.max() < (5e-4 if not exact else 3e-4 if name == "lxmert" else 1e-4), e.max()       # lxmert amplifies fp32 round-off most (DESIGN.md section 4)
     # and a sample of them against the fp64 oracle
     sel = np.arange(0, len(big), max(1, len(big) // 24))[:24]
     sub = {k: (v[sel] if hasattr(v, "shape") and v.shape[:1] == (len(big),) else v) for k, v in b.items()}
@@ -119,13 +122,14 @@ def test_fp8_fused_ensemble_full_model_size():
     assert np.isfinite(merged).all() and d.max() < 0.15 and np.corrcoef(merged, ref)[0, 1] > 0.8
 
 
-@pytest.mark.parametrize("name,n_queries", [("zk", 248), ("lds", 124), ("lxmert", 48)])
+@pytest.mark.parametrize("name,n_queries", [("zk", 96), ("lds", 56), ("lxmert", 24)])
 def test_full_depth_ndcg5_on_a_valid_like_set(name, n_queries):
     """north_star's "nDCG@5 on valid within 1e-3" at the depth the models ship with (12 / 9-5-5 layers) on a
     valid-like set: queries x 9..30 candidates with ground-truth relevance (evaluation.py:4-38), the zk head fed those labels
     (load_data_v4.py:259-263).  Checker = the oracle's fp32 CPU port (torch restatement for zk / lds, numpy fp32 for lxmert; the fp64
     numpy oracle would take an hour; they agree to 1e-5 on the CPU suite).  valid.tsv has 496 queries; the CPU port manages ~55 (zk),
-    ~40 (lds), ~12 (lxmert) pairs/s on the GPU box's host cores, so the sets are a half / a quarter / a tenth of that size."""
+    ~40 (lds), ~12 (lxmert) pairs/s on the GPU box's host cores, so the sets are a fifth / a ninth / a twentieth of that size (round 4: the
+    CPU port's time is what this test costs -- 215 s of an 800 s suite with 248 / 124 / 48 queries; the driver stops the suite at 1200 s)."""
     from kddcup_2020_multimodalitiesrecall_2nd_place_amd import ndcg
     from oracle import torch_models
     cfg = {"zk": ZkConfig(), "lds": LdsConfig(), "lxmert": LxmertConfig()}[name]
@@ -160,42 +164,3 @@ def test_full_depth_ndcg5_on_a_valid_like_set(name, n_queries):
         total += 1
         agree += set(pid[order[:5]]) == set(pid[np.argsort(-g, kind="stable")[:5]])
     assert agree == total, (agree, total)
-
-
-MX_CASES = [(300, 768, 768, 0, False), (16640 + 17, 768, 2304, 0, False), (2048, 3072, 768, 0, False), (4500, 768, 3072, 2, True),
-            (1000, 1024, 512, 3, True), (256, 256, 256, 0, False)]
-
-
-@pytest.mark.parametrize("case", MX_CASES)
-def test_gemm_mx_matches_numpy_on_its_operands_and_the_true_product(case):
-    """gemm_mx.hip (precision mode 5: fp16 high pass + MX-scaled e4m3 low pass with per-channel hardware scales) against (i) numpy on
-    exactly the operands it multiplies (oracle/fp8.py gemm_mx_ref) -- agreement to fp32 accumulation noise -- and (ii) the fp64 product
-    of the unsplit operands, where it must sit in the 2^-15 class (a single fp16 pass alone: 2^-11)."""
-    from helpers import act_ref
-    from kddcup_2020_multimodalitiesrecall_2nd_place_amd import lib
-    from oracle import fp8 as F8
-    M, K, N, act, out_h3 = case
-    l = lib.load()
-    a = weights.normal("mx/a/%d/%d" % (M, K), (M, K), 1)
-    a[0, :6] = [70000.0, -3e-6, 100.0, 0.0, 2 ** -20, -65504.0]                 # fp16 overflow / underflow corners in one row
-    a[0, :6] = np.clip(a[0, :6], -60000, 60000)
-    w = weights.round_to_bf16(weights.normal("mx/w/%d/%d" % (N, K), (N, K), 1, 1.0 / np.sqrt(K)))
-    w[3] *= 2.0 ** -9                                                            # a row with a much smaller scale
-    w[5, ::7] = 0.0
-    bias = weights.normal("mx/b/%d" % N, (N,), 1, 0.1)
-    out = torch.empty((M, N), device="cuda", dtype=torch.float32)
-    da, dw, db = (torch.as_tensor(np.ascontiguousarray(x)).cuda() for x in (a, w, bias))
-    rc = l.mms_dbg_gemm_mx(da.data_ptr(), M, K, dw.data_ptr(), N, db.data_ptr(), act, int(out_h3), out.data_ptr(), None)
-    assert rc == 0, l.mms_global_error()
-    got = out.cpu().numpy().astype(np.float64)
-    pre = F8.gemm_mx_ref(a, w) + bias
-    ref = act_ref(pre, act)
-    true = act_ref(a.astype(np.float64) @ w.astype(np.float64).T + bias, act)
-    hi_only = act_ref(a.astype(np.float16).astype(np.float64) @ w.astype(np.float64).T + bias, act)
-    scale = np.abs(true[1:]).max()
-    e_ops, e_true, e_hi = (np.abs(got - ref)[1:].max() / scale, np.abs(got - true)[1:].max() / scale, np.abs(hi_only - true)[1:].max() / scale)
-    print("\n[gemm_mx %s] vs its own operands %.2e   vs the true product %.2e   (fp16 pass alone %.2e)" % (case, e_ops, e_true, e_hi))
-    tol_ops = 3e-5 if out_h3 else 2e-5           # out_h3: plus the h3 rounding of the output itself (2^-15 relative)
-    assert e_ops < tol_ops, e_ops
-    assert e_true < 6e-5 and e_true < e_hi / 3
-    assert np.isfinite(got[0]).all()

@@ -110,3 +110,58 @@ def test_model_weights_through_a_checkpoint_bundle(name, tmp_path):
         with pytest.raises(KeyError):
             T.write_bundle(prefix, {k: v for k, v in ck.items() if not k.endswith("ExponentialMovingAverage")})
             weights.from_tf_checkpoint(cfg, prefix, ema=True)
+
+
+def test_reads_a_bundle_assembled_independently_of_the_package_writer(golden_dir, tmp_path):
+    """tests/golden/tf_bundle/*: built byte by byte by tests/golden/make_tf_bundle_golden.py, which shares no code with tf_checkpoint.py
+    (own CRC, varints, protobuf and table builder, following table_format.txt / tensor_bundle.proto): two shards, several data blocks,
+    prefix-compressed keys across restart points, shortened separator keys in the index block, a header with a version sub-message, a
+    rank-0 variable, every supported dtype, an EMA shadow name."""
+    import json
+    d = os.path.join(golden_dir, "tf_bundle")
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    prefix = os.path.join(d, exp["prefix"])
+    # structure of the fixture itself: more than one data block behind the index block, shared prefixes in use
+    buf = memoryview(open(prefix + ".index", "rb").read())
+    pos = 0
+    _mo, pos = T._get_varint(buf[-48:], pos); _ms, pos = T._get_varint(buf[-48:], pos)
+    io, pos = T._get_varint(buf[-48:], pos); isz, pos = T._get_varint(buf[-48:], pos)
+    index_entries = list(T._block_entries(T._read_block(buf, io, isz)))
+    assert len(index_entries) >= 4
+    assert any(k.decode() not in exp["variables"] for k, _ in index_entries)             # shortened separators, not only keys that exist
+    r = T.BundleReader(prefix, verify_tensors=True)
+    assert r.num_shards == 2 and sorted(r.get_variable_to_shape_map()) == sorted(exp["variables"])
+
+    def values(name, shape, dtype):        # the generator's closed formula, restated
+        n = int(np.prod(shape)) if shape else 1
+        x = (np.arange(n, dtype=np.float64) * 0.37 + sum(name.encode()) % 97) % 11.0 - 5.0
+        if dtype in ("int32", "int64"):
+            return np.round(x * 1000).astype(dtype).reshape(shape)
+        if dtype == "bfloat16":
+            return (np.round(x * 4).astype(np.float32) / 4).reshape(shape)
+        return x.astype(dtype).reshape(shape)
+
+    seen = set()
+    for name, meta in exp["variables"].items():
+        got = r.get_tensor(name)
+        want = values(name, tuple(meta["shape"]), meta["dtype"])
+        assert list(got.shape) == meta["shape"], name
+        assert np.array_equal(np.asarray(got, np.float64), np.asarray(want, np.float64)), name
+        seen.add(meta["dtype"])
+    assert seen == {"float32", "float64", "int32", "int64", "bfloat16", "float16"}
+    assert r.get_tensor("global_step").shape == ()
+    # a flipped byte in a shard is caught by that entry's CRC (and only there)
+    import shutil
+    for f in os.listdir(d):
+        shutil.copy(os.path.join(d, f), tmp_path / f)
+    shard1 = tmp_path / (exp["prefix"] + ".data-00001-of-00002")
+    raw = bytearray(shard1.read_bytes())
+    victim = "bert/encoder/layer_0/attention/self/query/kernel"
+    e = r.entries[victim]
+    assert e["shard_id"] == 1
+    raw[e["offset"] + 3] ^= 0x40
+    shard1.write_bytes(bytes(raw))
+    r2 = T.BundleReader(str(tmp_path / exp["prefix"]), verify_tensors=True)
+    with pytest.raises(T.BundleError):
+        r2.get_tensor(victim)
+    assert np.array_equal(r2.get_tensor("kdd_conv1/weights"), r.get_tensor("kdd_conv1/weights"))

@@ -22,7 +22,7 @@ r = torch.randn((M, 768), device="cuda", generator=g)
 gam = torch.ones(768, device="cuda"); bet = torch.zeros(768, device="cuda")
 out = torch.empty((M, 768), device="cuda")
 nbm = (M + 255) // 256
-nvirt = 24 * ((nbm >> 3) + (1 if nbm & 7 else 0))
+nvirt = 3 * nbm            # one stamp row per tile (row panel bm, column tile bn): index bm * 3 + bn
 buf = torch.zeros((nvirt, 6), dtype=torch.int64, device="cuda")
 l.mms_lab_ln_trace.argtypes = [C.c_void_p]
 mode = C.c_int32(0)
@@ -40,7 +40,8 @@ for k in range(5):
     d = us(t[:, k + 1] - t[:, k])
     print("%-42s mean %7.2f us  p50 %7.2f  p95 %7.2f  max %7.2f" % (names[k], d.mean(), np.median(d), np.percentile(d, 95), d.max()))
 print("tile total mean %.2f us" % us(t[:, 5] - t[:, 0]).mean())
-rounds = np.arange(nvirt)[buf.cpu().numpy()[:, 5] > 0] // 240
+PR = 85                      # panels per persistent round on 256 CUs (gemm_pp.hip: 80 triples inside the XCDs + 5 across)
+rounds = (np.arange(nvirt)[buf.cpu().numpy()[:, 5] > 0] // 3) // PR
 tot = us(t[:, 5] - t[:, 0])
 print("per persistent round: tiles, mean tile us, max tile us, mean main-loop us, mean wait us")
 for rr in range(int(rounds.max()) + 1):
