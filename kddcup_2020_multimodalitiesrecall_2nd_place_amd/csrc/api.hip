@@ -99,6 +99,7 @@ struct mms_handle {
     float* ln_stats = nullptr; int* ln_ctl = nullptr; int ln_slot = 0; unsigned ln_tag = 0;
 
     static constexpr int LN_SLOTS = 2048;
+    float* kparts = nullptr; int64_t kparts_rows = 0;      // fp32 partials of the split-K launches (small N = 768 projections), KSPLIT_MAX x rows x 768
     int fuse_ln = 0;       // mms_config.fuse_layernorm (lab build: env MMS_FUSE_LN overrides)
     int fuse_attn = 0;     // mms_config.fuse_attention: QKV projection + self-attention in one kernel (qkv_attn.hip; precision mode 2)
     int4* qa_sub[2] = {nullptr, nullptr}; int* qa_nsub = nullptr;     // sub-tile tables of the (up to two) token streams of a launch wave
@@ -706,6 +707,68 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
     launch_ln_to_planes(t, H, g, b, out.hi, out.lo, H, (int)M, st, m_dev, r);
 }
 
+// Small launches of the N = 768 projections (attention output, FFN down: M < SPLITK_ROWS padded token rows, i.e. calls of up to ~270 pairs --
+// the reference's own call sizes, evaluate_normal.py:15, run_pretraining_predict_score.py:523, lxmert/src/param.py:46): a 128 x 256 tile
+// grid has a handful of workgroups there and each walks its whole K serially (42 .. 100 us per launch at ANY M below ~4000,
+// profiles/r04g_small_batch_kernels.txt).  Split-K: S copies of the tile grid contract K / S columns each into fp32 partials, and the
+// LayerNorm kernel that follows anyway sums them (fixed order: deterministic) and adds bias + residual -- no extra launch.  S depends on K
+// alone, so launches in this regime stay bit-identical across batch sizes.
+constexpr int64_t SPLITK_ROWS = 8192;      // padded row bound of the launch (the live count is on the device): zk calls of <= 273 pairs
+constexpr int KSPLIT_MAX = 8;
+int splitk_for(const mms_handle* h, int64_t M, int K) {
+    if (M >= SPLITK_ROWS || h->nsplit == 1 || h->f8) return 1;
+    const int S = K >= 2048 ? 8 : 4;
+    return K % (64 * S) == 0 ? S : 1;
+}
+int ensure_kparts(mms_handle* h) {
+    if (h->kparts) return MMS_OK;
+    void* p;
+    if (int rc = dev_alloc(h, h->w_allocs, &p, (size_t)KSPLIT_MAX * SPLITK_ROWS * H * 4)) return rc;     // 200 MB, once per handle, at its first small call
+    h->kparts = (float*)p; h->kparts_rows = SPLITK_ROWS;
+    return MMS_OK;
+}
+
+// out = LayerNorm(A W^T + bias + resid) for a bf16 N = 768 projection on the two-kernel route: split-K partials (small M) or the plain fp32
+// tensor t, then the LayerNorm kernel.  a_index / amap: A rows; rmap / r_index: residual rows.
+int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap, const int* a_index, const bf16* w, const float* bias, int64_t M,
+            int K, const Planes& resid, RowMap rmap, const int* r_index, const float* g, const float* b, const Planes& out, float* t,
+            const int* m_dev, int cls_bit) {
+    const int S = splitk_for(h, M, K);
+    if (S > 1) {
+        if (int rc = ensure_kparts(h)) return rc;
+        GemmParams p{};
+        p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.amap = amap; p.a_index = a_index;
+        p.w = w; p.M = (int)M; p.N = H; p.K = K; p.act = ACT_NONE;
+        if (h->nsplit == 3) {
+            for (const auto& wp : h->w_planes)
+                if (w >= wp.base && w < wp.base + wp.elems) { p.w_lo = w + wp.elems; break; }
+            if (!p.w_lo) return h->fail(MMS_ERR_STATE, "proj_ln: weight has no lo plane");
+        }
+        p.out_kind = OUT_F32; p.c_f32 = h->kparts; p.ldc = H; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
+        p.k_splits = S; p.c_split_stride = (long long)h->kparts_rows * H;
+        p.m_dev = m_dev;
+        if (h->timing) {
+            if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
+            p.flop_counter = h->flop_counter;
+            HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
+            launch_gemm(p, h->nsplit, st);
+            HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
+            h->ev_cls.resize(h->ev_used / 2 + 1); h->ev_cls[h->ev_used / 2] = 0;
+            h->ev_used += 2;
+            h->gemm_launches += 1;
+        } else launch_gemm(p, h->nsplit, st);
+        LnResid r;
+        r.hi = resid.hi; r.lo = resid.lo; r.ld = H; r.rmap = rmap; r.r_index = r_index;
+        r.nparts = S; r.part_stride = p.c_split_stride; r.bias = bias;
+        r.o_f8 = out.f8;
+        launch_ln_to_planes(h->kparts, H, g, b, out.hi, out.lo, H, (int)M, st, m_dev, r);
+        return MMS_OK;
+    }
+    if (int rc = gemm(h, st, a, lda, amap, w, bias, M, H, K, ACT_NONE, to_f32(t, H), &resid, m_dev, a_index, rmap, r_index, cls_bit)) return rc;
+    ln_resid(h, st, t, g, b, out, M, m_dev, resid, rmap, r_index);
+    return MMS_OK;
+}
+
 // Packed-stream descriptor: per-pair first row / live count (relative to the stream's first row) and the
 // device-side number of live rows.  off == nullptr: dense layout (row of (b, s) = b * S + s).
 struct Pack { const int* off = nullptr; const int* cnt = nullptr; const int* rows = nullptr;
@@ -776,10 +839,11 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     if (fused) return MMS_OK;
     if (f8) {
         if (int rc = gemm_f8(h, st, h->ctx.f8 + row0 * H, H, w.wo8, w.wos, w.bo, M, H, H, ACT_NONE, to_f32(h->t + row0 * H, H), pk.rows)) return rc;
-    } else if (int rc = gemm(h, st, h->ctx.at(row0 * H), H, ID, w.wo, w.bo, M, H, H, ACT_NONE,
-                             to_f32(h->t + row0 * H, H), &resid, pk.rows, nullptr, ID, nullptr, 2)) return rc;
-    ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
-    return MMS_OK;
+        ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
+        return MMS_OK;
+    }
+    return proj_ln(h, st, h->ctx.at(row0 * H), H, ID, nullptr, w.wo, w.bo, M, H, resid, ID, nullptr, w.g, w.b, out.at(row0 * H), h->t + row0 * H,
+                   pk.rows, 2);
 }
 
 #ifdef MMS_LAB
@@ -828,9 +892,7 @@ int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes ou
     if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I), nullptr, pk.rows, nullptr, ID, nullptr, 4)) return rc;
     if (int rc = gemm_ln(h, st, false, h->mid, I, w.wd, w.wd8, w.wds, w.bd, M, I, resid, w.g, w.b, out.at(row0 * H), h->t + row0 * H, pk.rows, &fused)) return rc;
     if (fused) return MMS_OK;
-    if (int rc = gemm(h, st, h->mid, I, ID, w.wd, w.bd, M, H, I, ACT_NONE, to_f32(h->t + row0 * H, H), &resid, pk.rows, nullptr, ID, nullptr, 8)) return rc;
-    ln_resid(h, st, h->t + row0 * H, w.g, w.b, out.at(row0 * H), M, pk.rows, resid);
-    return MMS_OK;
+    return proj_ln(h, st, h->mid, I, ID, nullptr, w.wd, w.bd, M, I, resid, ID, nullptr, w.g, w.b, out.at(row0 * H), h->t + row0 * H, pk.rows, 8);
 }
 
 // Last self-attention + FFN block before the pooler: only the CLS row feeds the pooler (pixelbert.py:258-266,
@@ -852,13 +914,10 @@ int last_block_cls(mms_handle* h, hipStream_t st, const AttW& att, const FfnW& f
     a.key_add = key_add; a.kv_off = pk.off; a.kv_cnt = pk.cnt;
     a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo; a.ldo = H; a.B = (int)n;
     if (int rc = attend(h, a, st)) return rc;
-    if (int rc = gemm(h, st, h->ctx, H, ID, att.wo, att.bo, n, H, H, ACT_NONE, to_f32(h->t, H), &in, nullptr, nullptr, cls, pk.off)) return rc;
-    ln_resid(h, st, h->t, att.g, att.b, tmp, n, nullptr, in, cls, pk.off);
+    if (int rc = proj_ln(h, st, h->ctx, H, ID, nullptr, att.wo, att.bo, n, H, in, cls, pk.off, att.g, att.b, tmp, h->t, nullptr, 0)) return rc;
     const int I = h->cfg.inter;
     if (int rc = gemm(h, st, tmp, H, ID, ffn.wi, ffn.bi, n, I, H, act, to_planes(h->mid, I))) return rc;
-    if (int rc = gemm(h, st, h->mid, I, ID, ffn.wd, ffn.bd, n, H, I, ACT_NONE, to_f32(h->t, H), &tmp)) return rc;
-    ln_resid(h, st, h->t, ffn.g, ffn.b, in, n, nullptr, tmp);
-    return MMS_OK;
+    return proj_ln(h, st, h->mid, I, ID, nullptr, ffn.wd, ffn.bd, n, I, tmp, ID, nullptr, ffn.g, ffn.b, in, h->t, nullptr, 0);
 }
 
 int check_ready(mms_handle* h, int model, const void* batch, const float* logits) {

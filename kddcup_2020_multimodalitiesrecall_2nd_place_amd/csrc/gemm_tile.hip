@@ -46,7 +46,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
     // the grid is sized for the padded row bound; only the first nblk workgroups own live row panels
     const int nbn = p.N / BN, nbm = (Meff + BM - 1) / BM, nblk = nbm * nbn;
     int bid = blockIdx.x;
-    if (bid >= nblk) return;   // block-uniform exit (packed mode: fewer live rows than the bound)
+    // split-K: copy ksp of the tile grid contracts K columns [k0, k0 + klen) into its own fp32 partial (GemmParams::k_splits)
+    const int S = p.k_splits > 1 ? p.k_splits : 1;
+    if (bid >= nblk * S) return;   // block-uniform exit (packed mode: fewer live rows than the bound)
+    const int ksp = bid / nblk;
+    bid -= ksp * nblk;
+    const int klen = p.K / S, k0 = ksp * klen;
     {   // bijective XCD remap over the LIVE workgroups (block b runs on XCD b % 8; speed only)
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk = klen / BK;
     const int fr = lane & 15, fk = lane >> 4;
 
     // `hook(g)` runs after MFMA group g = ks * FM + i (used to interleave the next tile's LDS-DMA issue)
@@ -115,13 +120,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
             const int c = (lane & 7) ^ ((r >> 1) & 7);
             int gr = bm * BM + r;
             gr = gr < Meff ? gr : Meff - 1;
-            a_src[s] = p.a_hi + 2 * ((p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda) + plane_off(c * 8);   // hl32 planes
+            a_src[s] = p.a_hi + 2 * ((p.a_index ? (long long)p.a_index[gr] : p.amap(gr)) * (long long)p.lda) + plane_off(c * 8) + 2 * k0;   // hl32 planes
         }
 #pragma unroll
         for (int s = 0; s < GB; ++s) {
             const int r = (wave + NW * s) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((r >> 1) & 7);
-            w_src[s] = p.w + wtile_off(bn * BN + r, c * 8, p.K);                                                                       // tiled weights
+            w_src[s] = p.w + wtile_off(bn * BN + r, c * 8, p.K) + 16 * k0;                                                             // tiled weights
         }
         // piece q of a stage: q < GA*NSPLIT -> A planes, else B; one global_load_lds (1 KiB) per piece per wave
         constexpr int NPIECE = GA * NA + GB;
@@ -173,11 +178,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
             int r = bm * BM + lr + (NT / 8) * s;
             r = r < Meff ? r : Meff - 1;
             // hl32 planes (common.h): a row's K tile of 64 columns = [hi 32 | lo 32 | hi 32 | lo 32]; chunk c (8 columns) of the hi plane
-            a_row[s] = p.a_hi + 2 * ((p.a_index ? (long long)p.a_index[r] : p.amap(r)) * (long long)p.lda) + plane_off(c * 8);
+            a_row[s] = p.a_hi + 2 * ((p.a_index ? (long long)p.a_index[r] : p.amap(r)) * (long long)p.lda) + plane_off(c * 8) + 2 * k0;
         }
         static_assert(BK == 64, "K tile = two 32-column blocks");
 #pragma unroll
-        for (int s = 0; s < CB; ++s) w_row[s] = p.w + wtile_off(bn * BN + lr + (NT / 8) * s, c * 8, p.K);      // tiled weights: a K tile = 2 tiles of 512
+        for (int s = 0; s < CB; ++s) w_row[s] = p.w + wtile_off(bn * BN + lr + (NT / 8) * s, c * 8, p.K) + 16 * k0;      // tiled weights: a K tile = 2 tiles of 512
         u32x4 ra0[CA], ra1[CA], rb[CB], rb1[CB];
 #pragma unroll
         for (int s = 0; s < CA; ++s) {
@@ -219,12 +224,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(const 
         }
     }
 
+    if (S > 1) {      // partial sums: plain fp32 rows of this split's own buffer (host: no bias / residual / activation on a split launch)
+        GemmParams q = p;
+        q.c_f32 = p.c_f32 + (long long)ksp * p.c_split_stride;
+        gemm_epilogue<ACT, BM, BN, TM, TN, FM, FN>(q, acc, smem, bm, bn, wm, wn, wave, lane, Meff);
+        return;
+    }
     gemm_epilogue<ACT, BM, BN, TM, TN, FM, FN>(p, acc, smem, bm, bn, wm, wn, wave, lane, Meff);
 }
 
 template <int NSPLIT, int BM, int BN, int WM, int WN, int G, int OPT>
 static void launch_cfg(const GemmParams& p, hipStream_t st) {
-    const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
+    const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN) * (p.k_splits > 1 ? p.k_splits : 1);
     const dim3 grid(nblk), block(WM * WN * 64);
     switch (p.act) {
         case ACT_RELU: hipLaunchKernelGGL((gemm_tile_kernel<NSPLIT, ACT_RELU, BM, BN, WM, WN, G, OPT>), grid, block, 0, st, p); break;
@@ -250,6 +261,7 @@ static bool launch_variant(const GemmParams& p, int variant, hipStream_t st) {
 
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st) {
     if (p.M <= 0) return true;
+    if (p.k_splits > 1 && (p.K % (64 * p.k_splits) || p.out_kind != OUT_F32 || p.hm_rows || p.bias || p.r_hi || p.act != ACT_NONE)) return false;
     if (nsplit == 3) {   // A and W both split: 128x128 tile (4 operand planes x 16 KiB = 64 KiB, 2 workgroups / CU)
         if (!p.w_lo) return false;
         launch_cfg<3, 128, 128, 2, 2, 0, 0>(p, st);

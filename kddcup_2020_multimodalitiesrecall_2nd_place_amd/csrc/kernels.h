@@ -47,6 +47,10 @@ struct GemmParams {
     float* ln_stats;             // [rows][3 tiles][2] 8-byte {value, tag} granules
     unsigned ln_tag;             // unique per launch
     int* ln_ctl;                 // [0] workgroups checked in, [1] 0 undecided / 1 fused / 2 plain -- zeroed before the launch
+    // split-K (gemm_tile.hip; small launches of the N = 768 projections): k_splits > 1 -> the grid holds k_splits copies of the tile grid, copy s
+    // contracts K columns [s * K / k_splits, (s + 1) * K / k_splits) (a multiple of 64) and writes its fp32 partial to c_f32 + s * c_split_stride;
+    // bias / residual / activation are NOT applied (the LayerNorm kernel behind it sums the partials: LnResid::nparts)
+    int k_splits; long long c_split_stride;
     int variant;                 // 0: per-shape choice (gemm_dispatch.hip); tests name ONE tile engine per call (mms_dbg_gemm): 1, 4, 16 register-staged
                                  // tiles, 20 / 26 ping-pong (one tile per workgroup / persistent), 27 three-pass ping-pong; lab build: 3, 28
     unsigned long long* ln_dbg;  // lab build only: per-tile phase stamps [virtual tile][6] of wall_clock64 (tools/ln_trace.py); nullptr otherwise
@@ -118,7 +122,8 @@ bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st);   // false: shape 
 // optional residual of the LayerNorm input: row r adds planes row (r_index ? r_index[r] : rmap(r)) before normalising
 struct LnResid { const bf16* hi = nullptr; const bf16* lo = nullptr; int ld = 0; RowMap rmap{0, 0, 0}; const int* r_index = nullptr; int reverse = 0;
                  unsigned char* o_f8 = nullptr;
-                 const int* skip = nullptr; };   // skip: the kernel returns at once when *skip == 1 (the producing GEMM already normalised: gemm_pp_ln.h)   // o_f8: additionally write the row as e4m3 bytes (row stride ldo; precision mode 4)
+                 const int* skip = nullptr;
+                 int nparts = 1; long long part_stride = 0; const float* bias = nullptr; };   // nparts > 1: in = sum of nparts fp32 partials (split-K GEMM), + bias   // skip: the kernel returns at once when *skip == 1 (the producing GEMM already normalised: gemm_pp_ln.h)   // o_f8: additionally write the row as e4m3 bytes (row stride ldo; precision mode 4)
 void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta,
                          bf16* o_hi, bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev = nullptr, LnResid res = LnResid());
 void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipStream_t st);

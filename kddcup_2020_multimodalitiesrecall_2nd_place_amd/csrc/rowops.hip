@@ -114,6 +114,10 @@ __global__ __launch_bounds__(256) void k_ln_to_planes(const float* in, int ld, c
     if (res.reverse) row = lim - 1 - row;
     Row x;
     row_load(x, in + (long long)row * ld);
+    if (res.nparts > 1) {      // split-K producer: the row is the sum of its partials (fixed order) + bias
+        for (int s = 1; s < res.nparts; ++s) row_add(x, in + s * res.part_stride + (long long)row * ld);
+        if (res.bias) row_add(x, res.bias);
+    }
     if (res.hi) {
         const long long ro = (res.r_index ? (long long)res.r_index[row] : res.rmap(row)) * (long long)res.ld;
         row_add_planes(x, plane_ptr(res.hi, ro), plane_ptr(res.lo, ro));

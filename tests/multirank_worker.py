@@ -82,7 +82,8 @@ def main():
         return ensemble_main(rank, world)
     cfg = ZkConfig(layers=2, vocab=4096, inter=1024)
     w = weights.make_weights(cfg)
-    NQ = 25      # ~480 pairs: whole set and shards all run the same GEMM engine (rows < 16384, gemm_dispatch.hip) => bitwise comparable
+    NQ = 12      # ~230 pairs: whole set and shards all run in ONE engine regime (< 8192 padded token rows: register-staged tiles, N = 768
+                 # projections split over K by a factor that depends on K alone; api.hip SPLITK_ROWS) => bitwise comparable
     whole = synth.make_pairs(NQ, (8, 30), vocab=cfg.vocab, tag="/mr")
     qop = whole.query_id - whole.query_id.min()
     counts = sharding.shard_sizes(qop, NQ, world)
