@@ -413,7 +413,8 @@ def main():
         traffic = traffic_src = fused_traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % a.model)
         if os.path.exists(tp) and not a.dense and a.precision == 2 and a.workload == "bench" and \
-                json.load(open(tp)).get("fuse_attention", 0) == a.fuse_attn:
+                json.load(open(tp)).get("fuse_attention", 0) == a.fuse_attn and \
+                json.load(open(tp)).get("fuse_layernorm", 0) == next(iter(members.values()))[2].fuse_layernorm:
             traffic = round(json.load(open(tp))["hbm_bytes_per_launch"], 1)
             fused_traffic = json.load(open(tp)).get("fused_hbm_bytes_per_launch")
             traffic_src = "profiles/pmc_traffic_%s.json (builder's rocprofv3 --pmc run of this workload, FETCH_SIZE x 2 + WRITE_SIZE; not re-measured here)" % a.model
@@ -477,6 +478,8 @@ def main():
                 if c[1] > 0:
                     t = c[2] / (c[0] * 1e-3) / 1e12
                     res["roofline"][key] = {"kernel": what, "launches": int(c[1]), "avg_launch_ms": round(c[0] / c[1], 4), "achieved": round(t, 2), "frac": round(t / peak, 4)}
+                    if key == "layernorm_fused" and traffic is not None:
+                        res["roofline"][key]["traffic"] = json.load(open(tp)).get("ln_fused_hbm_bytes_per_launch")
         # the whole step on the same terms: every executed dense-contraction FLOP (device-counted) over the barrier-bracketed step time
         step_fl = (gemm_fl + fused[2]) / max(a.steps, 1)
         res["roofline"]["whole_step"] = {"executed_flops": round(step_fl, 1), "ms_per_step": round(dt / a.steps * 1e3, 3),

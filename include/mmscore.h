@@ -220,6 +220,10 @@ int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32
  * LayerNorm kernel queued behind it; *mode_out = 1 when the launch ran fused, 2 when it took the plain two-kernel route */
 int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, const float* bias, const float* resid_f32,
                     const float* gamma, const float* beta, int32_t f8, float* c_f32, int32_t* mode_out, void* stream);
+/* the small-launch route of the same operation (calls of a few hundred pairs): register-staged tiles with the contraction split `splits`
+ * ways into fp32 partials (K % (64 * splits) == 0; 1 = unsplit) + the LayerNorm kernel that sums them and adds bias + residual */
+int mms_dbg_proj_ln_splitk(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, const float* bias, const float* resid_f32,
+                           const float* gamma, const float* beta, int32_t splits, float* c_f32, void* stream);
 /* time one GEMM shape on random data (variant as in mms_dbg_gemm; 52: the MX-fp8 engine; 60 / 61: the LayerNorm kernel with / without
  * residual; 62 / 63: N = 768 projection + residual + LayerNorm as two kernels / as one launch with the fused epilogue) */
 int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t act, int32_t out_planes, int32_t resid,

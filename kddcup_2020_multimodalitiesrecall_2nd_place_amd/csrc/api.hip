@@ -1870,6 +1870,41 @@ int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32
     return MMS_OK;
 }
 
+// out = LayerNorm(A W^T + bias + resid) over N = 768 on the SMALL-launch route: the register-staged tile engine with the contraction split
+// `splits` ways (1, or a divisor of K / 64: fp32 partials) and the LayerNorm kernel that sums the partials, adds bias + residual and normalises
+// -- the kernel pair proj_ln() launches for calls of a few hundred pairs
+int mms_dbg_proj_ln_splitk(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, const float* bias, const float* resid_f32,
+                           const float* gamma, const float* beta, int32_t splits, float* c_f32, void* stream) {
+    const int64_t N = H;
+    if (!a_f32 || !w_f32_nk || !resid_f32 || !gamma || !beta || !c_f32 || M <= 0 || splits < 1 || K % (64 * splits)) { g_err = "mms_dbg_proj_ln_splitk: bad argument"; return MMS_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    bf16 *ap = nullptr, *wp = nullptr, *rp = nullptr, *cp = nullptr;
+    float* parts = nullptr;
+    DBG_TRY(hipMalloc((void**)&ap, (size_t)M * K * 4)); DBG_TRY(hipMalloc((void**)&wp, (size_t)N * K * 4));
+    DBG_TRY(hipMalloc((void**)&rp, (size_t)M * N * 4)); DBG_TRY(hipMalloc((void**)&cp, (size_t)M * N * 4));
+    DBG_TRY(hipMalloc((void**)&parts, (size_t)splits * M * N * 4));
+    launch_split_f32(a_f32, ap, ap + MMS_PLANE_LO, M * K, st);
+    launch_tile_weights(w_f32_nk, wp, wp + N * K, N, K, st);
+    launch_split_f32(resid_f32, rp, rp + MMS_PLANE_LO, M * N, st);
+    GemmParams p{};
+    p.a_hi = ap; p.a_lo = ap + MMS_PLANE_LO; p.lda = (int)K; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
+    p.w = wp; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = ACT_NONE;
+    p.out_kind = OUT_F32; p.c_f32 = parts; p.ldc = (int)N;
+    p.k_splits = splits; p.c_split_stride = (long long)M * N;
+    p.variant = 4;
+    if (splits == 1) p.bias = bias;
+    launch_gemm(p, 2, st);
+    LnResid r;
+    r.hi = rp; r.lo = rp + MMS_PLANE_LO; r.ld = (int)N;
+    if (splits > 1) { r.nparts = splits; r.part_stride = p.c_split_stride; r.bias = bias; }
+    launch_ln_to_planes(parts, (int)N, gamma, beta, cp, cp + MMS_PLANE_LO, (int)N, (int)M, st, nullptr, r);
+    launch_planes_to_f32(cp, cp + MMS_PLANE_LO, c_f32, M * N, st);
+    DBG_TRY(hipStreamSynchronize(st));
+    DBG_TRY(hipGetLastError());
+    for (void* q : {(void*)ap, (void*)wp, (void*)rp, (void*)cp, (void*)parts}) (void)hipFree(q);
+    return MMS_OK;
+}
+
 __global__ void k_fill_random(float* p, long long n, unsigned seed) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         unsigned x = (unsigned)(i * 2654435761u) ^ seed;

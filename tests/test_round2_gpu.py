@@ -425,6 +425,34 @@ def test_gemm_with_fused_layernorm_epilogue(case):
     assert err < (2e-4 if f8 else 3e-5), err
 
 
+@pytest.mark.parametrize("case", [(30, 768, 4), (30, 3072, 8), (1000 + 13, 768, 4), (4000, 3072, 8), (257, 3072, 1), (5, 768, 2)])
+def test_split_k_projection_with_partials_summed_in_the_layernorm(case):
+    """The small-launch route of the N = 768 projections (api.hip proj_ln): gemm_tile.hip contracts K in `splits` slices into fp32
+    partials, k_ln_to_planes sums them in a fixed order, adds bias + residual and normalises.  Against fp64, and bit-for-bit repeatable."""
+    M, K, S = case
+    l = lib.load()
+    a = weights.normal("sk/a/%d/%d" % (M, K), (M, K), 1)
+    w = weights.round_to_bf16(weights.normal("sk/w/%d" % K, (768, K), 1, 1.0 / np.sqrt(K)))
+    bias = weights.normal("sk/b", (768,), 1, 0.1)
+    r = weights.normal("sk/r/%d" % M, (M, 768), 1) + 0.3
+    gamma = weights.normal("sk/g", (768,), 1, 0.1, 1.0)
+    beta = weights.normal("sk/be", (768,), 1, 0.1)
+    da, dw, db, dr, dg, dbe = _dev(a), _dev(w), _dev(bias), _dev(r), _dev(gamma), _dev(beta)
+    outs = []
+    for _ in range(2):
+        out = torch.empty((M, 768), device="cuda", dtype=torch.float32)
+        rc = l.mms_dbg_proj_ln_splitk(da.data_ptr(), M, K, dw.data_ptr(), db.data_ptr(), dr.data_ptr(), dg.data_ptr(), dbe.data_ptr(), S,
+                                      out.data_ptr(), None)
+        assert rc == 0, l.mms_global_error()
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    v = a.astype(np.float64) @ w.astype(np.float64).T + bias + r
+    mu = v.mean(1, keepdims=True)
+    ref = (v - mu) / np.sqrt(((v - mu) ** 2).mean(1, keepdims=True) + 1e-12) * gamma + beta
+    err = np.abs(outs[0] - ref).max() / np.abs(ref).max()
+    assert err < 3e-5, err
+
+
 @pytest.mark.parametrize("name,precision", [("zk", 2), ("lxmert", 2), ("lds", 2), ("lds", 4)])
 def test_fused_layernorm_forward_matches_the_two_kernel_route(name, precision):
     """mms_config.fuse_layernorm at a size where the big launches really take the fused epilogue (>= 16384 rows): logits against
