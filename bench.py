@@ -277,6 +277,7 @@ def main():
     ap.add_argument("--cands", type=int, default=30)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of host CPU work spent on the cpu_baseline sample (default 20; the contract test uses less)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (precision 3 on fp32 weights, lds, lxmert, H2D-inclusive)")
     ap.add_argument("--fp32-weights", action="store_true", help="seeded weights NOT rounded to bf16 (what a real checkpoint looks like)")
     ap.add_argument("--fuse-attn", type=int, default=-1, help="mms_config.fuse_attention (default: the LIBRARY default, scorers.make_scorer's \"auto\": 2 for zk / lds, 0 for lxmert): QKV projection + self-attention in one kernel; 1 = exact-fp32 attention MFMAs (bit-identical to the two-kernel route), 2 = split-bf16 MFMAs")
@@ -510,7 +511,7 @@ def main():
             def hip_logits(bb):
                 lg, _ = scorers.score_batch(s0, bb)
                 return lg.double().cpu().numpy()
-            res["cpu_baseline"] = cpu_baseline(cfg0, w0, hip_logits)
+            res["cpu_baseline"] = cpu_baseline(cfg0, w0, hip_logits, budget_s=a.cpu_budget)
         print(json.dumps(res), flush=True)
     scorer.close()
     if world > 1:

@@ -710,7 +710,7 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
 // Small launches of the N = 768 projections (attention output, FFN down: M < SPLITK_ROWS padded token rows, i.e. calls of up to ~270 pairs --
 // the reference's own call sizes, evaluate_normal.py:15, run_pretraining_predict_score.py:523, lxmert/src/param.py:46): a 128 x 256 tile
 // grid has a handful of workgroups there and each walks its whole K serially (42 .. 100 us per launch at ANY M below ~4000,
-// profiles/r04g_small_batch_kernels.txt).  Split-K: S copies of the tile grid contract K / S columns each into fp32 partials, and the
+// profiles/rd4g_small_batch_kernels.txt).  Split-K: S copies of the tile grid contract K / S columns each into fp32 partials, and the
 // LayerNorm kernel that follows anyway sums them (fixed order: deterministic) and adds bias + residual -- no extra launch.  S depends on K
 // alone, so launches in this regime stay bit-identical across batch sizes.
 constexpr int64_t SPLITK_ROWS = 8192;      // padded row bound of the launch (the live count is on the device): zk calls of <= 273 pairs
@@ -1287,11 +1287,22 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
         a.q_off = pv.off; a.q_cnt = pv.cnt; a.kv_off = pl.off; a.kv_cnt = pl.cnt;
         if (int rc = attend(h, a, st)) return rc;
         if (c.pack_tokens) {
-            if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
+            // per stream: the fused bias + residual + LayerNorm epilogue on big launches (mms_config.fuse_layernorm bit 0), else GEMM -> LayerNorm kernel
             const Planes rv = h->x.at(ML * H);
-            if (int rc = gemm(h, st, h->ctx.at(ML * H), H, ID, w.cross.wo, w.cross.bo, MV, H, H, ACT_NONE, to_f32(h->t + ML * H, H), &rv, pv.rows)) return rc;
-            ln_resid(h, st, h->t, w.cross.g, w.cross.b, h->y, ML, pl.rows, h->x);
-            ln_resid(h, st, h->t + ML * H, w.cross.g, w.cross.b, h->y.at(ML * H), MV, pv.rows, rv);
+            bool fl = false, fv = false;
+            if (!(h->f8 && h->x.f8)) {
+                if (int rc = gemm_ln(h, st, false, h->ctx, H, w.cross.wo, nullptr, nullptr, w.cross.bo, ML, H, h->x, w.cross.g, w.cross.b, h->y, h->t, pl.rows, &fl)) return rc;
+                if (int rc = gemm_ln(h, st, false, h->ctx.at(ML * H), H, w.cross.wo, nullptr, nullptr, w.cross.bo, MV, H, rv, w.cross.g, w.cross.b, h->y.at(ML * H),
+                                     h->t + ML * H, pv.rows, &fv)) return rc;
+            }
+            if (!fl) {
+                if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
+                ln_resid(h, st, h->t, w.cross.g, w.cross.b, h->y, ML, pl.rows, h->x);
+            }
+            if (!fv) {
+                if (int rc = gemm(h, st, h->ctx.at(ML * H), H, ID, w.cross.wo, w.cross.bo, MV, H, H, ACT_NONE, to_f32(h->t + ML * H, H), &rv, pv.rows)) return rc;
+                ln_resid(h, st, h->t + ML * H, w.cross.g, w.cross.b, h->y.at(ML * H), MV, pv.rows, rv);
+            }
         } else {
             if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, R, H, H, ACT_NONE, to_f32(h->t, H), &h->x)) return rc;
             ln_resid(h, st, h->t, w.cross.g, w.cross.b, h->y, R, nullptr, h->x);

@@ -47,7 +47,7 @@ class _Base:
         if fuse_layernorm == "auto":
             # mms_config.fuse_layernorm mask 3: bias + residual + LayerNorm in the epilogue of the attention-output and FFN-down projections of
             # the big launches (precision mode 2; gemm_pp_ln.h) -- no LayerNorm launches, no fp32 round trip of the pre-LayerNorm tensor;
-            # +1.5 % on the bench batch (profiles/r04d_*).  Other precision modes ignore it.
+            # +1.5 % on the bench batch (profiles/rd4b_*).  Other precision modes ignore it.
             fuse_layernorm = 3
         self.fuse_layernorm = 3 if fuse_layernorm is True else int(fuse_layernorm)
         self.cfg = cfg

@@ -40,20 +40,40 @@ def _key(name: str, seed: int) -> np.uint64:
     return np.uint64(int.from_bytes(h[:8], "little"))
 
 
-def uniform01(name: str, n: int, seed: int, stream: int = 0) -> np.ndarray:
-    """n doubles in (0, 1), a pure function of (name, seed, stream, index)."""
+def uniform01(name: str, n: int, seed: int, stream: int = 0, start: int = 0) -> np.ndarray:
+    """n doubles in (0, 1), a pure function of (name, seed, stream, index); ``start``: index of the first one."""
     with np.errstate(over="ignore"):
-        ctr = np.arange(n, dtype=np.uint64) * np.uint64(2) + np.uint64(stream)
+        ctr = np.arange(start, start + n, dtype=np.uint64) * np.uint64(2) + np.uint64(stream)
         bits = _splitmix64(_splitmix64(ctr ^ _key(name, seed)))
     return ((bits >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
 
 
-def normal(name: str, shape, seed: int, std: float = 1.0, mean: float = 0.0) -> np.ndarray:
-    n = int(np.prod(shape))
-    u1 = uniform01(name, n, seed, 0)
-    u2 = uniform01(name, n, seed, 1)
+_CHUNK = 1 << 20
+_pool = None
+
+
+def _normal_chunk(name, seed, std, mean, start, n, bf16=False):
+    u1 = uniform01(name, n, seed, 0, start)
+    u2 = uniform01(name, n, seed, 1, start)
     z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
-    return (mean + std * z).reshape(shape).astype(np.float32)
+    out = (mean + std * z).astype(np.float32)
+    return round_to_bf16(out) if bf16 else out
+
+
+def normal(name: str, shape, seed: int, std: float = 1.0, mean: float = 0.0, bf16: bool = False) -> np.ndarray:
+    """Every element is a pure function of (name, seed, index), so large tensors are generated in chunks on a thread pool (numpy releases
+    the GIL inside its ufuncs): the full-size models take seconds instead of 15 .. 20 s each (half of the GPU suite's wall time was this)."""
+    global _pool
+    n = int(np.prod(shape))
+    if n <= 2 * _CHUNK:
+        return _normal_chunk(name, seed, std, mean, 0, n, bf16).reshape(shape)
+    if _pool is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max(1, min(32, (os.cpu_count() or 2) - 1)))
+    starts = list(range(0, n, _CHUNK))
+    parts = list(_pool.map(lambda s0: _normal_chunk(name, seed, std, mean, s0, min(_CHUNK, n - s0), bf16), starts))
+    return np.concatenate(parts).reshape(shape)
 
 
 def round_to_bf16(x: np.ndarray) -> np.ndarray:
@@ -70,8 +90,7 @@ class _Gen:
         self.out: dict[str, np.ndarray] = {}
 
     def mat(self, name, shape, std):
-        w = normal(name, shape, self.seed, std)
-        self.out[name] = round_to_bf16(w) if self.bf16 else w
+        self.out[name] = normal(name, shape, self.seed, std, bf16=self.bf16)      # rounded to bf16 inside the (parallel) chunks
 
     def vec(self, name, shape, std, mean=0.0):
         self.out[name] = normal(name, shape, self.seed, std, mean)
@@ -206,9 +225,21 @@ def make_lxmert_weights(cfg: LxmertConfig = LxmertConfig(), seed: int = 20200823
     return g.out
 
 
+_MEMO: dict = {}
+
+
 def make_weights(cfg, seed: int = 20200823, bf16_matrices: bool = True):
-    return {"zk": make_zk_weights, "lds": make_lds_weights, "lxmert": make_lxmert_weights}[cfg.name](
-        cfg, seed, bf16_matrices)
+    """Seeded weights of ``cfg``.  Memoised per process (a pure function of its arguments): callers get their own dict over SHARED, read-only
+    arrays -- replace an entry to change a tensor (``w[k] = w[k] * 2``), in-place edits raise."""
+    key = (repr(cfg), seed, bool(bf16_matrices))
+    if key not in _MEMO:
+        w = {"zk": make_zk_weights, "lds": make_lds_weights, "lxmert": make_lxmert_weights}[cfg.name](cfg, seed, bf16_matrices)
+        for v in w.values():
+            v.flags.writeable = False
+        if len(_MEMO) >= 12:                       # bound the host memory a long-lived process keeps (full models: 0.4 .. 0.8 GB each)
+            _MEMO.pop(next(iter(_MEMO)))
+        _MEMO[key] = w
+    return dict(_MEMO[key])
 
 
 # ------------------------------------------------------------------------------------------------------------------

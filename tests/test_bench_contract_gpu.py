@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_bench_prints_one_contract_line():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--queries", "40"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--queries", "40", "--cpu-budget", "4"],
                          cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -37,7 +37,20 @@ def test_bench_prints_one_contract_line():
     p3 = sec["precision3"]
     assert p3["precision_mode"] == 3 and p3["value"] > 0 and p3["parity_max_vecrel_vs_fp32_port"] < 1e-3
     assert sec["lds"]["value"] > 0 and sec["lxmert"]["value"] > 0
-    assert d["value_fp32_checkpoint"] == p3 and d["config"]["fuse_attention"] == 2     # mode 3 also as a top-level value; the route the line ran
+    # every secondary model line carries its own parity against the oracle's fp32 port (64 pairs of the timed batch)
+    for k in ("lds", "lxmert", "dense", "all_boxes"):
+        assert sec[k]["parity_max_vecrel_vs_fp32_port"] < 1e-3, (k, sec[k])
+    sw = sec["box_sweep"]
+    assert len(sw) == 5 and all(x["value"] > 0 and 0 < x["live_token_fraction"] <= 1 for x in sw)
+    assert [x["mean_boxes_per_pair"] for x in sw] == sorted(x["mean_boxes_per_pair"] for x in sw) and sw[-1]["mean_boxes_per_pair"] == 10.0
+    assert sec["dense"]["live_token_fraction"] == 1.0
+    sh = sec["shard_rates"]
+    assert sh["bench_strong_n8"]["predicted_strong_8"] == round(8 * sh["bench_strong_n8"]["value_one_gpu"], 1) and sh["testB_n8"]["pairs_rank0"] > 0
+    assert d["value_fp32_checkpoint"] == p3     # mode 3 also as a top-level value
+    # the line runs the LIBRARY defaults: what make_scorer(cfg, weights) gives a user
+    assert d["config"]["fuse_attention"] == 2 and d["config"]["fuse_layernorm"] == 3
+    ws = r["whole_step"]
+    assert 0 < ws["frac"] <= r["frac_incl_fused"] + 1e-6 and abs(ws["achieved"] - ws["executed_flops"] / (ws["ms_per_step"] * 1e-3) / 1e12) < 0.05
     fq = r["fused_qkv_attention"]          # the Q|K|V projections ran inside the fused kernel, timed apart from the plain GEMM launches
     assert fq["launches"] > 0 and fq["achieved"] > 0 and abs(fq["frac"] - fq["achieved"] / r["peak"]) < 1e-3
     assert r["achieved_incl_fused"] > 0 and min(r["achieved"], fq["achieved"]) <= r["achieved_incl_fused"] <= max(r["achieved"], fq["achieved"])

@@ -6,7 +6,7 @@ assignment: only the weights of the named classes are quantised to e4m3 with one
 csrc/rowops.hip k_quant_rows_f8 stores); every activation and all other weights stay fp64.  Any real fp8 kernel for that assignment adds
 its activation quantisation on top, so an assignment whose floor is above the bar cannot meet it.
 Also reported: the same floor with e4m3 activations emulated on the class's A operand (round-to-nearest e4m3 of the fp64 activation, what
-pack4_f8 does), for the two cheapest-looking classes.  Output recorded in profiles/r04_f8_class_study.txt."""
+pack4_f8 does), for the two cheapest-looking classes.  Output recorded in profiles/rd4_f8_class_study.txt."""
 import os
 import sys
 import time
