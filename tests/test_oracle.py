@@ -220,3 +220,27 @@ def test_auto_precision_sees_through_the_export_dtype():
     w2 = weights.make_weights(cfg)
     assert weights.auto_precision({k: v.astype(np.float64) for k, v in w2.items()}) == 2
     assert weights.expected_shapes(cfg) == weights.expected_shapes(cfg)
+
+
+def test_zk_label_conv_same_padding_agrees_with_an_independent_conv2d():
+    """The zk image-token stage has no reference-produced pin (TensorFlow 1.x cannot run here).  This is the next best
+    thing for its one non-obvious TF semantic -- `slim.conv2d(768, [1, 8])` with padding='SAME' on 8 positions (model_triple.py:189): TF pads
+    total 7 as 3 left / 4 right.  torch.nn.functional.conv2d(padding='same') is an independent implementation of the same rule (the extra
+    column goes to the right for even kernels); the oracle's explicit loop must equal it, and must NOT equal the 4 left / 3 right variant."""
+    import torch
+    import torch.nn.functional as F
+    cfg = small_cfg("zk", layers=1)
+    w = weights.make_weights(cfg)
+    rs = np.random.RandomState(4)
+    ids = rs.randint(1, cfg.vocab, size=(3, 10, 8)).astype(np.int64)
+    ids[0, 0, 3:] = 0
+    w64 = {k: np.asarray(v, np.float64) for k, v in w.items()}
+    got = O.zk_label_text(ids, w64)                                             # [3,10,768]: mean over positions of relu(conv)
+    E = torch.as_tensor(w64["bert/embeddings/word_embeddings"])
+    x = E[torch.as_tensor(ids)].reshape(30, 8, 768).permute(0, 2, 1)[:, :, None, :]          # NCHW: [30, 768 in, 1, 8 positions]
+    k = torch.as_tensor(w64["kdd_conv1/weights"]).permute(3, 2, 0, 1)                        # HWIO [1,8,in,out] -> OIHW
+    b = torch.as_tensor(w64["kdd_conv1/biases"])
+    ref = F.relu(F.conv2d(x, k, b, padding="same")).mean(3)[:, :, 0].reshape(3, 10, 768).numpy()
+    assert np.abs(got - ref).max() < 1e-9 * np.abs(ref).max() + 1e-12
+    wrong = F.relu(F.conv2d(F.pad(x, (4, 3)), k, b)).mean(3)[:, :, 0].reshape(3, 10, 768).numpy()      # 4 left / 3 right
+    assert np.abs(got - wrong).max() > 1e-3 * np.abs(ref).max()
