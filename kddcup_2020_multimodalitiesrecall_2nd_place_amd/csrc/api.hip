@@ -564,12 +564,19 @@ struct GemmOut {
     RowMap cmap{0, 0, 0};
 };
 
+int ensure_kparts(mms_handle* h);
+// Tiny launches (M < TINY_ROWS token rows: the reference's own zk / lds call sizes of 1 and 5 pairs) of the wide projections (QKV, K | V, FFN-up:
+// N >= 1536, K = 768): 9 .. 12 workgroups walking K serially take 25 .. 42 us; four K slices + k_splitk_reduce (sum in fixed order, bias,
+// activation, head-major fp32 or planes) take ~half.  The N = 768 projections use proj_ln() below (no reduce launch at all).
+constexpr int64_t TINY_ROWS = 256;
+
 int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf16* w, const float* bias, int64_t M,
          int N, int K, int act, const GemmOut& out, const Planes* resid = nullptr, const int* m_dev = nullptr,
          const int* a_index = nullptr, RowMap rmap = RowMap{0, 0, 0}, const int* r_index = nullptr, int cls_bit = 0) {
     if (M <= 0) return MMS_OK;
     const int nsplit = (h->nsplit == 2 && (h->x1_mask & cls_bit)) ? 1 : h->nsplit;
     if (N % 128 || K % 64) return h->fail(MMS_ERR_ARG, "gemm: N % 128 or K % 64 != 0");
+    const bool tiny = M < TINY_ROWS && N >= 1536 && N % 256 == 0 && K == H && h->nsplit >= 2 && !h->f8 && !resid && out.cmap.grp == 0 && !(h->x1_mask & cls_bit);
     GemmParams p{};
     p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.amap = amap;
     p.w = w; p.bias = bias; p.M = (int)M; p.N = N; p.K = K;
@@ -584,18 +591,30 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     p.c_hi = out.pl.hi; p.c_lo = out.pl.lo; p.ldp = out.ldp; p.cmap = out.cmap;
     if (resid && !h->resid_in_ln) { p.r_hi = resid->hi; p.r_lo = resid->lo; p.ldr = H; }
     p.m_dev = m_dev; p.a_index = a_index; p.rmap = rmap; p.r_index = r_index;
+    constexpr int TINY_S = 4;
+    if (tiny) {      // K slices into fp32 partials; the reduce kernel below applies what the epilogue would have
+        if (int rc = ensure_kparts(h)) return rc;
+        p.bias = nullptr; p.act = ACT_NONE; p.out_kind = OUT_F32; p.c_f32 = h->kparts; p.ldc = N; p.hm_rows = 0; p.hm_col0 = 0;
+        p.k_splits = TINY_S; p.c_split_stride = (long long)TINY_ROWS * N;
+    }
+    auto tiny_reduce = [&]() {
+        if (tiny) launch_splitk_reduce(h->kparts, TINY_S, (long long)TINY_ROWS * N, (int)M, N, m_dev, bias, act, out.f32, out.ldc, out.hm_rows, out.hm_col0,
+                                       out.pl.hi, out.pl.lo, out.ldp, st);
+    };
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
     if (h->timing) {
         if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
         p.flop_counter = h->flop_counter;   // executed algorithmic FLOPs (2*M_live*N*K), counted on the device
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
         launch_gemm(p, nsplit, st);
+        tiny_reduce();
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
         h->ev_cls.resize(h->ev_used / 2 + 1); h->ev_cls[h->ev_used / 2] = 0;
         h->ev_used += 2;
         h->gemm_launches += 1;
     } else {
         launch_gemm(p, nsplit, st);
+        tiny_reduce();
     }
     return MMS_OK;
 }

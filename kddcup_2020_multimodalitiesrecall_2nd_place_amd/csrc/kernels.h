@@ -127,6 +127,9 @@ struct LnResid { const bf16* hi = nullptr; const bf16* lo = nullptr; int ld = 0;
 void launch_ln_to_planes(const float* in, int ld, const float* gamma, const float* beta,
                          bf16* o_hi, bf16* o_lo, int ldo, int M, hipStream_t st, const int* m_dev = nullptr, LnResid res = LnResid());
 void launch_split_f32(const float* in, bf16* o_hi, bf16* o_lo, long long n, hipStream_t st);
+// split-K reduce + epilogue: out = act(sum_s parts[s] + bias) as plain / head-major fp32 (c_f32) or split planes (c_hi / c_lo)
+void launch_splitk_reduce(const float* parts, int S, long long stride, int M, int N, const int* m_dev, const float* bias, int act, float* c_f32, int ldc,
+                          int hm_rows, int hm_col0, bf16* c_hi, bf16* c_lo, int ldp, hipStream_t st);
 void launch_planes_to_f32(const bf16* hi, const bf16* lo, float* out, long long n, hipStream_t st);
 void launch_tile_weights(const float* in, bf16* o_hi, bf16* o_lo, long long N, long long K, hipStream_t st);   // fp32 W[N][K] -> tiled bf16 (hi, optional lo)
 void launch_mean8(const float* in, float* out, int U, hipStream_t st);

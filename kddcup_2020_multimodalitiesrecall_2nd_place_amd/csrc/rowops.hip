@@ -131,6 +131,44 @@ void launch_ln_to_planes(const float* in, int ld, const float* gamma, const floa
     if (M > 0) hipLaunchKernelGGL(k_ln_to_planes, row_grid(M), dim3(256), 0, st, in, ld, gamma, beta, o_hi, o_lo, ldo, M, m_dev, res);
 }
 
+// Reduce + epilogue of a split-K GEMM launch whose consumer is NOT a LayerNorm (QKV, FFN-up at tiny M: api.hip gemm()): out = act(sum of the
+// S fp32 partials (fixed order) + bias), written as plain / head-major fp32 (the [Q | K | V] blocks of GemmParams::hm_rows) or as split planes.
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* parts, int S, long long stride, int M, int N, const int* m_dev, const float* bias, int act,
+                                                       float* c_f32, int ldc, int hm_rows, int hm_col0, bf16* c_hi, bf16* c_lo, int ldp) {
+    const int lim = m_dev ? min(M, *m_dev) : M;
+    const long long n4 = (long long)lim * (N / 4);
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const int row = (int)(i / (N / 4)), col = (int)(i % (N / 4)) * 4;
+        float4 v = *reinterpret_cast<const float4*>(parts + (long long)row * N + col);
+        for (int s = 1; s < S; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(parts + s * stride + (long long)row * N + col);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        const float y[4] = {apply_act(v.x, act), apply_act(v.y, act), apply_act(v.z, act), apply_act(v.w, act)};
+        if (c_f32) {
+            const int hc = hm_col0 + col;
+            float* dst = hm_rows ? c_f32 + ((long long)(hc >> 6) * hm_rows + row) * 64 + (hc & 63) : c_f32 + (long long)row * ldc + col;
+            *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
+        } else {
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bf16 a, c; split_bf16(y[e], a, c); h[e] = a; l[e] = c; }
+            const long long off = (long long)row * ldp + col;
+            *reinterpret_cast<bf16x4*>(plane_ptr(c_hi, off)) = h;
+            *reinterpret_cast<bf16x4*>(plane_ptr(c_lo, off)) = l;
+        }
+    }
+}
+void launch_splitk_reduce(const float* parts, int S, long long stride, int M, int N, const int* m_dev, const float* bias, int act, float* c_f32, int ldc,
+                          int hm_rows, int hm_col0, bf16* c_hi, bf16* c_lo, int ldp, hipStream_t st) {
+    const long long n4 = (long long)M * (N / 4);
+    if (n4 <= 0) return;
+    const long long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, parts, S, stride, M, N, m_dev, bias, act, c_f32, ldc,
+                       hm_rows, hm_col0, c_hi, c_lo, ldp);
+}
+
 __global__ __launch_bounds__(256) void k_ln_f32(const float* in, const float* gamma, const float* beta,
                                                 float* out, int M) {
     const int row = wave_row();

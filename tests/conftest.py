@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # weights.make_weights hands out read-only (memoised) arrays; the oracle wraps them in tensors it never writes to
+    config.addinivalue_line("filterwarnings", "ignore:The given NumPy array is not writable")
 
 
 @pytest.fixture(scope="session")

