@@ -138,6 +138,7 @@ struct mms_handle {
     size_t ev_used = 0;
     int64_t gemm_launches = 0;
     int64_t fused_attn_launches = 0;     // qkv_attn.hip launches since mms_create (mms_dbg_counter)
+    int64_t ln_fused_launches = 0, splitk_launches = 0;      // LayerNorm-fused GEMM launches / split-K launches (small-call routes) since mms_create
     std::vector<hipEvent_t> ev_fused; size_t ev_fused_used = 0; int64_t fused_timed = 0;     // timing of the fused launches, apart from the GEMMs' (mms_fused_timing)
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -594,6 +595,7 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     constexpr int TINY_S = 4;
     if (tiny) {      // K slices into fp32 partials; the reduce kernel below applies what the epilogue would have
         if (int rc = ensure_kparts(h)) return rc;
+        h->splitk_launches += 1;
         p.bias = nullptr; p.act = ACT_NONE; p.out_kind = OUT_F32; p.c_f32 = h->kparts; p.ldc = N; p.hm_rows = 0; p.hm_col0 = 0;
         p.k_splits = TINY_S; p.c_split_stride = (long long)TINY_ROWS * N;
     }
@@ -675,6 +677,7 @@ int gemm_ln(mms_handle* h, hipStream_t st, bool f8, const Planes& a, int lda, co
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
     const int* skip = p.ln_ctl + 1;
     h->ln_slot += 1;
+    h->ln_fused_launches += 1;
     if (h->timing) {
         if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
         p.flop_counter = h->flop_counter + 2;     // slot 2: the LayerNorm-fused launches (mms_gemm_timing adds it to the GEMM total)
@@ -755,6 +758,7 @@ int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap
     const int S = splitk_for(h, M, K);
     if (S > 1) {
         if (int rc = ensure_kparts(h)) return rc;
+        h->splitk_launches += 1;
         GemmParams p{};
         p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.amap = amap; p.a_index = a_index;
         p.w = w; p.M = (int)M; p.N = H; p.K = K; p.act = ACT_NONE;
@@ -1380,6 +1384,13 @@ int mms_create(const mms_config* cfg, mms_handle** out) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) { g_err = std::string("no HIP device: ") + hipGetErrorString(e); return MMS_ERR_HIP; }
     if (cfg->device < 0 || cfg->device >= ndev) { g_err = "bad device ordinal"; return MMS_ERR_ARG; }
+    {   // the kernels are written for gfx950 alone (160 KiB LDS per workgroup, v_mfma_f32_16x16x32_bf16, MX-scaled fp8 MFMA, global_load_lds b128,
+        // v_permlane16_swap): refuse any other device here instead of failing inside the first launch
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, cfg->device);
+        if (e != hipSuccess) { g_err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return MMS_ERR_HIP; }
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { g_err = std::string("device ") + std::to_string(cfg->device) + " is " + prop.gcnArchName + ": libmmscore is built for gfx950 (MI355X) only"; return MMS_ERR_HIP; }
+    }
     mms_handle* h = new mms_handle();
     h->cfg = *cfg;
     h->f8 = cfg->precision == 4;
@@ -1945,7 +1956,7 @@ __global__ void k_fill_random(float* p, long long n, unsigned seed) {
 
 int64_t mms_dbg_counter(mms_handle* h, int32_t which) {
     if (!h) return -1;
-    return which == 0 ? h->fused_attn_launches : -1;
+    return which == 0 ? h->fused_attn_launches : which == 1 ? h->ln_fused_launches : which == 2 ? h->splitk_launches : -1;
 }
 
 // GEMM micro-benchmark on random operands: returns the average kernel time (ms) over `iters` launches.
