@@ -1031,22 +1031,31 @@ int zk_label_features(mms_handle* h, hipStream_t st, const int32_t* uniq_ids, in
 // image tokens of pairs [p0, p0+n) (model_triple.py:189-195, pixelbert.py:449-452) -> fp32 [n*10,768] at h->qkv + n*10*768 (the
 // QKV buffer is idle until the encoder starts).  The split box features sit in the (still unused) FFN buffer unless the caller
 // already holds them (featp_shared: the fused three-model entry point splits them once for all members).
+// compact = true (packed single-model path): only the LIVE boxes are split / projected / combined; tok then holds them consecutively, pair b's at
+// row box_off[b] (h->pk_off[1]); their number is on the device (h->pk_rows + 1).
 int zk_image_tokens(mms_handle* h, hipStream_t st, const mms_zk_batch* b, const int32_t* label_index, int64_t p0, int64_t n,
-                    const Planes* featp_shared = nullptr) {
+                    const Planes* featp_shared = nullptr, bool compact = false) {
     const int64_t NB = n * MMS_NBOX;
     Planes featp = h->mid;
-    if (featp_shared) featp = *featp_shared;
+    const int* box_idx = nullptr;
+    const int* box_rows = nullptr;
+    if (compact) {      // stream 1's plan buffers are idle in a zk handle
+        launch_zk_box_plan(b->len_query + p0, b->num_boxes + p0, h->cfg.text_len, (int)n, h->pk_cnt[1], h->pk_off[1], h->pk_src[1], h->pk_rows + 1, st);
+        box_idx = h->pk_src[1]; box_rows = h->pk_rows + 1;
+        launch_split_f32_rows(b->feats + p0 * MMS_NBOX * MMS_FEAT, box_idx, box_rows, (int)NB, MMS_FEAT, featp.hi, featp.lo, st);
+    } else if (featp_shared) featp = *featp_shared;
     else launch_split_f32(b->feats + p0 * MMS_NBOX * MMS_FEAT, featp.hi, featp.lo, NB * MMS_FEAT, st);
     float* img = h->qkv;                 // [NB,768] fp32
     float* tok = h->qkv + NB * H;        // [NB,768] fp32
-    if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_conv2, h->b_conv2, NB, H, MMS_FEAT, ACT_RELU, to_f32(img, H))) return rc;
+    if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_conv2, h->b_conv2, NB, H, MMS_FEAT, ACT_RELU, to_f32(img, H), nullptr, box_rows)) return rc;
     launch_zk_tokpre(h->lab_feat, label_index + p0 * MMS_NBOX, (int)h->n_labels, b->boxes_5 + p0 * MMS_NBOX * 5, h->w_dense1, h->b_dense1,
-                     img, h->ctx.hi, h->ctx.lo, (int)NB, st);
-    return gemm(h, st, h->ctx, H, ID, h->w_femb, h->b_femb, NB, H, H, ACT_NONE, to_f32(tok, H));
+                     img, h->ctx.hi, h->ctx.lo, (int)NB, st, box_idx, box_rows);
+    return gemm(h, st, h->ctx, H, ID, h->w_femb, h->b_femb, NB, H, H, ACT_NONE, to_f32(tok, H), nullptr, box_rows);
 }
 
 // embeddings + encoder + pooler + AM-softmax head of pairs [p0, p0+n) on the image tokens `tok` [n*10,768]
-int zk_encode(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, int64_t n, const float* tok, float* logits, float* probs) {
+int zk_encode(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, int64_t n, const float* tok, float* logits, float* probs,
+              const int* box_off = nullptr) {
     const mms_config& c = h->cfg;
     const int T = c.text_len, S = T + MMS_NBOX;
     // --- embeddings + mask (packed: live tokens only, laid out contiguously) ---
@@ -1056,7 +1065,7 @@ int zk_encode(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, 
                             h->pk_rows, st);
         pk.off = h->pk_off[0]; pk.cnt = h->pk_cnt[0]; pk.rows = h->pk_rows;
         launch_zk_embed_packed(h->E, h->type_tab, h->pos_tab, h->emb_g, h->emb_b, b->query_ids + p0 * T, b->segment_ids + p0 * S, tok,
-                               T, c.vocab, h->pk_src[0], h->pk_rows, (int)(n * S), h->x.hi, h->x.lo, st);
+                               T, c.vocab, h->pk_src[0], h->pk_rows, (int)(n * S), h->x.hi, h->x.lo, st, box_off);
     } else {
         launch_zk_embed(h->E, h->type_tab, h->pos_tab, h->emb_g, h->emb_b, b->query_ids + p0 * T, b->segment_ids + p0 * S, tok, T,
                         c.vocab, h->x.hi, h->x.lo, (int)n, st);
@@ -1085,8 +1094,13 @@ int zk_encode(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, 
 }
 
 int zk_chunk(mms_handle* h, hipStream_t st, const mms_zk_batch* b, const int32_t* label_index, int64_t p0, int64_t n, float* logits, float* probs) {
-    if (int rc = zk_image_tokens(h, st, b, label_index, p0, n)) return rc;
-    return zk_encode(h, st, b, p0, n, h->qkv + n * MMS_NBOX * H, logits, probs);
+    bool compact = h->cfg.pack_tokens != 0;
+#ifdef MMS_LAB
+    static const bool no_compact = getenv("MMS_NO_BOX_COMPACT") != nullptr;      // A/B: image-token stage on all 10 box rows of every pair
+    if (no_compact) compact = false;
+#endif
+    if (int rc = zk_image_tokens(h, st, b, label_index, p0, n, nullptr, compact)) return rc;
+    return zk_encode(h, st, b, p0, n, h->qkv + n * MMS_NBOX * H, logits, probs, compact ? h->pk_off[1] : nullptr);
 }
 
 int lds_chunk(mms_handle* h, hipStream_t st, const mms_lds_batch* b, int64_t p0, int64_t n, float* logits, float* probs,
@@ -1230,22 +1244,31 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
     float* visn_add = h->key_add2;
     Pack pl, pv;
     Planes featp = h->mid;
-    if (featp_shared) featp = *featp_shared;
-    else launch_split_f32(b->feats + p0 * V * MMS_FEAT, featp.hi, featp.lo, MV * MMS_FEAT, st);
     float* xf = h->qkv;
-    if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_visn, h->b_visn, MV, H, MMS_FEAT, ACT_NONE, to_f32(xf, H))) return rc;
+    // packed single-model path: the vision plan comes first and visn_fc runs on the LIVE boxes only (features split by gather, projection with the
+    // device-side row count): the masked boxes -- 62 % of the rows on the bench batch -- cannot reach a logit
+    bool compact = c.pack_tokens && !featp_shared;
+#ifdef MMS_LAB
+    { static const bool no_compact = getenv("MMS_NO_BOX_COMPACT") != nullptr; if (no_compact) compact = false; }
+#endif
     if (c.pack_tokens) {
         launch_lx_pack_plan(b->input_mask + p0 * T, b->visual_attention_mask + p0 * V, T, (int)n, h->pk_off[0], h->pk_cnt[0],
                             h->pk_src[0], lang_add, h->pk_rows, h->pk_off[1], h->pk_cnt[1], h->pk_src[1], visn_add, h->pk_rows + 1, st);
         pl.off = h->pk_off[0]; pl.cnt = h->pk_cnt[0]; pl.rows = h->pk_rows;
         pv.off = h->pk_off[1]; pv.cnt = h->pk_cnt[1]; pv.rows = h->pk_rows + 1;
+    }
+    if (compact) launch_split_f32_rows(b->feats + p0 * V * MMS_FEAT, h->pk_src[1], h->pk_rows + 1, (int)MV, MMS_FEAT, featp.hi, featp.lo, st);
+    else if (featp_shared) featp = *featp_shared;
+    else launch_split_f32(b->feats + p0 * V * MMS_FEAT, featp.hi, featp.lo, MV * MMS_FEAT, st);
+    if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_visn, h->b_visn, MV, H, MMS_FEAT, ACT_NONE, to_f32(xf, H), nullptr, compact ? h->pk_rows + 1 : nullptr)) return rc;
+    if (c.pack_tokens) {
         if (h->lq_active)   // language rows after the l_layers, copied from the distinct-query store (pair p0 + src / T, token src % T)
             launch_rows_gather(h->lq_store.hi, h->lq_store.lo, h->pk_src[0], h->lq_index + p0, T, h->pk_rows, (int)ML, h->x.hi, h->x.lo, st);
         else
             launch_lx_embed_lang_packed(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->pk_src[0],
                                         h->pk_rows, (int)ML, h->x.hi, h->x.lo, st);
         launch_lx_visn(xf, h->g_visn, h->be_visn, b->boxes + p0 * V * 4, 4, h->w_box, h->b_box, h->g_box, h->be_box, h->lab_feat,
-                       label_index + p0 * V, (int)h->n_labels, h->x.at(ML * H).hi, h->x.at(ML * H).lo, (int)MV, st, h->pk_src[1], h->pk_rows + 1);
+                       label_index + p0 * V, (int)h->n_labels, h->x.at(ML * H).hi, h->x.at(ML * H).lo, (int)MV, st, h->pk_src[1], h->pk_rows + 1, compact ? 1 : 0);
     } else {
         launch_lx_masks(b->input_mask + p0 * T, b->visual_attention_mask + p0 * V, T, lang_add, visn_add, (int)n, st);
         launch_lx_embed_lang(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->x.hi, h->x.lo, (int)n, st);

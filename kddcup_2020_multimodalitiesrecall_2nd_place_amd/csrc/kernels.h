@@ -137,7 +137,11 @@ void launch_mean8(const float* in, float* out, int U, hipStream_t st);
 // zk (code/imagebert_zk/model_triple.py:162-214, pixelbert.py:541-621)
 void launch_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab, bf16* o_hi, bf16* o_lo, hipStream_t st);
 void launch_zk_tokpre(const float* labfeat, const int* lab_index, int n_labels, const float* boxes5, const float* Wd,
-                      const float* bd, const float* img, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st);
+                      const float* bd, const float* img, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st,
+                      const int* src = nullptr, const int* rows_dev = nullptr);      // src: compact rows, row r stands for box src[r]; r < *rows_dev
+// live boxes of a packed zk wave: cnt / off per pair, box_idx[off[b] + j] = b * 10 + j, *rows_dev = their number (rowops.hip)
+void launch_zk_box_plan(const int* len_query, const int* num_boxes, int T, int n, int* cnt, int* off, int* box_idx, int* rows_dev, hipStream_t st);
+void launch_split_f32_rows(const float* in, const int* idx, const int* rows_dev, int max_rows, int width, bf16* o_hi, bf16* o_lo, hipStream_t st);
 void launch_zk_embed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
                      const float* beta, const int* query_ids, const int* segment_ids, const float* tok,
                      int T, int vocab, bf16* o_hi, bf16* o_lo, int B, hipStream_t st);
@@ -148,7 +152,7 @@ void launch_zk_pack_plan(const int* len_query, const int* num_boxes, int T, int 
 void launch_zk_embed_packed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
                             const float* beta, const int* query_ids, const int* segment_ids, const float* tok,
                             int T, int vocab, const int* tok_src, const int* rows_dev, int max_rows,
-                            bf16* o_hi, bf16* o_lo, hipStream_t st);
+                            bf16* o_hi, bf16* o_lo, hipStream_t st, const int* box_off = nullptr);      // box_off: tok holds live boxes only, pair b's at row box_off[b]
 // lds: identical feature / label token rows of a pair merged, multiplicity as an additive log on the key (rowops.hip)
 void launch_lds_pack_plan(const float* feats, const int64_t* labelfeat, int T, int n, int* nz_flags, int* off, int* cnt, int* tok_src,
                           float* key_add, int* rows_dev, hipStream_t st);
@@ -181,7 +185,7 @@ void launch_lx_label_emb(const float* E, const float* pos_tab, const float* type
 void launch_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes, int box_dim,
                     const float* Wb, const float* bb, const float* g_y, const float* b_y, const float* z,
                     const int* lab_index, int n_labels, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st,
-                    const int* src = nullptr, const int* rows_dev = nullptr);
+                    const int* src = nullptr, const int* rows_dev = nullptr, int xf_compact = 0);   // xf_compact: xf row = OUTPUT row (projection ran on the live boxes only)
 void launch_ln_f32(const float* in, const float* gamma, const float* beta, float* out, int M, hipStream_t st);
 void launch_lx_masks(const int64_t* input_mask, const float* visual_mask, int T, float* lang_add,
                      float* visn_add, int B, hipStream_t st);

@@ -417,21 +417,42 @@ void launch_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab, bf1
 // model_triple.py:190-195: mean(relu(conv1)) [by unique label] + kdd_dense1(boxes_5) + relu(conv2(feats))
 __global__ __launch_bounds__(256) void k_zk_tokpre(const float* labfeat, const int* lab_index, int n_labels, const float* boxes5,
                                                    const float* Wd, const float* bd, const float* img,
-                                                   bf16* o_hi, bf16* o_lo, int rows) {
+                                                   bf16* o_hi, bf16* o_lo, int rows, const int* src, const int* rows_dev) {
     const int row = wave_row();
-    if (row >= rows) return;
+    if (row >= rows || (rows_dev && row >= *rows_dev)) return;
+    const int box = src ? src[row] : row;      // compact rows (live boxes only): img / output by row, label and geometry by the box it stands for
     Row x;
-    row_load(x, labfeat + clamp_id(lab_index[row], n_labels) * MMS_HIDDEN);   // a bad index must not read outside the table
+    row_load(x, labfeat + clamp_id(lab_index[box], n_labels) * MMS_HIDDEN);   // a bad index must not read outside the table
     row_add(x, bd);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) row_axpy(x, boxes5[(long long)row * 5 + k], Wd + k * MMS_HIDDEN);
+    for (int k = 0; k < 5; ++k) row_axpy(x, boxes5[(long long)box * 5 + k], Wd + k * MMS_HIDDEN);
     row_add(x, img + (long long)row * MMS_HIDDEN);
     row_store_planes(x, plane_ptr(o_hi, (long long)row * MMS_HIDDEN), plane_ptr(o_lo, (long long)row * MMS_HIDDEN));
 }
 void launch_zk_tokpre(const float* labfeat, const int* lab_index, int n_labels, const float* boxes5, const float* Wd,
-                      const float* bd, const float* img, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st) {
+                      const float* bd, const float* img, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st, const int* src, const int* rows_dev) {
     if (rows > 0)
-        hipLaunchKernelGGL(k_zk_tokpre, row_grid(rows), dim3(256), 0, st, labfeat, lab_index, n_labels, boxes5, Wd, bd, img, o_hi, o_lo, rows);
+        hipLaunchKernelGGL(k_zk_tokpre, row_grid(rows), dim3(256), 0, st, labfeat, lab_index, n_labels, boxes5, Wd, bd, img, o_hi, o_lo, rows, src, rows_dev);
+}
+
+// fp32 rows [*][width] -> split planes of the rows listed in idx (compact: output row r = input row idx[r]), r < *rows_dev; width % 256 == 0
+__global__ __launch_bounds__(256) void k_split_f32_rows(const float* in, const int* idx, const int* rows_dev, int max_rows, int width, bf16* o_hi, bf16* o_lo) {
+    const int row = wave_row();
+    if (row >= max_rows || row >= *rows_dev) return;
+    const float* src = in + (long long)idx[row] * width;
+    for (int t = 0; t < width / 256; ++t) {
+        const float4 f = *reinterpret_cast<const float4*>(src + t * 256 + lane_id() * 4);
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bf16 a, c; split_bf16(v[e], a, c); h[e] = a; l[e] = c; }
+        const long long off = (long long)row * width + t * 256 + lane_id() * 4;
+        *reinterpret_cast<bf16x4*>(plane_ptr(o_hi, off)) = h;
+        *reinterpret_cast<bf16x4*>(plane_ptr(o_lo, off)) = l;
+    }
+}
+void launch_split_f32_rows(const float* in, const int* idx, const int* rows_dev, int max_rows, int width, bf16* o_hi, bf16* o_lo, hipStream_t st) {
+    if (max_rows > 0) hipLaunchKernelGGL(k_split_f32_rows, row_grid(max_rows), dim3(256), 0, st, in, idx, rows_dev, max_rows, width, o_hi, o_lo);
 }
 
 // pixelbert.py:580-621: concat text || image tokens, + token_type[segment_ids], + positions
@@ -656,12 +677,12 @@ void launch_lx_label_emb(const float* E, const float* pos_tab, const float* type
 __global__ __launch_bounds__(256) void k_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes,
                                                  int box_dim, const float* Wb, const float* bb, const float* g_y,
                                                  const float* b_y, const float* z, const int* lab_index, int n_labels,
-                                                 bf16* o_hi, bf16* o_lo, int rows, const int* src_map, const int* rows_dev) {
+                                                 bf16* o_hi, bf16* o_lo, int rows, const int* src_map, const int* rows_dev, int xf_compact) {
     const int orow = wave_row();
     if (orow >= rows || (rows_dev && orow >= *rows_dev)) return;
     const int row = src_map ? src_map[orow] : orow;   // packed mode: output row orow <- box row src_map[orow]
     Row x, y;
-    row_load(x, xf + (long long)row * MMS_HIDDEN);
+    row_load(x, xf + (long long)(xf_compact ? orow : row) * MMS_HIDDEN);      // xf_compact: the visn_fc projection ran on the live boxes only, in output order
     row_ln(x, g_x, b_x);
     row_load(y, bb);
     for (int k = 0; k < box_dim; ++k) {
@@ -682,10 +703,10 @@ __global__ __launch_bounds__(256) void k_lx_visn(const float* xf, const float* g
 void launch_lx_visn(const float* xf, const float* g_x, const float* b_x, const float* boxes, int box_dim,
                     const float* Wb, const float* bb, const float* g_y, const float* b_y, const float* z,
                     const int* lab_index, int n_labels, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st, const int* src,
-                    const int* rows_dev) {
+                    const int* rows_dev, int xf_compact) {
     if (rows > 0)
         hipLaunchKernelGGL(k_lx_visn, row_grid(rows), dim3(256), 0, st, xf, g_x, b_x, boxes, box_dim, Wb, bb, g_y, b_y, z,
-                           lab_index, n_labels, o_hi, o_lo, rows, src, rows_dev);
+                           lab_index, n_labels, o_hi, o_lo, rows, src, rows_dev, xf_compact);
 }
 
 // modeling.py:890-910: additive masks (1 - m) * -10000 for language and visual keys
@@ -816,18 +837,39 @@ void launch_zk_pack_plan(const int* len_query, const int* num_boxes, int T, int 
     hipLaunchKernelGGL(k_zk_plan_fill, grid, dim3(256), 0, st, len_query, num_boxes, T, n, off, tok_src, key_add);
 }
 
+// Live boxes of a zk launch wave (packed mode): pair b keeps nv(b) image tokens -- min(num_boxes, 10), or all 10 when nothing of the pair is
+// live (k_zk_plan_fill's rule) -- so only those boxes' 2048-d features are split, projected (kdd_conv2, kdd_featureemb) and combined; the
+// padded ones (62 % of the rows on the bench batch) cannot reach a logit.  box_idx[r] = b * 10 + j for compact row r = box_off[b] + j.
+__global__ __launch_bounds__(256) void k_zk_box_count(const int* len_query, const int* num_boxes, int T, int n, int* cnt) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    const int lq = min(max(len_query[b], 0), T), nb = min(max(num_boxes[b], 0), MMS_NBOX);
+    cnt[b] = (lq + nb == 0) ? MMS_NBOX : nb;
+}
+__global__ __launch_bounds__(256) void k_zk_box_fill(const int* cnt, const int* off, int n, int* box_idx) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    for (int j = 0; j < cnt[b]; ++j) box_idx[off[b] + j] = b * MMS_NBOX + j;
+}
+void launch_zk_box_plan(const int* len_query, const int* num_boxes, int T, int n, int* cnt, int* off, int* box_idx, int* rows_dev, hipStream_t st) {
+    if (n <= 0) return;
+    const dim3 grid((n + 255) / 256);
+    hipLaunchKernelGGL(k_zk_box_count, grid, dim3(256), 0, st, len_query, num_boxes, T, n, cnt);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PLAN_THREADS), 0, st, cnt, n, off, rows_dev);
+    hipLaunchKernelGGL(k_zk_box_fill, grid, dim3(256), 0, st, cnt, off, n, box_idx);
+}
 __global__ __launch_bounds__(256) void k_zk_embed_packed(const float* E, const float* type_tab, const float* pos_tab,
                                                          const float* gamma, const float* beta, const int* query_ids,
                                                          const int* segment_ids, const float* tok, int T, int vocab,
                                                          const int* tok_src, const int* rows_dev, int max_rows,
-                                                         bf16* o_hi, bf16* o_lo) {
+                                                         bf16* o_hi, bf16* o_lo, const int* box_off) {
     const int S = T + MMS_NBOX;
     const int row = wave_row();
     if (row >= max_rows || row >= *rows_dev) return;
     const int src = tok_src[row], b = src / S, s = src % S;
     Row x;
     if (s < T) row_load(x, E + clamp_id(query_ids[b * T + s], vocab) * MMS_HIDDEN);
-    else row_load(x, tok + ((long long)b * MMS_NBOX + (s - T)) * MMS_HIDDEN);
+    else row_load(x, tok + ((box_off ? (long long)box_off[b] : (long long)b * MMS_NBOX) + (s - T)) * MMS_HIDDEN);      // box_off: image tokens of live boxes only (compact)
     row_add(x, type_tab + clamp_id(segment_ids[src], 2) * MMS_HIDDEN);
     row_add(x, pos_tab + (s < T ? s : T) * MMS_HIDDEN);
     row_ln(x, gamma, beta);
@@ -836,10 +878,10 @@ __global__ __launch_bounds__(256) void k_zk_embed_packed(const float* E, const f
 void launch_zk_embed_packed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
                             const float* beta, const int* query_ids, const int* segment_ids, const float* tok, int T,
                             int vocab, const int* tok_src, const int* rows_dev, int max_rows, bf16* o_hi, bf16* o_lo,
-                            hipStream_t st) {
+                            hipStream_t st, const int* box_off) {
     if (max_rows > 0)
         hipLaunchKernelGGL(k_zk_embed_packed, row_grid(max_rows), dim3(256), 0, st, E, type_tab, pos_tab, gamma, beta, query_ids,
-                           segment_ids, tok, T, vocab, tok_src, rows_dev, max_rows, o_hi, o_lo);
+                           segment_ids, tok, T, vocab, tok_src, rows_dev, max_rows, o_hi, o_lo, box_off);
 }
 
 // lds has no attention mask (pixelmodel.py:189-190): all 40 tokens of a pair attend and are attended.  But its 10 feature tokens and

@@ -365,7 +365,8 @@ def test_lxmert_distinct_query_stage_equals_per_pair_scoring():
         single = np.concatenate([scorers.score_batch(s, {k: v[i:i + 1] for k, v in b.items()})[0].cpu().numpy() for i in range(ps.n)])
         s.close()
         assert vecrel(batch, ref).max() < TOL_P2
-        assert np.abs(batch - single).max() < 1e-5, np.abs(batch - single).max()
+        # (1-pair calls run the tiny-launch route -- wide projections split over K, api.hip TINY_ROWS -- the batch does not: fp32 summation order)
+        assert np.abs(batch - single).max() < 1e-4, np.abs(batch - single).max()
     s = scorers.LxmertScorer(cfg, w, precision=4)      # the fp8 mode goes through the same stage
     assert np.isfinite(scorers.score_batch(s, b)[0].cpu().numpy()).all()
     s.close()
