@@ -16,7 +16,7 @@ VARY = len(sys.argv) > 4 and sys.argv[4] == "vary"
 
 
 class A:
-    precision = PREC; chunk = 0; fp32_weights = False; fuse_ln = False; dense = False; all_boxes = False; fuse_attn = 2 if PREC == 2 else 0
+    precision = PREC; chunk = 0; fp32_weights = False; fuse_ln = -1; dense = False; all_boxes = False; fuse_attn = -1      # library defaults
 
 
 dev = torch.device("cuda", 0)
