@@ -104,8 +104,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                 sc[jt][qt][r] = v;
                 m = fmaxf(m, v);
             }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows4_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int jt = 0; jt < KT; ++jt)
@@ -115,8 +114,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                 sc[jt][qt][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows4_sum(sum);
         const float inv = 1.0f / sum;
 #pragma unroll
         for (int jt = 0; jt < KT; ++jt)

@@ -121,6 +121,26 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Reductions over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48; every lane gets the result) on v_permlane16_swap /
+// v_permlane32_swap: VALU, where __shfl_xor(v, 16 / 32) is a ds_bpermute round trip through the LDS crossbar.  Same operations in the same
+// order as  v = op(v, shfl_xor(v, 16)); v = op(v, shfl_xor(v, 32))  (op commutative), so results are bit-identical to the shuffle form.
+__device__ __forceinline__ float rows4_sum(float v) {
+    unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // {rows 0 0 2 2, rows 1 1 3 3}
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    u = __float_as_uint(v);
+    const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // {low low, high high}
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows4_max(float v) {
+    unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    u = __float_as_uint(v);
+    const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // row remap: logical row r -> physical row (r / grp) * stride + off + r % grp   (grp == 0: identity)
 struct RowMap {
     int grp, stride, off;

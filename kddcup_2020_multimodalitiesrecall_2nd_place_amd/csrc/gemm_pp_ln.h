@@ -25,18 +25,6 @@ __device__ __forceinline__ unsigned long long ln_granule(float v, unsigned tag) 
     return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
 }
 
-// v summed over the four 16-lane rows of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48), every lane gets the total: v_permlane16_swap /
-// v_permlane32_swap (VALU) instead of two ds_bpermute round trips -- the epilogue does this 16 times per lane in a dependent chain
-// (32 LDS crossbar latencies ~ 1.5 us per tile).  Same additions in the same order as v += shfl_xor(v, 16); v += shfl_xor(v, 32).
-__device__ __forceinline__ float ln_rows_sum(float v) {
-    unsigned u = __float_as_uint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // {rows 0 0 2 2, rows 1 1 3 3}
-    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    u = __float_as_uint(v);
-    const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // {low low, high high}
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
 // 1 = fused, 2 = plain; decided once per launch (a CAS), identical for every workgroup.  Called by every wave at kernel entry, after
 // its workgroup's check-in: fused as soon as all gridDim.x workgroups are in, plain if they are not within ~30 us (wall_clock64 ticks
 // at 100 MHz) -- a workgroup that arrives later than that just reads the decision.
@@ -111,7 +99,7 @@ __device__ __forceinline__ void pp_epilogue_ln(const GemmParams& p, f32x4 (&acc)
             for (int e = 0; e < 4; ++e) { ss += acc[i][j][e]; qq += acc[i][j][e] * acc[i][j][e]; }
         }
         if (row0 + 16 * i + mrow >= Meff) { ss = 0.f; qq = 0.f; }
-        ss = ln_rows_sum(ss); qq = ln_rows_sum(qq);
+        ss = rows4_sum(ss); qq = rows4_sum(qq);      // common.h: v_permlane16/32_swap, not ds_bpermute (16 dependent reductions per lane: ~1 us per tile)
         if (nq == 0) red[wn * 256 + wm * 128 + 16 * i + mrow] = float2{ss, qq};
     }
     __syncthreads();

@@ -442,8 +442,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                                 sc[jt][r] = v;
                                 m = fmaxf(m, v);
                             }
-                        m = fmaxf(m, __shfl_xor(m, 16, 64));
-                        m = fmaxf(m, __shfl_xor(m, 32, 64));
+                        m = rows4_max(m);
                         float sum = 0.f;
 #pragma unroll
                         for (int jt = 0; jt < MAXT; ++jt)
@@ -453,8 +452,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                                 sc[jt][r] = e;
                                 sum += e;
                             }
-                        sum += __shfl_xor(sum, 16, 64);
-                        sum += __shfl_xor(sum, 32, 64);
+                        sum = rows4_sum(sum);
                         const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
                         for (int jt = 0; jt < MAXT; ++jt)
@@ -550,8 +548,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                             sc[jt][r] = v;
                             m = fmaxf(m, v);
                         }
-                    m = fmaxf(m, __shfl_xor(m, 16, 64));
-                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    m = rows4_max(m);
                     float sum = 0.f;
 #pragma unroll
                     for (int jt = 0; jt < MAXT; ++jt)
@@ -561,8 +558,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                             sc[jt][r] = e;
                             sum += e;
                         }
-                    sum += __shfl_xor(sum, 16, 64);
-                    sum += __shfl_xor(sum, 32, 64);
+                    sum = rows4_sum(sum);
                     const float inv = 1.0f / sum;
 #pragma unroll
                     for (int jt = 0; jt < MAXT; ++jt)
