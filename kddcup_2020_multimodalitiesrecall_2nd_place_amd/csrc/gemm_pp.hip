@@ -230,10 +230,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
             d = smem + slot * SLOT + NSPLIT * PLANE + h * 8192 + wave * 1024;
             if constexpr (LNF) {
                 // tile row (bn * 16 + h * 8 + wave) of the tiled weights is wave-uniform; the lane's part of the address is one register.
-                // Residual stages: the W region is not read (any valid source keeps the piece count uniform)
+                // (Residual stages fetch no W piece at all: stage(), NRES_NEXT)
                 int w_lane = (gr_l << 5) + (gc ^ pp_swz(gr_l)) * 8;
                 asm volatile("" : "+v"(w_lane));      // a seat's bn never changes: without this the W addresses of every piece are hoisted out of the tile loop (10 registers)
-                s = p.w + (((long long)(bn * 16 + h * 8 + wave) * (p.K >> 5) + (kst >= nk_main ? 0 : kst)) << 9) + w_lane;
+                s = p.w + (((long long)(bn * 16 + h * 8 + wave) * (p.K >> 5) + kst) << 9) + w_lane;
             } else s = w_src[h] + kst * WSTEP;
         }
         __builtin_amdgcn_global_load_lds((glb_void*)s, (lds_void*)d, 16, 0, 0);
@@ -280,10 +280,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     // RES (LNF): a residual stage -- W is the identity, so only the wave column that owns the stage's 32 output columns (stage j of the
     // eight: columns 32 j .. 32 j + 31 = half nh = j & 1 of wave column j >> 1) has anything to add: it runs the two quadrants (A0, B_nh),
     // (A1, B_nh) = 16 + 16 MFMAs; the other waves only keep the ring and the barriers going
-    auto stage = [&](auto pre_tag, auto wait_tag, auto res_tag, int s, int slot) {
+    // NRES_NEXT (LNF): the stage issued during this one (s + D) is a residual stage: only its A pieces are fetched (its W is the identity built in
+    // registers), and the counted wait allows exactly that many pieces to stay in flight
+    auto stage = [&](auto pre_tag, auto wait_tag, auto res_tag, auto nres_tag, int s, int slot) {
         constexpr bool PRE = decltype(pre_tag)::value;
         constexpr int WAITN = decltype(wait_tag)::value;
         constexpr bool RES = decltype(res_tag)::value;
+        constexpr int PI = decltype(nres_tag)::value ? NAP : P;      // pieces of stage s + D
         const int rj = RES ? s - nk_main : 0;
         const bool own = !RES || wn == (rj >> 1);
         const bool rh1 = RES && (rj & 1);      // owner of a residual stage: which half of its columns
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         } else if (RD) { read_b(sb, 0, b0); read_b(sb, 1, b1); read_a(sb, 0); }
         if (DMA) {
 #pragma unroll
-            for (int q = 0; q < P / 2; ++q) issue(q, s + D, nslot);
+            for (int q = 0; q < PI / 2; ++q) issue(q, s + D, nslot);
         }
         bar();
         if constexpr (RES) {
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
         if (RD && own) read_a(sb, 1);
         if (DMA) {
 #pragma unroll
-            for (int q = P / 2; q < P; ++q) issue(q, s + D, nslot);
+            for (int q = PI / 2; q < PI; ++q) issue(q, s + D, nslot);
         }
         if (WAITN >= 0) pp_wait_vmcnt<(WAITN >= 0 && !(DIAG & 2) ? WAITN : 0)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -405,17 +408,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         int slot = 0, s = 0;
-        auto run_stages = [&](auto res_tag, int s_end) {      // stages [s, s_end) of this kind, every one followed by at least D more
+        auto run_stages = [&](auto res_tag, auto nres_tag, int s_end) {      // stages [s, s_end) of this kind, every one followed by at least D more
+            constexpr int PI = decltype(nres_tag)::value ? NAP : P;
             for (; s < s_end; ++s) {
-                stage(std::true_type{}, std::integral_constant<int, (D - 1) * P>{}, res_tag, s, slot);
+                stage(std::true_type{}, std::integral_constant<int, (D - 1) * PI>{}, res_tag, nres_tag, s, slot);
                 slot = slot == NSLOT - 1 ? 0 : slot + 1;
             }
         };
         // tail: R stages still to come after this one -> R-1 of them may stay in flight; the last stage waits for nothing
         auto tail = [&](auto r_tag, auto res_tag) {
             constexpr int R = decltype(r_tag)::value;
+            constexpr int PT = decltype(res_tag)::value ? NAP : P;      // pieces of the stages still in flight (all of one kind inside a tail)
             if (ns - 1 - s == R) {
-                stage(std::false_type{}, std::integral_constant<int, R >= 1 ? (R - 1) * P : -1>{}, res_tag, s, slot);
+                stage(std::false_type{}, std::integral_constant<int, R >= 1 ? (R - 1) * PT : -1>{}, res_tag, res_tag, s, slot);
                 slot = slot == NSLOT - 1 ? 0 : slot + 1;
                 ++s;
             }
@@ -427,12 +432,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
             tail(std::integral_constant<int, 0>{}, res_tag);
         };
         if (LNF && ns > nk_main) {      // the product's stages, then the residual stages (NRES > D: the tail lies inside them)
-            static_assert(!LNF || NRES > D, "the K loop's tail must lie inside the residual stages");
-            run_stages(std::false_type{}, nk_main);
-            run_stages(std::integral_constant<bool, LNF>{}, ns - D);
-            tails(std::integral_constant<bool, LNF>{});
+            static_assert(!LNF || (NRES > D && D == 2), "the K loop's tail must lie inside the residual stages");
+            constexpr auto T = std::integral_constant<bool, LNF>{};
+            run_stages(std::false_type{}, std::false_type{}, nk_main - D);      // product stages that prefetch product stages
+            run_stages(std::false_type{}, T, nk_main);                          // the last D of them prefetch residual stages: A pieces only
+            run_stages(T, T, ns - D);
+            tails(T);
         } else {
-            run_stages(std::false_type{}, ns - D);
+            run_stages(std::false_type{}, std::false_type{}, ns - D);
             tails(std::false_type{});
         }
         if (wave < NW / 2) pp_barrier();     // re-align the two halves: nobody reads the ring any more
