@@ -996,14 +996,16 @@ int ensure_dedup_ws(mms_handle* h, int64_t rows) {
 // Finds the distinct tuples of ids[rows][8] (T = int32_t: zk feed, int64_t: lxmert feed): h->dd_uniq32 / dd_uniq64 hold them,
 // h->dd_index the row -> tuple index.  *U needs the count on the host: one 4-byte read + stream sync (the dense feed's price;
 // callers that pass uniq_label_ids / label_index themselves stay fully asynchronous).
+// async = true: no read-back -- *U is set to the upper bound `rows`, the count stays on the device (h->dd_counter[0]; zk small calls)
 template <typename T>
-int dedup_labels(mms_handle* h, hipStream_t st, const T* ids, int64_t rows, int64_t* U) {
+int dedup_labels(mms_handle* h, hipStream_t st, const T* ids, int64_t rows, int64_t* U, bool async = false) {
     if (rows > (int64_t)1 << 30) return h->fail(MMS_ERR_ARG, "too many label tuples in one call");
     if (int rc = ensure_dedup_ws(h, rows)) return rc;
     if constexpr (sizeof(T) == 4)
         launch_label_dedup_i32((const int32_t*)ids, (int)rows, h->dd_slots, h->dd_cap, h->dd_rep, h->dd_uid, h->dd_counter, h->dd_uniq32, h->dd_uniq64, h->dd_index, st);
     else
         launch_label_dedup_i64((const int64_t*)ids, (int)rows, h->dd_slots, h->dd_cap, h->dd_rep, h->dd_uid, h->dd_counter, h->dd_uniq32, h->dd_uniq64, h->dd_index, st);
+    if (async) { *U = rows; return MMS_OK; }
     int n = 0;
     HIP_TRY(h, hipMemcpyAsync(&n, h->dd_counter, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
@@ -1014,10 +1016,21 @@ int dedup_labels(mms_handle* h, hipStream_t st, const T* ids, int64_t rows, int6
 // ------------------------------------------------------------------------------------------------
 // zk forward
 // ------------------------------------------------------------------------------------------------
-int zk_label_features(mms_handle* h, hipStream_t st, const int32_t* uniq_ids, int64_t U) {
+// U_dev != nullptr (small calls, U <= LAB_CHUNK): U is only an upper bound, the number of distinct tuples is on the device -- the kernels
+// stop at it and the call never waits for the GPU (the dense-feed read-back of the large calls costs nothing there, but it kept every
+// 1-pair call of the reference's zk driver from being asynchronous)
+int zk_label_features(mms_handle* h, hipStream_t st, const int32_t* uniq_ids, int64_t U, const int* U_dev = nullptr) {
     if (int rc = ensure_label_ws(h, U)) return rc;
     h->n_labels = U;
     const int KD = MMS_LABEL_LEN * H;
+    if (U_dev) {
+        launch_zk_im2col(h->E, uniq_ids, (int)U, h->cfg.vocab, h->lab_planes.hi, h->lab_planes.lo, st, U_dev);
+        launch_scale_count(U_dev, MMS_LABEL_LEN, h->dd_counter + 1, st);
+        if (int rc = gemm(h, st, h->lab_planes, KD, ID, h->w_conv1, h->b_conv1, U * MMS_LABEL_LEN, H, KD, ACT_RELU, to_f32(h->lab_f32, H), nullptr,
+                          h->dd_counter + 1)) return rc;
+        launch_mean8(h->lab_f32, h->lab_feat, (int)U, st, U_dev);
+        return MMS_OK;
+    }
     for (int64_t u0 = 0; u0 < U; u0 += h->lab_cap) {
         const int64_t n = (U - u0) < h->lab_cap ? (U - u0) : h->lab_cap;
         launch_zk_im2col(h->E, uniq_ids + u0 * MMS_LABEL_LEN, (int)n, h->cfg.vocab, h->lab_planes.hi, h->lab_planes.lo, st);
@@ -1492,12 +1505,15 @@ int mms_score_zk(mms_handle* h, const mms_zk_batch* b, float* logits, float* pro
     const int32_t* uniq = b->uniq_label_ids;
     const int32_t* index = b->label_index;
     int64_t U = b->n_uniq_labels;
+    const int* U_dev = nullptr;
     if (!uniq) {
-        if (int rc = dedup_labels<int32_t>(h, st, b->label_ids, B * MMS_NBOX, &U)) return rc;
+        const bool async = B * MMS_NBOX <= 512;      // calls of <= 51 pairs (the label workspace is sized for the upper bound): device-side count, no read-back
+        if (int rc = dedup_labels<int32_t>(h, st, b->label_ids, B * MMS_NBOX, &U, async)) return rc;
         uniq = h->dd_uniq32; index = h->dd_index;
+        if (async) U_dev = h->dd_counter;
     }
     if (int rc = ln_begin_call(h, st)) return rc;
-    if (int rc = zk_label_features(h, st, uniq, U)) return rc;
+    if (int rc = zk_label_features(h, st, uniq, U, U_dev)) return rc;
     for (int64_t p0 = 0; p0 < B; p0 += cs)
         if (int rc = zk_chunk(h, st, b, index, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
     return post_launch(h);

@@ -132,10 +132,11 @@ void launch_splitk_reduce(const float* parts, int S, long long stride, int M, in
                           int hm_rows, int hm_col0, bf16* c_hi, bf16* c_lo, int ldp, hipStream_t st);
 void launch_planes_to_f32(const bf16* hi, const bf16* lo, float* out, long long n, hipStream_t st);
 void launch_tile_weights(const float* in, bf16* o_hi, bf16* o_lo, long long N, long long K, hipStream_t st);   // fp32 W[N][K] -> tiled bf16 (hi, optional lo)
-void launch_mean8(const float* in, float* out, int U, hipStream_t st);
+void launch_mean8(const float* in, float* out, int U, hipStream_t st, const int* U_dev = nullptr);      // U_dev: device-side row count (U is then an upper bound)
+void launch_scale_count(const int* in, int mul, int* out, hipStream_t st);                               // *out = *in * mul
 
 // zk (code/imagebert_zk/model_triple.py:162-214, pixelbert.py:541-621)
-void launch_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab, bf16* o_hi, bf16* o_lo, hipStream_t st);
+void launch_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab, bf16* o_hi, bf16* o_lo, hipStream_t st, const int* U_dev = nullptr);
 void launch_zk_tokpre(const float* labfeat, const int* lab_index, int n_labels, const float* boxes5, const float* Wd,
                       const float* bd, const float* img, bf16* o_hi, bf16* o_lo, int rows, hipStream_t st,
                       const int* src = nullptr, const int* rows_dev = nullptr);      // src: compact rows, row r stands for box src[r]; r < *rows_dev

@@ -377,9 +377,9 @@ void launch_prep_w_mx(const float* w, f16* w16, unsigned char* w8, unsigned* w8_
     if (N > 0) hipLaunchKernelGGL(k_prep_w_mx, row_grid(N), dim3(256), 0, st, w, w16, w8, (unsigned char*)w8_scale4, col_scale, N, K);
 }
 
-__global__ __launch_bounds__(256) void k_mean8(const float* in, float* out, int U) {
+__global__ __launch_bounds__(256) void k_mean8(const float* in, float* out, int U, const int* U_dev) {
     const int row = wave_row();
-    if (row >= U) return;
+    if (row >= U || (U_dev && row >= *U_dev)) return;
     Row x;
     row_zero(x);
     for (int p = 0; p < MMS_LABEL_LEN; ++p) row_add(x, in + ((long long)row * MMS_LABEL_LEN + p) * MMS_HIDDEN);
@@ -387,9 +387,11 @@ __global__ __launch_bounds__(256) void k_mean8(const float* in, float* out, int 
     for (int i = 0; i < 12; ++i) x.v[i] *= (1.0f / MMS_LABEL_LEN);
     row_store_f32(x, out + (long long)row * MMS_HIDDEN);
 }
-void launch_mean8(const float* in, float* out, int U, hipStream_t st) {
-    if (U > 0) hipLaunchKernelGGL(k_mean8, row_grid(U), dim3(256), 0, st, in, out, U);
+void launch_mean8(const float* in, float* out, int U, hipStream_t st, const int* U_dev) {
+    if (U > 0) hipLaunchKernelGGL(k_mean8, row_grid(U), dim3(256), 0, st, in, out, U, U_dev);
 }
+__global__ void k_scale_count(const int* in, int mul, int* out) { *out = *in * mul; }
+void launch_scale_count(const int* in, int mul, int* out, hipStream_t st) { hipLaunchKernelGGL(k_scale_count, dim3(1), dim3(1), 0, st, in, mul, out); }
 
 // ------------------------------------------------------------------------------------------------
 // zk
@@ -397,9 +399,9 @@ void launch_mean8(const float* in, float* out, int U, hipStream_t st) {
 // im2col for kdd_conv1 (model_triple.py:189): row (u, p), column block k holds E[ids[u][p+k-3]] or 0
 // (SAME padding of an 8-tap window over 8 positions: 3 left / 4 right).
 __global__ __launch_bounds__(256) void k_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab,
-                                                   bf16* o_hi, bf16* o_lo) {
+                                                   bf16* o_hi, bf16* o_lo, const int* U_dev) {
     const int w = wave_row();
-    if (w >= U * MMS_LABEL_LEN * MMS_LABEL_LEN) return;
+    if (w >= U * MMS_LABEL_LEN * MMS_LABEL_LEN || (U_dev && w >= *U_dev * MMS_LABEL_LEN * MMS_LABEL_LEN)) return;
     const int k = w % MMS_LABEL_LEN, p = (w / MMS_LABEL_LEN) % MMS_LABEL_LEN, u = w / (MMS_LABEL_LEN * MMS_LABEL_LEN);
     const int src = p + k - 3;
     Row x;
@@ -409,9 +411,9 @@ __global__ __launch_bounds__(256) void k_zk_im2col(const float* E, const int* un
     const long long off = ((long long)u * MMS_LABEL_LEN + p) * (MMS_LABEL_LEN * MMS_HIDDEN) + k * MMS_HIDDEN;
     row_store_planes(x, plane_ptr(o_hi, off), plane_ptr(o_lo, off));
 }
-void launch_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab, bf16* o_hi, bf16* o_lo, hipStream_t st) {
+void launch_zk_im2col(const float* E, const int* uniq_ids, int U, int vocab, bf16* o_hi, bf16* o_lo, hipStream_t st, const int* U_dev) {
     if (U > 0)
-        hipLaunchKernelGGL(k_zk_im2col, row_grid((long long)U * 64), dim3(256), 0, st, E, uniq_ids, U, vocab, o_hi, o_lo);
+        hipLaunchKernelGGL(k_zk_im2col, row_grid((long long)U * 64), dim3(256), 0, st, E, uniq_ids, U, vocab, o_hi, o_lo, U_dev);
 }
 
 // model_triple.py:190-195: mean(relu(conv1)) [by unique label] + kdd_dense1(boxes_5) + relu(conv2(feats))

@@ -37,3 +37,11 @@ for _ in range(calls):
 dt = time.perf_counter() - t0
 print("%s B=%d: %.3f ms per call (prepare %.3f ms, C call returns after %.3f ms, rest = waiting for the GPU) -> %.0f pairs/s"
       % (name, B, dt / calls * 1e3, tp / calls * 1e3, tc / calls * 1e3, B * calls / dt))
+# the same calls enqueued back to back, ONE synchronisation at the end (a caller that does not read each result before the next call)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(calls):
+    s.score_prepared(bench.prepare(s, name, fd))
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("%s B=%d, %d calls enqueued back to back: %.3f ms per call -> %.0f pairs/s" % (name, B, calls, dt / calls * 1e3, B * calls / dt))
