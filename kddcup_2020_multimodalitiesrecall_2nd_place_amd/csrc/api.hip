@@ -577,7 +577,13 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     if (M <= 0) return MMS_OK;
     const int nsplit = (h->nsplit == 2 && (h->x1_mask & cls_bit)) ? 1 : h->nsplit;
     if (N % 128 || K % 64) return h->fail(MMS_ERR_ARG, "gemm: N % 128 or K % 64 != 0");
-    const bool tiny = M < TINY_ROWS && N >= 1536 && N % 256 == 0 && K == H && h->nsplit >= 2 && !h->f8 && !resid && out.cmap.grp == 0 && !(h->x1_mask & cls_bit);
+    const bool splittable = h->nsplit >= 2 && !h->f8 && !resid && out.cmap.grp == 0 && !(h->x1_mask & cls_bit) && N % 256 == 0;
+    const bool wide = splittable && M < TINY_ROWS && N >= 1536 && K == H;
+    // ... and the two long-K projections in front of the encoder at any small M: kdd_conv1 as im2col (K = 6144, M = 8 x distinct label texts: 96 serial
+    // K steps, 170 us per call whatever the batch) and kdd_conv2 / visn_fc / featureemb (K = 2048) below TALL_ROWS box rows: eight K slices
+    constexpr int64_t TALL_ROWS = 4096;
+    const bool tall = splittable && !wide && M < TALL_ROWS && N == H && K >= 2048 && K % 512 == 0;
+    const bool tiny = wide || tall;
     GemmParams p{};
     p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.amap = amap;
     p.w = w; p.bias = bias; p.M = (int)M; p.N = N; p.K = K;
@@ -592,15 +598,16 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     p.c_hi = out.pl.hi; p.c_lo = out.pl.lo; p.ldp = out.ldp; p.cmap = out.cmap;
     if (resid && !h->resid_in_ln) { p.r_hi = resid->hi; p.r_lo = resid->lo; p.ldr = H; }
     p.m_dev = m_dev; p.a_index = a_index; p.rmap = rmap; p.r_index = r_index;
-    constexpr int TINY_S = 4;
+    const int TINY_S = tall ? 8 : 4;
+    const long long part_stride = (tall ? TALL_ROWS : TINY_ROWS) * (long long)N;      // <= 8 x 4096 x 768 floats: inside kparts (KSPLIT_MAX x SPLITK_ROWS x 768)
     if (tiny) {      // K slices into fp32 partials; the reduce kernel below applies what the epilogue would have
         if (int rc = ensure_kparts(h)) return rc;
         h->splitk_launches += 1;
         p.bias = nullptr; p.act = ACT_NONE; p.out_kind = OUT_F32; p.c_f32 = h->kparts; p.ldc = N; p.hm_rows = 0; p.hm_col0 = 0;
-        p.k_splits = TINY_S; p.c_split_stride = (long long)TINY_ROWS * N;
+        p.k_splits = TINY_S; p.c_split_stride = part_stride;
     }
     auto tiny_reduce = [&]() {
-        if (tiny) launch_splitk_reduce(h->kparts, TINY_S, (long long)TINY_ROWS * N, (int)M, N, m_dev, bias, act, out.f32, out.ldc, out.hm_rows, out.hm_col0,
+        if (tiny) launch_splitk_reduce(h->kparts, TINY_S, part_stride, (int)M, N, m_dev, bias, act, out.f32, out.ldc, out.hm_rows, out.hm_col0,
                                        out.pl.hi, out.pl.lo, out.ldp, st);
     };
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
@@ -800,6 +807,7 @@ struct Pack { const int* off = nullptr; const int* cnt = nullptr; const int* row
 // sub-tile table of one token stream (n pairs of at most S tokens; packed or dense) for qkv_attn.hip, in table slot `slot`
 void plan_tiles(mms_handle* h, hipStream_t st, Pack& pk, int64_t n, int S, int slot) {
     if (!h->fuse_attn || (h->nsplit != 2 && h->nsplit != 3) || h->f8 || S > 48) return;
+    if (n * S < 16384 || S < 16) return;      // att_block() takes the fused kernel only for launches of >= 16384 rows with pairs of >= 16 tokens (the plan is 68 us: 2.4 % of a 256-pair call)
     launch_qkv_tile_plan(pk.off, pk.cnt, pk.rows, (int)n, S, h->qa_sub[slot], h->qa_nsub + slot, h->nsplit, st);
     pk.sub = h->qa_sub[slot]; pk.n_sub = h->qa_nsub + slot;
 }

@@ -53,7 +53,7 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     if (variant == 99) {  // auto (profiles/r01c_gemm_variants.txt): 256x256 ping-pong phases for large M; for the small GEMMs
                           // (CLS-only last block, poolers) 256x256 / 16 waves on wide outputs, 128x256 / 8 waves otherwise
         if (p.N % 256 == 0 && p.M >= 16384) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)
-        else variant = (p.N >= 1536 && p.N % 256 == 0 && p.M >= 8192) ? 16 : 4;
+        else variant = 4;   // (rounds 1-3 sent wide outputs at M >= 8192 to the 256x256 / 16-wave tile: 82 .. 95 us per launch on lds' 256-pair calls, the 128x256 tile is faster there)
     }
 #ifdef MMS_LAB
     if (variant == 28) { if (launch_gemm_dw(p, nsplit, st)) return; variant = 26; }
