@@ -188,7 +188,7 @@ int mms_finalize(mms_handle* h);
  * order at most (~1e-5 relative), and not at all between launches of the same size regime -- < 256, < 8192, < 16384 padded token rows
  * (pairs x sequence length) and above: each regime has its own GEMM routes (split-K tiles for small calls, persistent ping-pong engines with
  * the fused QKV + attention / LayerNorm epilogues for big ones).  A call is ~100 (zk, lds) to ~230 (lxmert) dependent
- * launches: 1.1 - 2.3 ms at 1 pair, so batch thousands of pairs per call when throughput matters ("Call sizes"). */
+ * launches: 1.0 - 2.3 ms at 1 pair, so batch thousands of pairs per call when throughput matters ("Call sizes"). */
 int mms_score_zk(mms_handle* h, const mms_zk_batch* b, float* logits, float* probs, void* stream);
 int mms_score_lds(mms_handle* h, const mms_lds_batch* b, float* logits, float* probs, void* stream);
 int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, float* probs, void* stream);
