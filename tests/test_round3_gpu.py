@@ -38,14 +38,17 @@ def test_large_launch_equals_small_chunks(name, precision, pack, exact):
     routes = dict(fuse_attention=0 if name == "lxmert" else 1, fuse_layernorm=0) if exact else {}
     big, _ = _hip_logits(cfg, w, b, precision=precision, pack_tokens=pack, **routes)
     small, _ = _hip_logits(cfg, w, b, precision=precision, pack_tokens=pack, chunk_pairs=48, **routes)
-    e = vecrel(big, small)
-    print("\n[%s p%d pack=%d] %d pairs: one launch vs 48-pair chunks, vec-rel max %.2e" % (name, precision, pack, len(big), e.max()))
-    assert e.max() < (5e-4 if not exact else 3e-4), e.max()       # exact: summation order only (big-M engines vs small tiles with split-K N = 768 projections)
-    # and a sample of them against the fp64 oracle
-    sel = np.arange(0, len(big), max(1, len(big) // 24))[:24]
+    # the metric of SURVEY.md section 8(d) with its absolute floor: a few of the ~1300 pairs of these shallow random models have logit vectors that
+    # nearly vanish, where a purely relative difference of two fp32-faithful routes diverges
+    e = np.linalg.norm(big - small, axis=1) / np.maximum(np.linalg.norm(small, axis=1), 0.1)
+    print("\n[%s p%d pack=%d] %d pairs: one launch vs 48-pair chunks, vec-rel max %.2e (median %.2e)" % (name, precision, pack, len(big), e.max(), np.median(e)))
+    assert e.max() < (5e-4 if not exact else 3e-4) and np.median(e) < 3e-5, (e.max(), np.median(e))       # exact: summation order only (big-M engines vs split-K small tiles)
+    # and the pairs that moved most + a sample of the rest against the fp64 oracle: BOTH routes inside the contract
+    sel = np.unique(np.concatenate([np.argsort(-e)[:6], np.arange(0, len(big), max(1, len(big) // 18))[:18]]))
     sub = {k: (v[sel] if hasattr(v, "shape") and v.shape[:1] == (len(big),) else v) for k, v in b.items()}
     ref, _ = O.forward(cfg, w, sub, np.float64)
-    assert vecrel(big[sel], ref).max() < TOL_P2
+    floor = np.maximum(np.linalg.norm(ref, axis=1), 0.1)
+    assert (np.linalg.norm(big[sel] - ref, axis=1) / floor).max() < TOL_P2 and (np.linalg.norm(small[sel] - ref, axis=1) / floor).max() < TOL_P2
 
 
 def test_plain_c_host_scores_on_the_gpu_and_matches_ctypes(tmp_path):
