@@ -43,8 +43,8 @@ t0 = time.perf_counter()
 for i in range(calls):
     if VARY and i % 2 == 1:
         run(small)
-        continue
-    sc = run(feed)
+    else:
+        sc = run(feed)
     if (i + 1) % 50 == 0:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
