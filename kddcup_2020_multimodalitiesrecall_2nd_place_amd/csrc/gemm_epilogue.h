@@ -56,8 +56,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += join_bf16(rh[e], rl[e]);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT);
+                v = apply_act4<ACT>(v);
                 const long long orow = p.cmap(row);
                 if (p.out_kind == OUT_F32) {
                     float* dst = p.hm_rows ? p.c_f32 + ((long long)((p.hm_col0 + col) >> 6) * p.hm_rows + orow) * 64 + ((p.hm_col0 + col) & 63)

@@ -90,10 +90,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
             static_assert(FN <= 2 || FN % 4 == 0, "a wave covers half a head, one head or whole heads");
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                f32x4 v = acc[i][j];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT);
-                *reinterpret_cast<f32x4*>(dst + 16 * j + (j >> 2) * head_step) = v;
+                *reinterpret_cast<f32x4*>(dst + 16 * j + (j >> 2) * head_step) = apply_act4<ACT>(acc[i][j]);
             }
         } else if (p.out_kind == OUT_H3) {
             // h3 operand planes (common.h), row-major: the same pairing of column fragments as the bf16 planes -- after the exchange a lane
@@ -123,8 +120,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
             unsigned char* d8 = p.c_f8 + orow * p.ldf8 + col;
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                *reinterpret_cast<unsigned*>(d8 + 16 * j) = pack4_f8(apply_act(acc[i][j][0], ACT), apply_act(acc[i][j][1], ACT),
-                                                                     apply_act(acc[i][j][2], ACT), apply_act(acc[i][j][3], ACT));
+            {
+                const f32x4 g = apply_act4<ACT>(acc[i][j]);
+                *reinterpret_cast<unsigned*>(d8 + 16 * j) = pack4_f8(g[0], g[1], g[2], g[3]);
+            }
         } else {
             static_assert(FN % 2 == 0, "plane stores pair up column fragments");
             bf16* dh = pp_plane_lane_row(p.c_hi, orow * p.ldp, col0, nq);     // ldp % 32 == 0, col0 % 32 == 0
@@ -135,9 +134,11 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, f32x4 (&acc)[FM
             for (int j = 0; j < FN; j += 2) {
                 bf16x4 h[2], l[2];
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
+                for (int jj = 0; jj < 2; ++jj) {
+                    const f32x4 g = apply_act4<ACT>(acc[i][j + jj]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { bf16 a, c2; split_bf16(apply_act(acc[i][j + jj][e], ACT), a, c2); h[jj][e] = a; l[jj][e] = c2; }
+                    for (int e = 0; e < 4; ++e) { bf16 a, c2; split_bf16(g[e], a, c2); h[jj][e] = a; l[jj][e] = c2; }
+                }
                 pp_store_plane_pair(dh, j, h[0], h[1]);
                 pp_store_plane_pair(dl, j, l[0], l[1]);
             }
