@@ -138,6 +138,7 @@ struct mms_handle {
     size_t ev_used = 0;
     int64_t gemm_launches = 0;
     int64_t fused_attn_launches = 0;     // qkv_attn.hip launches since mms_create (mms_dbg_counter)
+    int64_t skinny_launches = 0;         // gemm_skinny.hip launches (launches of <= 128 padded rows) since mms_create
     int64_t ln_fused_launches = 0, splitk_launches = 0;      // LayerNorm-fused GEMM launches / split-K launches (small-call routes) since mms_create
     std::vector<hipEvent_t> ev_fused; size_t ev_fused_used = 0; int64_t fused_timed = 0;     // timing of the fused launches, apart from the GEMMs' (mms_fused_timing)
 
@@ -566,6 +567,22 @@ struct GemmOut {
 };
 
 int ensure_kparts(mms_handle* h);
+// Launches of at most SKINNY_ROWS padded rows in precision mode 2 (the reference's zk call size: 1 pair = 30 token rows; up to 4 zk / 3 lds / 6 lxmert pairs,
+// and the box-row projections of up to 12 pairs): gemm_skinny.hip -- one workgroup per 16 output columns, K split over its waves, no LDS staging, no
+// partial buffer, ONE launch where the split-K routes below need two.  128, measured (profiles/rd4r_skinny_gemm.txt): above it a workgroup's A panel
+// (> 393 KB through one CU's fill path) costs more than the second launch saves.
+constexpr int64_t SKINNY_ROWS_DEFAULT = 128;
+int64_t skinny_rows() {
+#ifdef MMS_LAB
+    static const int64_t v = getenv("MMS_SKINNY_ROWS") ? atoll(getenv("MMS_SKINNY_ROWS")) : SKINNY_ROWS_DEFAULT;      // A/B: 0 = the split-K routes of round 4
+    return v;
+#else
+    return SKINNY_ROWS_DEFAULT;
+#endif
+}
+bool skinny_shape(const mms_handle* h, int64_t M, int K) {
+    return h->nsplit == 2 && !h->f8 && M <= skinny_rows() && K % 256 == 0 && (K < 2048 || K % 512 == 0) && h->resid_in_ln;
+}
 // Tiny launches (M < TINY_ROWS token rows: the reference's own zk / lds call sizes of 1 and 5 pairs) of the wide projections (QKV, K | V, FFN-up:
 // N >= 1536, K = 768): 9 .. 12 workgroups walking K serially take 25 .. 42 us; four K slices + k_splitk_reduce (sum in fixed order, bias,
 // activation, head-major fp32 or planes) take ~half.  The N = 768 projections use proj_ln() below (no reduce launch at all).
@@ -573,17 +590,20 @@ constexpr int64_t TINY_ROWS = 256;
 
 int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf16* w, const float* bias, int64_t M,
          int N, int K, int act, const GemmOut& out, const Planes* resid = nullptr, const int* m_dev = nullptr,
-         const int* a_index = nullptr, RowMap rmap = RowMap{0, 0, 0}, const int* r_index = nullptr, int cls_bit = 0) {
+         const int* a_index = nullptr, RowMap rmap = RowMap{0, 0, 0}, const int* r_index = nullptr, int cls_bit = 0, int force_ks = 0) {
     if (M <= 0) return MMS_OK;
     const int nsplit = (h->nsplit == 2 && (h->x1_mask & cls_bit)) ? 1 : h->nsplit;
     if (N % 128 || K % 64) return h->fail(MMS_ERR_ARG, "gemm: N % 128 or K % 64 != 0");
+    const bool skinny = nsplit == 2 && skinny_shape(h, M, K);
     const bool splittable = h->nsplit >= 2 && !h->f8 && !resid && out.cmap.grp == 0 && !(h->x1_mask & cls_bit) && N % 256 == 0;
     const bool wide = splittable && M < TINY_ROWS && N >= 1536 && K == H;
     // ... and the two long-K projections in front of the encoder at any small M: kdd_conv1 as im2col (K = 6144, M = 8 x distinct label texts: 96 serial
     // K steps, 170 us per call whatever the batch) and kdd_conv2 / visn_fc / featureemb (K = 2048) below TALL_ROWS box rows: eight K slices
     constexpr int64_t TALL_ROWS = 4096;
     const bool tall = splittable && !wide && M < TALL_ROWS && N == H && K >= 2048 && K % 512 == 0;
-    const bool tiny = wide || tall;
+    const bool tiny = (wide || tall) && !skinny;
+    // the skinny kernel slices K the way this projection's tile route does for launches of up to 255 rows, so that it is bit-identical to it
+    const int skinny_ks = force_ks ? force_ks : wide ? 4 : tall ? 8 : 1;
     GemmParams p{};
     p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.amap = amap;
     p.w = w; p.bias = bias; p.M = (int)M; p.N = N; p.K = K;
@@ -611,6 +631,7 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
                                        out.pl.hi, out.pl.lo, out.ldp, st);
     };
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
+    if (skinny) { p.variant = 5; p.k_splits = skinny_ks; h->skinny_launches += 1; }
     if (h->timing) {
         if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
         p.flop_counter = h->flop_counter;   // executed algorithmic FLOPs (2*M_live*N*K), counted on the device
@@ -762,7 +783,7 @@ int ensure_kparts(mms_handle* h) {
 int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap, const int* a_index, const bf16* w, const float* bias, int64_t M,
             int K, const Planes& resid, RowMap rmap, const int* r_index, const float* g, const float* b, const Planes& out, float* t,
             const int* m_dev, int cls_bit) {
-    const int S = splitk_for(h, M, K);
+    const int S = skinny_shape(h, M, K) ? 1 : splitk_for(h, M, K);      // <= 128 rows: the skinny kernel writes the whole sum, the LayerNorm kernel reads one tensor
     if (S > 1) {
         if (int rc = ensure_kparts(h)) return rc;
         h->splitk_launches += 1;
@@ -794,7 +815,8 @@ int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap
         launch_ln_to_planes(h->kparts, H, g, b, out.hi, out.lo, H, (int)M, st, m_dev, r);
         return MMS_OK;
     }
-    if (int rc = gemm(h, st, a, lda, amap, w, bias, M, H, K, ACT_NONE, to_f32(t, H), &resid, m_dev, a_index, rmap, r_index, cls_bit)) return rc;
+    if (int rc = gemm(h, st, a, lda, amap, w, bias, M, H, K, ACT_NONE, to_f32(t, H), &resid, m_dev, a_index, rmap, r_index, cls_bit,
+                      skinny_shape(h, M, K) ? splitk_for(h, M, K) : 0)) return rc;
     ln_resid(h, st, t, g, b, out, M, m_dev, resid, rmap, r_index);
     return MMS_OK;
 }
@@ -2003,7 +2025,7 @@ __global__ void k_fill_random(float* p, long long n, unsigned seed) {
 
 int64_t mms_dbg_counter(mms_handle* h, int32_t which) {
     if (!h) return -1;
-    return which == 0 ? h->fused_attn_launches : which == 1 ? h->ln_fused_launches : which == 2 ? h->splitk_launches : -1;
+    return which == 0 ? h->fused_attn_launches : which == 1 ? h->ln_fused_launches : which == 2 ? h->splitk_launches : which == 3 ? h->skinny_launches : -1;
 }
 
 // GEMM micro-benchmark on random operands: returns the average kernel time (ms) over `iters` launches.

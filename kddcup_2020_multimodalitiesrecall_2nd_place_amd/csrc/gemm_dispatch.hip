@@ -45,7 +45,7 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         variant = 99;
     }
 #endif
-    if (variant != 1 && variant != 4 && variant != 16 && variant != 20 && variant != 26
+    if (variant != 1 && variant != 4 && variant != 5 && variant != 54 && variant != 58 && variant != 16 && variant != 20 && variant != 26
 #ifdef MMS_LAB
         && variant != 3 && variant != 28
 #endif
@@ -58,6 +58,12 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
 #ifdef MMS_LAB
     if (variant == 28) { if (launch_gemm_dw(p, nsplit, st)) return; variant = 26; }
 #endif
+    if (variant == 5) { if (launch_gemm_skinny(p, nsplit, st)) return; variant = 4; }      // a handful of rows (api.hip names it with its K-slice count in k_splits; never the per-shape default here)
+    if (variant == 54 || variant == 58) {      // kernel tests: the skinny kernel with 4 / 8 K slices
+        GemmParams q = p; q.k_splits = variant - 50;
+        if (launch_gemm_skinny(q, nsplit, st)) return;
+        variant = 4;
+    }
     if (variant == 26) { if (launch_gemm_pp(p, nsplit, 0, st, true)) return; variant = 4; }
     if (variant == 20) { if (launch_gemm_pp(p, nsplit, 0, st)) return; variant = 4; }
     if (launch_gemm_tile(p, nsplit, variant, st)) return;

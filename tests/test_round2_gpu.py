@@ -459,6 +459,65 @@ def test_split_k_projection_with_partials_summed_in_the_layernorm(case):
     assert err < 3e-5, err
 
 
+SKINNY_SHAPES = [  # K, N, act, planes
+    (768, 2304, lib.ACT_NONE, False),       # Q | K | V
+    (768, 3072, lib.ACT_GELU_TANH, True),   # FFN up, planes out
+    (768, 3072, lib.ACT_GELU_ERF, True),
+    (3072, 768, lib.ACT_NONE, False),       # FFN down: 8 waves x K / 8
+    (2048, 768, lib.ACT_RELU, False),       # kdd_conv2 / visn_fc
+    (6144, 768, lib.ACT_RELU, False),       # kdd_conv1 as im2col
+    (768, 768, lib.ACT_TANH, True),         # pooler
+]
+
+
+@pytest.mark.parametrize("M", [1, 5, 30, 33, 64, 65, 128, 129, 200, 256])
+@pytest.mark.parametrize("shape", SKINNY_SHAPES)
+def test_skinny_gemm_matches_fp64_and_the_tile_engine_bit_for_bit(M, shape):
+    """gemm_skinny.hip (the forward's choice for launches of <= 128 rows -- the reference's zk call size; row blocks of 128 above): one workgroup per 16
+    output columns, K split over its waves.  Against fp64 with 1 / 4 / 8 K slices (variants 5 / 54 / 58); with ONE slice it accumulates in the tile engine's
+    order, so the result equals the 128x256 tile's (variant 4) BIT FOR BIT -- the 128-row bound is not a numerical regime boundary; and the first row of a
+    larger launch equals a 1-row launch bit for bit (a row's arithmetic does not depend on the row count)."""
+    K, N, act, planes = shape
+    l = lib.load()
+    a = weights.normal("skn/a/%d" % K, (256, K), 1)[:M]
+    w = weights.round_to_bf16(weights.normal("skn/w/%d/%d" % (N, K), (N, K), 1, 1.0 / np.sqrt(K)))
+    bias = weights.normal("skn/b/%d" % N, (N,), 1, 0.1)
+    da, dw, db = _dev(a), _dev(w), _dev(bias)
+
+    def run(variant, rows=M):
+        out = torch.empty((rows, N), device="cuda", dtype=torch.float32)
+        rc = l.mms_dbg_gemm(da.data_ptr(), rows, K, K, dw.data_ptr(), N, db.data_ptr(), None, act, 2, int(planes), variant, out.data_ptr(), None)
+        assert rc == 0, l.mms_global_error()
+        return out.cpu().numpy()
+
+    ref = act_ref(a.astype(np.float64) @ w.astype(np.float64).T + bias, act)
+    got = {v: run(v) for v in ([5, 54] + ([58] if K % 512 == 0 else []))}
+    for v, g in got.items():
+        err = np.abs(g - ref).max() / np.abs(ref).max()
+        assert err < 3e-5, (M, shape, v, err)
+        if M > 1:
+            assert np.array_equal(run(v, 1)[0], g[0]), (M, shape, v)
+    tile = run(4)
+    if act != lib.ACT_GELU_ERF:      # (the erf polynomial is compiled per epilogue: last-bit differences between any two engines)
+        assert np.array_equal(got[5], tile), (M, shape)
+    else:
+        assert np.abs(got[5] - tile).max() < 1e-4 * np.abs(ref).max()
+
+
+def test_one_pair_call_runs_on_the_skinny_kernel():
+    """A 1-pair zk call (evaluate_normal.py:15: 30 token rows) takes gemm_skinny.hip for every projection: no split-K launch, no partial buffer.  A 5-pair
+    lds call (run_pretraining_predict_score.py:523: 200 token rows) takes it for the box-row projections (50 rows) and the split-K tile route for the rest."""
+    for name, B, all_skinny in (("zk", 1, True), ("lds", 5, False)):
+        cfg = small_cfg(name)
+        w = weights.make_weights(cfg)
+        ps = synth.make_pairs(1, B, vocab=cfg.vocab, tag="/skinny")
+        s = scorers.make_scorer(cfg, w)
+        scorers.score_batch(s, synth.batch_for(cfg, ps))
+        torch.cuda.synchronize()
+        assert s.handle.counter(3) > 0 and (s.handle.counter(2) == 0) == all_skinny, (name, s.handle.counter(3), s.handle.counter(2))
+        s.close()
+
+
 @pytest.mark.parametrize("name,precision", [("zk", 2), ("lxmert", 2), ("lds", 2), ("lds", 4)])
 def test_fused_layernorm_forward_matches_the_two_kernel_route(name, precision):
     """mms_config.fuse_layernorm at a size where the big launches really take the fused epilogue (>= 16384 rows): logits against
