@@ -238,7 +238,7 @@ int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B,
                       const float* key_add, float* out_f32, void* stream);
 /* launch counters since mms_create: which = 0 -> fused QKV + attention launches (mms_config.fuse_attention took effect), 1 -> GEMM launches
  * with the fused LayerNorm epilogue (mms_config.fuse_layernorm), 2 -> split-K launches of the small-call routes, 3 -> skinny-GEMM launches (launches of <= 128
- * padded rows, precision mode 2); anything else: -1 */
+ * padded rows, precision modes 2 and 3); anything else: -1 */
 int64_t mms_dbg_counter(mms_handle* h, int32_t which);
 int mms_dbg_layernorm(const float* x, const float* gamma, const float* beta, int64_t M, float* out_f32, void* stream);
 

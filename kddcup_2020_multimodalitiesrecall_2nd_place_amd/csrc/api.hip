@@ -567,7 +567,7 @@ struct GemmOut {
 };
 
 int ensure_kparts(mms_handle* h);
-// Launches of at most SKINNY_ROWS padded rows in precision mode 2 (the reference's zk call size: 1 pair = 30 token rows; up to 4 zk / 3 lds / 6 lxmert pairs,
+// Launches of at most SKINNY_ROWS padded rows in precision modes 2 and 3 (the reference's zk call size: 1 pair = 30 token rows; up to 4 zk / 3 lds / 6 lxmert pairs,
 // and the box-row projections of up to 12 pairs): gemm_skinny.hip -- one workgroup per 16 output columns, K split over its waves, no LDS staging, no
 // partial buffer, ONE launch where the split-K routes below need two.  128, measured (profiles/rd4r_skinny_gemm.txt): above it a workgroup's A panel
 // (> 393 KB through one CU's fill path) costs more than the second launch saves.
@@ -581,7 +581,7 @@ int64_t skinny_rows() {
 #endif
 }
 bool skinny_shape(const mms_handle* h, int64_t M, int K) {
-    return h->nsplit == 2 && !h->f8 && M <= skinny_rows() && K % 256 == 0 && (K < 2048 || K % 512 == 0) && h->resid_in_ln;
+    return (h->nsplit == 2 || h->nsplit == 3) && !h->f8 && M <= skinny_rows() && K % 256 == 0 && (K < 2048 || K % 512 == 0) && h->resid_in_ln;
 }
 // Tiny launches (M < TINY_ROWS token rows: the reference's own zk / lds call sizes of 1 and 5 pairs) of the wide projections (QKV, K | V, FFN-up:
 // N >= 1536, K = 768): 9 .. 12 workgroups walking K serially take 25 .. 42 us; four K slices + k_splitk_reduce (sum in fixed order, bias,
@@ -594,7 +594,7 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     if (M <= 0) return MMS_OK;
     const int nsplit = (h->nsplit == 2 && (h->x1_mask & cls_bit)) ? 1 : h->nsplit;
     if (N % 128 || K % 64) return h->fail(MMS_ERR_ARG, "gemm: N % 128 or K % 64 != 0");
-    const bool skinny = nsplit == 2 && skinny_shape(h, M, K);
+    const bool skinny = (nsplit == 2 || nsplit == 3) && skinny_shape(h, M, K);
     const bool splittable = h->nsplit >= 2 && !h->f8 && !resid && out.cmap.grp == 0 && !(h->x1_mask & cls_bit) && N % 256 == 0;
     const bool wide = splittable && M < TINY_ROWS && N >= 1536 && K == H;
     // ... and the two long-K projections in front of the encoder at any small M: kdd_conv1 as im2col (K = 6144, M = 8 x distinct label texts: 96 serial

@@ -33,7 +33,9 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
 #ifdef MMS_LAB
     if (!p.variant) { static const int env_variant = getenv("MMS_GEMM_VARIANT") ? atoi(getenv("MMS_GEMM_VARIANT")) : 99; variant = env_variant; }
 #endif
-    if (nsplit == 3) {   // three passes: 256x128 ping-pong phases for large M (variant 27 forces it), 128x128 tile otherwise
+    if (nsplit == 3) {   // three passes: 256x128 ping-pong phases for large M (variant 27 forces it), 128x128 tile otherwise; a handful of rows: skinny kernel (api.hip names it)
+        if (variant == 5 && launch_gemm_skinny(p, 3, st)) return;
+        if (variant == 54 || variant == 58) { GemmParams q = p; q.k_splits = variant - 50; if (launch_gemm_skinny(q, 3, st)) return; }
         if ((variant == 27 || (variant == 99 && p.M >= 16384)) && launch_gemm_ppw(p, st)) return;
         launch_gemm_tile(p, 3, 1, st);
         return;

@@ -1,5 +1,5 @@
 // Skinny GEMM for the smallest calls: C[M][N] = act(A W^T + bias) on a handful of token rows (the reference's zk driver scores ONE pair per
-// sess.run: 30 rows, evaluate_normal.py:15), precision mode 2 (A = hi + lo bf16 planes, W = tiled bf16).  api.hip takes it for launches of
+// sess.run: 30 rows, evaluate_normal.py:15), precision modes 2 and 3 (A = hi + lo bf16 planes, W = tiled bf16 -- with a lo plane in mode 3).  api.hip takes it for launches of
 // <= 128 padded rows; the kernel itself handles any M <= 512 in row blocks of 128 (tested to 256).
 //
 // Such a launch is pure latency: the 128x256 tile engine puts 3 .. 12 workgroups on the chip, each walking K serially through LDS
@@ -18,7 +18,8 @@ namespace {
 
 constexpr int SKINNY_MAX_ROWS = 512;
 
-template <int FM, int KS, int ACT, int U>
+// WPL: weight planes -- 1: precision mode 2 (a_hi w + a_lo w), 2: precision mode 3 (w = w_hi + w_lo: a_hi w_hi + a_lo w_hi + a_hi w_lo, the tile engine's order)
+template <int FM, int KS, int ACT, int U, int WPL>
 __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float red[KS][FM * 16][16];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const GemmParams p
         a_row[i] = p.a_hi + 2 * ((p.a_index ? (long long)p.a_index[r] : p.amap(r)) * (long long)p.lda) + 8 * fk;
     }
     const bf16* w_lane = p.w + (long long)(n0 >> 4) * nk * 512 + fr * 32 + fk * 8;
+    const long long wlo_delta = WPL == 2 ? p.w_lo - p.w : 0;
     const int mrows = Meff - r0 < FM * 16 ? Meff - r0 : FM * 16;      // live rows of this block
     const int nfrag = (mrows + 15) >> 4;      // live row fragments (uniform)
     // no branch in the loop: the fragments past the live rows re-read the clamped row (one cache line for the whole wave), so the compiler is
@@ -53,11 +55,12 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const GemmParams p
     // U K steps per trip (per % U == 0: launch_gemm_skinny), every load of the trip in front of its first MFMA: a trip costs one memory latency
     // whatever U is, and these launches are nothing but a chain of trips (U = 6: a K = 768 slice of a quarter is ONE trip)
     for (int ktu = kt0; ktu < kt0 + per; ktu += U) {
-        bf16x8 b[U], a0[U][FM], a1[U][FM];
+        bf16x8 b[U], bl[WPL == 2 ? U : 1], a0[U][FM], a1[U][FM];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kt = ktu + u;
             b[u] = *reinterpret_cast<const bf16x8*>(w_lane + (long long)kt * 512);
+            if constexpr (WPL == 2) bl[u] = *reinterpret_cast<const bf16x8*>(w_lane + wlo_delta + (long long)kt * 512);
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 a0[u][i] = *reinterpret_cast<const bf16x8*>(a_row[i] + kt * 64);
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const GemmParams p
             for (int i = 0; i < FM; ++i) {
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u][i], b[u], acc[i], 0, 0, 0);
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u][i], b[u], acc[i], 0, 0, 0);
+                if constexpr (WPL == 2) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u][i], bl[u], acc[i], 0, 0, 0);
             }
         }
     }
@@ -105,32 +109,41 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const GemmParams p
     }
 }
 
-template <int FM, int KS, int U>
+template <int FM, int KS, int U, int WPL>
 void launch_act(const GemmParams& p, hipStream_t st) {
     const dim3 grid(p.N / 16, (p.M + FM * 16 - 1) / (FM * 16)), block(64 * KS);
     switch (p.act) {
-        case ACT_RELU: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_RELU, U>), grid, block, 0, st, p); break;
-        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_GELU_TANH, U>), grid, block, 0, st, p); break;
-        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_GELU_ERF, U>), grid, block, 0, st, p); break;
-        case ACT_TANH: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_TANH, U>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_NONE, U>), grid, block, 0, st, p); break;
+        case ACT_RELU: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_RELU, U, WPL>), grid, block, 0, st, p); break;
+        case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_GELU_TANH, U, WPL>), grid, block, 0, st, p); break;
+        case ACT_GELU_ERF: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_GELU_ERF, U, WPL>), grid, block, 0, st, p); break;
+        case ACT_TANH: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_TANH, U, WPL>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_NONE, U, WPL>), grid, block, 0, st, p); break;
     }
 }
-template <int FM, int KS>
+template <int FM, int KS, int WPL>
 void launch_fm(const GemmParams& p, hipStream_t st) {
-    constexpr int DEEP = FM <= 4 ? 6 : FM <= 6 ? 3 : 2;      // K steps in flight per wave: what the register file holds (operand registers: FM = 2: 120, FM = 4: 216, FM = 6: 156, FM = 8: 136)
+    // K steps in flight per wave: what the register file holds (operand registers at WPL = 1: FM = 2: 120, FM = 4: 216, FM = 6: 156, FM = 8: 136; the lo
+    // weight fragment of mode 3 adds 4 per step: FM = 4 runs three steps per trip there)
+    constexpr int DEEP = FM <= 2 ? 6 : FM <= 4 ? (WPL == 2 ? 3 : 6) : FM <= 6 ? 3 : 2;
     const int per = (p.K >> 5) / KS;
-    if (per % DEEP == 0) launch_act<FM, KS, DEEP>(p, st);
-    else launch_act<FM, KS, 2>(p, st);
+    if (per % DEEP == 0) launch_act<FM, KS, DEEP, WPL>(p, st);
+    else launch_act<FM, KS, 2, WPL>(p, st);
 }
 
-template <int KS>
+template <int KS, int WPL>
 void launch_ks(const GemmParams& p, hipStream_t st) {
-    if (p.M <= 32) launch_fm<2, KS>(p, st);
-    else if (p.M <= 64) launch_fm<4, KS>(p, st);
-    else if (p.M <= 96) launch_fm<6, KS>(p, st);      // (zk's label-text projection of a 1-pair call: 8 positions x 10 labels = 80 rows, K = 6144)
-    else launch_fm<8, KS>(p, st);      // more than 128 rows: row blocks of 128 (a workgroup's A panel is then <= 393 KB: its fill time is what a
-                                       // 16-row-fragment workgroup was bound by)
+    if (p.M <= 32) launch_fm<2, KS, WPL>(p, st);
+    else if (p.M <= 64) launch_fm<4, KS, WPL>(p, st);
+    else if (p.M <= 96) launch_fm<6, KS, WPL>(p, st);      // (zk's label-text projection of a 1-pair call: 8 positions x 10 labels = 80 rows, K = 6144)
+    else launch_fm<8, KS, WPL>(p, st);      // more than 128 rows: row blocks of 128
+}
+template <int WPL>
+bool launch_wpl(const GemmParams& p, int ks, hipStream_t st) {
+    if (ks == 1) launch_ks<1, WPL>(p, st);
+    else if (ks == 4) launch_ks<4, WPL>(p, st);
+    else if (ks == 8) launch_ks<8, WPL>(p, st);
+    else return false;
+    return true;
 }
 
 }  // namespace
@@ -144,11 +157,8 @@ void launch_ks(const GemmParams& p, hipStream_t st) {
 bool launch_gemm_skinny(const GemmParams& p, int nsplit, hipStream_t st) {
     if (p.M <= 0) return true;
     const int ks = p.k_splits > 1 ? p.k_splits : 1;
-    if (nsplit != 2 || p.M > SKINNY_MAX_ROWS || p.N % 16 || p.K % (64 * ks) || p.w_lo || p.f8 || p.r_hi || p.ln_gamma) return false;
+    if ((nsplit != 2 && nsplit != 3) || p.M > SKINNY_MAX_ROWS || p.N % 16 || p.K % (64 * ks) || p.f8 || p.r_hi || p.ln_gamma) return false;
+    if (nsplit == 3 && !p.w_lo) return false;
     if (p.out_kind != OUT_F32 && p.out_kind != OUT_PLANES) return false;
-    if (ks == 1) launch_ks<1>(p, st);
-    else if (ks == 4) launch_ks<4>(p, st);
-    else if (ks == 8) launch_ks<8>(p, st);
-    else return false;
-    return true;
+    return nsplit == 3 ? launch_wpl<2>(p, ks, st) : launch_wpl<1>(p, ks, st);
 }

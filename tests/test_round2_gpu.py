@@ -504,14 +504,37 @@ def test_skinny_gemm_matches_fp64_and_the_tile_engine_bit_for_bit(M, shape):
         assert np.abs(got[5] - tile).max() < 1e-4 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("M", [1, 30, 65, 128])
+@pytest.mark.parametrize("shape", [(768, 2304, lib.ACT_NONE, False), (768, 3072, lib.ACT_GELU_TANH, True), (3072, 768, lib.ACT_NONE, False), (2048, 768, lib.ACT_RELU, False)])
+def test_skinny_gemm_precision3_follows_fp32_weights_and_equals_the_tile_engine(M, shape):
+    """The skinny kernel with the weights' lo plane (precision mode 3: a_hi w_hi + a_lo w_hi + a_hi w_lo per 32-wide K block, the tile engine's order): an
+    arbitrary fp32 W followed to ~2^-16, and bit-identical to the 128x128 three-pass tile (variant 0 at this size)."""
+    K, N, act, planes = shape
+    l = lib.load()
+    a = weights.normal("skn3/a/%d" % K, (128, K), 1)[:M]
+    w = weights.normal("skn3/w/%d/%d" % (N, K), (N, K), 1, 1.0 / np.sqrt(K))      # NOT bf16-representable
+    bias = weights.normal("skn3/b/%d" % N, (N,), 1, 0.1)
+    da, dw, db = _dev(a), _dev(w), _dev(bias)
+    outs = {}
+    for v in [5, 54] + ([58] if K % 512 == 0 else []) + [0]:
+        out = torch.empty((M, N), device="cuda", dtype=torch.float32)
+        rc = l.mms_dbg_gemm(da.data_ptr(), M, K, K, dw.data_ptr(), N, db.data_ptr(), None, act, 3, int(planes), v, out.data_ptr(), None)
+        assert rc == 0, l.mms_global_error()
+        outs[v] = out.cpu().numpy()
+    ref = act_ref(a.astype(np.float64) @ w.astype(np.float64).T + bias, act)
+    for v, g in outs.items():
+        assert np.abs(g - ref).max() / np.abs(ref).max() < 5e-5, (M, shape, v)
+    assert np.array_equal(outs[5], outs[0]), (M, shape)
+
+
 def test_one_pair_call_runs_on_the_skinny_kernel():
     """A 1-pair zk call (evaluate_normal.py:15: 30 token rows) takes gemm_skinny.hip for every projection: no split-K launch, no partial buffer.  A 5-pair
     lds call (run_pretraining_predict_score.py:523: 200 token rows) takes it for the box-row projections (50 rows) and the split-K tile route for the rest."""
-    for name, B, all_skinny in (("zk", 1, True), ("lds", 5, False)):
+    for name, B, all_skinny, precision in (("zk", 1, True, 2), ("lds", 5, False, 2), ("zk", 1, True, 3)):
         cfg = small_cfg(name)
-        w = weights.make_weights(cfg)
+        w = weights.make_weights(cfg, bf16_matrices=(precision != 3))
         ps = synth.make_pairs(1, B, vocab=cfg.vocab, tag="/skinny")
-        s = scorers.make_scorer(cfg, w)
+        s = scorers.make_scorer(cfg, w, precision=precision)
         scorers.score_batch(s, synth.batch_for(cfg, ps))
         torch.cuda.synchronize()
         assert s.handle.counter(3) > 0 and (s.handle.counter(2) == 0) == all_skinny, (name, s.handle.counter(3), s.handle.counter(2))
