@@ -2059,7 +2059,7 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     if (resid) { p.r_hi = rp; p.r_lo = rp + MMS_PLANE_LO; p.ldr = (int)N; }
     if (out_planes) { p.out_kind = OUT_PLANES; p.c_hi = cp; p.c_lo = cp + MMS_PLANE_LO; p.ldp = (int)N; }
     else { p.out_kind = OUT_F32; p.c_f32 = cf; p.ldc = (int)N; }
-    p.variant = variant < 50 ? variant : 0;
+    p.variant = (variant < 50 || variant == 54 || variant == 58) ? variant : 0;      // (54 / 58: the skinny kernel with 4 / 8 K slices)
     hipEvent_t e0, e1;
     DBG_TRY(hipEventCreate(&e0)); DBG_TRY(hipEventCreate(&e1));
     // variants 50 / 51: the precision-5 engine (gemm_mx.hip) / its high pass alone (lab) on the same random operands
