@@ -47,15 +47,23 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         variant = 99;
     }
 #endif
-    if (variant != 1 && variant != 4 && variant != 5 && variant != 54 && variant != 58 && variant != 16 && variant != 20 && variant != 26
+    if (variant != 1 && variant != 3 && variant != 4 && variant != 5 && variant != 54 && variant != 58 && variant != 16 && variant != 20 && variant != 26
 #ifdef MMS_LAB
-        && variant != 3 && variant != 28
+        && variant != 28
 #endif
     ) variant = 99;
     if (variant == 99) {  // auto (profiles/r01c_gemm_variants.txt): 256x256 ping-pong phases for large M; for the small GEMMs
                           // (CLS-only last block, poolers) 256x256 / 16 waves on wide outputs, 128x256 / 8 waves otherwise
         if (p.N % 256 == 0 && p.M >= 16384) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)
         else variant = 4;   // (rounds 1-3 sent wide outputs at M >= 8192 to the 256x256 / 16-wave tile: 82 .. 95 us per launch on lds' 256-pair calls, the 128x256 tile is faster there)
+        // ... and when even the PADDED row bound gives no more workgroups than the chip has CUs (calls of up to ~50 .. 120 pairs): the same tile with LDS-DMA
+        // double buffering (no VGPR round trip, one barrier per K step; 128 KiB of LDS, so one workgroup per CU -- which is all such a launch has anyway):
+        // 10 .. 15 % faster there, slower as soon as a CU would hold two of the register-staged workgroups (profiles/rd4x_tile_engines_midsize.txt).
+        // Same accumulation order: bit-identical to variant 4.
+        if (variant == 4 && p.N % 256 == 0) {
+            const long long wgs = (long long)((p.M + 127) / 128) * (p.N / 256) * (p.k_splits > 1 ? p.k_splits : 1);
+            if (wgs <= device_cu_count()) variant = 3;
+        }
     }
 #ifdef MMS_LAB
     if (variant == 28) { if (launch_gemm_dw(p, nsplit, st)) return; variant = 26; }

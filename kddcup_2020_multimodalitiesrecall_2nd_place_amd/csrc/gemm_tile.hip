@@ -250,9 +250,7 @@ template <int NSPLIT>
 static bool launch_variant(const GemmParams& p, int variant, hipStream_t st) {
     switch (variant) {
         case 1: launch_cfg<NSPLIT, 128, 128, 2, 2, 0, 0>(p, st); return true;                               // reg-staged 128x128 (N % 256 != 0)
-#ifdef MMS_LAB
-        case 3: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 0>(p, st); return true;  // LDS-DMA, double buffered, 1 WG/CU (A/B only)
-#endif
+        case 3: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 0>(p, st); return true;  // LDS-DMA, double buffered, 1 WG/CU: launches of no more workgroups than CUs (gemm_dispatch.hip)
         case 4: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 0, 0>(p, st); return true;  // reg-staged 128x256 (default)
         case 16: if (p.N % 256) return false; launch_cfg<NSPLIT, 256, 256, 4, 4, 0, 0>(p, st); return true; // 16 waves, 1 WG/CU, 25 % fewer operand bytes per flop
         default: return false;

@@ -44,8 +44,8 @@ GEMM_CASES = [
 ]
 
 
-# the tile engines a forward can launch (gemm_dispatch.hip): 128x128, 128x256, 256x256/16 waves, 256x256 persistent ping-pong
-GEMM_VARIANTS = [1, 4, 16, 20, 26]
+# the tile engines a forward can launch (gemm_dispatch.hip): 128x128, 128x256 LDS-DMA double buffer, 128x256 register-staged, 256x256/16 waves, 256x256 ping-pong (one tile per workgroup / persistent)
+GEMM_VARIANTS = [1, 3, 4, 16, 20, 26]
 
 
 @pytest.fixture
@@ -127,6 +127,25 @@ def test_gemm_transpose_detecting(gemm_variant):
     rc = l.mms_dbg_gemm(da.data_ptr(), M, K, K, dw.data_ptr(), N, None, None, 0, 2, 0, gemm_variant, out.data_ptr(), None)
     assert rc == 0
     assert np.array_equal(out.cpu().numpy(), w.T)
+
+
+@pytest.mark.parametrize("case", [(300, 768, 2304, lib.ACT_NONE, False), (200, 768, 3072, lib.ACT_GELU_TANH, True), (1000, 3072, 768, lib.ACT_NONE, False), (64, 2048, 768, lib.ACT_RELU, False)])
+def test_lds_dma_tile_equals_the_register_staged_tile_bit_for_bit(case):
+    """gemm_dispatch.hip picks the LDS-DMA double-buffered 128x256 tile (variant 3) for launches of no more workgroups than CUs and the register-staged one
+    (variant 4) otherwise: same fragments, same accumulation order -- the choice must not be visible in the results."""
+    M, K, N, act, planes = case
+    l = lib.load()
+    a = weights.normal("v34/a/%d/%d" % (M, K), (M, K), 1)
+    w = weights.round_to_bf16(weights.normal("v34/w/%d/%d" % (N, K), (N, K), 1, 1.0 / np.sqrt(K)))
+    bias = weights.normal("v34/b/%d" % N, (N,), 1, 0.1)
+    da, dw, db = _dev(a), _dev(w), _dev(bias)
+    outs = []
+    for v in (3, 4, 0):
+        out = torch.empty((M, N), device="cuda", dtype=torch.float32)
+        rc = l.mms_dbg_gemm(da.data_ptr(), M, K, K, dw.data_ptr(), N, db.data_ptr(), None, act, 2, int(planes), v, out.data_ptr(), None)
+        assert rc == 0, l.mms_global_error()
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[2], outs[1]), case
 
 
 ATT_CASES = [(7, 30, 30, True), (5, 40, 40, False), (6, 23, 23, True), (9, 10, 10, True), (4, 23, 10, True),
