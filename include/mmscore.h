@@ -185,7 +185,7 @@ int mms_finalize(mms_handle* h);
 
 /* logits / probs: device fp32 [B,2] (probs may be NULL).
  * Pairs are independent: how a caller groups them into calls (or mms_config.chunk_pairs into launch waves) changes a logit by fp32 summation
- * order at most (~1e-5 relative), and not at all between launches of the same size regime -- < 256, < 8192, < 16384 padded token rows
+ * order at most (~1e-5 relative), and not at all between launches of the same size regime -- < 1024, < 8192, < 16384 padded token rows
  * (pairs x sequence length) and above: each regime has its own GEMM routes (split-K tiles for small calls -- and, bit-identical to them, the skinny
  * kernel for launches of <= 128 rows --, persistent ping-pong engines with the fused QKV + attention / LayerNorm epilogues for big ones; DESIGN.md
  * section 3).  A call is ~110 (zk, lds) to ~220 (lxmert) dependent launches: 0.6 - 1.1 ms at 1 pair, so batch thousands of pairs per call when

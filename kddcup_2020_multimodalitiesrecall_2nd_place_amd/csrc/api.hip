@@ -583,10 +583,21 @@ int64_t skinny_rows() {
 bool skinny_shape(const mms_handle* h, int64_t M, int K) {
     return (h->nsplit == 2 || h->nsplit == 3) && !h->f8 && M <= skinny_rows() && K % 256 == 0 && (K < 2048 || K % 512 == 0) && h->resid_in_ln;
 }
-// Tiny launches (M < TINY_ROWS token rows: the reference's own zk / lds call sizes of 1 and 5 pairs) of the wide projections (QKV, K | V, FFN-up:
-// N >= 1536, K = 768): 9 .. 12 workgroups walking K serially take 25 .. 42 us; four K slices + k_splitk_reduce (sum in fixed order, bias,
-// activation, head-major fp32 or planes) take ~half.  The N = 768 projections use proj_ln() below (no reduce launch at all).
-constexpr int64_t TINY_ROWS = 256;
+// Small launches (M < TINY_ROWS padded token rows: calls of up to 34 zk / 25 lds / 51 lxmert pairs) of the wide projections (QKV, K | V, FFN-up:
+// N >= 1536, K = 768): the 128 x 256 tile grid is a few dozen workgroups walking K serially (25 .. 42 us at ANY such M: the time of one tile); four K slices
+// + k_splitk_reduce (sum in fixed order, bias, activation, head-major fp32 or planes) take 10 + 6.  The N = 768 projections use proj_ln() below (no reduce
+// launch at all).  1024, measured (profiles/rd4x_tile_engines_midsize.txt): zk 12 / 17 / 34 pairs -16 / -15 / -7 % against a bound of 256, lds 12 pairs -14 %;
+// from ~2000 rows on the partial traffic and the second launch cost more than the shorter K walk saves (zk 68 pairs +10 %, lds 50 pairs +20 % at a bound of 2048).
+constexpr int64_t TINY_ROWS_DEFAULT = 1024;
+int64_t tiny_rows() {
+#ifdef MMS_LAB
+    static const int64_t v = getenv("MMS_TINY_ROWS") ? atoll(getenv("MMS_TINY_ROWS")) : TINY_ROWS_DEFAULT;      // A/B: row bound of the wide split-K route (<= 4096: kparts)
+    return v;
+#else
+    return TINY_ROWS_DEFAULT;
+#endif
+}
+#define TINY_ROWS tiny_rows()
 
 int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf16* w, const float* bias, int64_t M,
          int N, int K, int act, const GemmOut& out, const Planes* resid = nullptr, const int* m_dev = nullptr,

@@ -1,4 +1,4 @@
-// Shared GEMM epilogue (gemm_tile.hip, gemm_ring.hip): accumulators -> per-wave LDS strip (16 rows at a time) ->
+// Shared GEMM epilogue (gemm_tile.hip): accumulators -> per-wave LDS strip (16 rows at a time) ->
 // row-contiguous float4, so bias / residual / activation / split run vectorised and global stores are 16 B (fp32)
 // or 8 B (bf16x4 per plane) per lane, 256 / 128 contiguous bytes per row.
 #pragma once

@@ -1,4 +1,4 @@
-"""GPU suite, round 4: the launch-size regimes of api.hip meet at fixed PADDED row counts (pairs x tokens per pair) -- 128 (skinny kernel), 256 (tiny split-K route with
+"""GPU suite, round 4: the launch-size regimes of api.hip meet at fixed PADDED row counts (pairs x tokens per pair) -- 128 (skinny kernel), 1024 (wide projections split over K with
 k_splitk_reduce), 4096 (long-K projections in front of the encoder), 8192 (split-K N = 768 projections summed in the LayerNorm kernel), 16 384 (persistent
 ping-pong engines, fused QKV + attention, LayerNorm in the GEMM epilogue).  The same pairs scored in ONE call of a size one pair below / at each bound must give the
 same scores up to fp32 round-off of a different summation order, packed and dense, with a ragged last wave -- a partial-buffer, row-bound or off-by-one slip
@@ -14,9 +14,9 @@ from oracle import np_models as O
 pytestmark = pytest.mark.gpu
 
 # pairs per launch wave so that wave rows = pairs x S straddle 256 / 4096 (box rows = pairs x 10) / 8192 / 16 384
-WAVES = {"zk": [4, 5, 8, 9, 273, 274, 409, 410, 546, 547],  # S = 30: 120 | 150 (skinny kernel <= 128 rows), 240 | 270, 8190 | 8220, box rows 4090 | 4100, 16 380 | 16 410
-         "lds": [3, 4, 6, 7, 204, 205, 409, 410],            # S = 40: 120 | 160, 240 | 280, 8160 | 8200, 16 360 | 16 400
-         "lxmert": [6, 7, 12, 13, 409, 410, 819, 820]}       # language rows S = 20: 120 | 140, 240 | 260, 8180 | 8200, 16 380 | 16 400; vision rows (10 per pair) 4090 | 4100, 8190 | 8200
+WAVES = {"zk": [4, 5, 34, 35, 273, 274, 409, 410, 546, 547],  # S = 30: 120 | 150 (skinny kernel <= 128 rows), 1020 | 1050, 8190 | 8220, box rows 4090 | 4100, 16 380 | 16 410
+         "lds": [3, 4, 25, 26, 204, 205, 409, 410],          # S = 40: 120 | 160, 1000 | 1040, 8160 | 8200, 16 360 | 16 400
+         "lxmert": [6, 7, 51, 52, 409, 410, 819, 820]}       # language rows S = 20: 120 | 140, 1020 | 1040, 8180 | 8200, 16 380 | 16 400; vision rows (10 per pair) 4090 | 4100, 8190 | 8200
 
 
 @pytest.mark.parametrize("name", ["zk", "lds", "lxmert"])
