@@ -1,0 +1,38 @@
+"""GPU box: thousands of small scoring calls of mixed sizes through one handle per model -- free device memory before / after, and every repetition of a size
+must reproduce its first result bit for bit (workspace growth / reuse, split-K partial buffer, skinny / tile / persistent routes taking turns).
+python tools/soak_small.py [rounds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import bench
+from kddcup_2020_multimodalitiesrecall_2nd_place_amd import scorers, synth, weights
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dev = torch.device("cuda", 0)
+SIZES = [1, 5, 2, 256, 3, 34, 35, 600, 1, 17, 130, 4, 1024, 8, 5, 60]
+for name in ("zk", "lds", "lxmert"):
+    cfg = bench.CFGS[name]()
+    w = weights.make_weights(cfg)
+    s = scorers.make_scorer(cfg, w, precision=2)
+    ps = synth.make_pairs(40, 30, tag="/bench0", with_feats=False)
+    feats = bench.device_feats(ps, dev, 20200823)
+    fd = bench.device_feed(name, {name: cfg}, ps, feats, dev)
+    def sub(c):
+        return {k: (v[:c].contiguous() if torch.is_tensor(v) and v.shape[:1] == (ps.n,) else v[:c * 10].contiguous() if torch.is_tensor(v) and v.shape[:1] == (ps.n * 10,) else v) for k, v in fd.items()}
+    feeds = {c: sub(c) for c in set(SIZES)}
+    first = {}
+    for c in SIZES:
+        first.setdefault(c, s.score_prepared(bench.prepare(s, name, feeds[c]))[1].clone())
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    t0 = time.perf_counter(); calls = 0; same = True
+    for r in range(rounds):
+        for c in SIZES:
+            out = s.score_prepared(bench.prepare(s, name, feeds[c]))[1]
+            same = same and bool(torch.equal(out, first[c])); calls += 1
+    torch.cuda.synchronize()
+    print("%s: %d calls of %s pairs in %.1f s, every repetition bit-identical to the first: %s, free memory %.3f -> %.3f GB" % (
+        name, calls, sorted(set(SIZES)), time.perf_counter() - t0, same, free0 / 1e9, torch.cuda.mem_get_info()[0] / 1e9), flush=True)
+    s.close()
