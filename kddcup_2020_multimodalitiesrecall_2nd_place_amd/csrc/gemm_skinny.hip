@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const GemmParams p
     const int fr = lane & 15, fk = lane >> 4;
     int Meff = p.M;
     if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
-    if (p.flop_counter && blockIdx.x == 0 && tid == 0)
+    if (p.flop_counter && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
         atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
     const int r0 = blockIdx.y * (FM * 16);      // row block (launches of more than 128 rows: blocks of 128, FM = 8)
     if (Meff <= r0) return;
