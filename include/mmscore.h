@@ -227,7 +227,8 @@ int mms_dbg_gemm_f8(const float* a_f32, int64_t M, int64_t K, const float* w_f32
 int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, const float* bias, const float* resid_f32,
                     const float* gamma, const float* beta, int32_t f8, float* c_f32, int32_t* mode_out, void* stream);
 /* the small-launch route of the same operation (calls of a few hundred pairs): register-staged tiles with the contraction split `splits`
- * ways into fp32 partials (K % (64 * splits) == 0; 1 = unsplit) + the LayerNorm kernel that sums them and adds bias + residual */
+ * ways into fp32 partials (K % (64 * splits) == 0; 1 = unsplit) + the LayerNorm kernel that sums them and adds bias + residual; splits < 0: |splits|
+ * partials from the skinny kernel instead (K slices dealt to workgroups, M <= 512): bit-identical to the tile engine's */
 int mms_dbg_proj_ln_splitk(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, const float* bias, const float* resid_f32,
                            const float* gamma, const float* beta, int32_t splits, float* c_f32, void* stream);
 /* time one GEMM shape on random data (variant as in mms_dbg_gemm; 52: the MX-fp8 engine; 60 / 61: the LayerNorm kernel with / without

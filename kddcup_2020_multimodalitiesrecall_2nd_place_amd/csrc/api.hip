@@ -794,10 +794,11 @@ int ensure_kparts(mms_handle* h) {
 int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap, const int* a_index, const bf16* w, const float* bias, int64_t M,
             int K, const Planes& resid, RowMap rmap, const int* r_index, const float* g, const float* b, const Planes& out, float* t,
             const int* m_dev, int cls_bit) {
-    const int S = skinny_shape(h, M, K) ? 1 : splitk_for(h, M, K);      // <= 128 rows: the skinny kernel writes the whole sum, the LayerNorm kernel reads one tensor
+    const int S = splitk_for(h, M, K);
+    const bool skinny = skinny_shape(h, M, K);      // <= 128 rows: the partials come from the skinny kernel, one single-wave workgroup per (16 columns, K slice)
     if (S > 1) {
         if (int rc = ensure_kparts(h)) return rc;
-        h->splitk_launches += 1;
+        (skinny ? h->skinny_launches : h->splitk_launches) += 1;
         GemmParams p{};
         p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.amap = amap; p.a_index = a_index;
         p.w = w; p.M = (int)M; p.N = H; p.K = K; p.act = ACT_NONE;
@@ -809,6 +810,7 @@ int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap
         p.out_kind = OUT_F32; p.c_f32 = h->kparts; p.ldc = H; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
         p.k_splits = S; p.c_split_stride = (long long)h->kparts_rows * H;
         p.m_dev = m_dev;
+        if (skinny) p.variant = 55;      // gemm_skinny.hip, K slices dealt to workgroups (same partials as the tile engine's: bit-identical)
         if (h->timing) {
             if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
             p.flop_counter = h->flop_counter;
@@ -1997,7 +1999,9 @@ int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32
 int mms_dbg_proj_ln_splitk(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, const float* bias, const float* resid_f32,
                            const float* gamma, const float* beta, int32_t splits, float* c_f32, void* stream) {
     const int64_t N = H;
-    if (!a_f32 || !w_f32_nk || !resid_f32 || !gamma || !beta || !c_f32 || M <= 0 || splits < 1 || K % (64 * splits)) { g_err = "mms_dbg_proj_ln_splitk: bad argument"; return MMS_ERR_ARG; }
+    const bool skinny_parts = splits < 0;      // negative: the partials come from gemm_skinny.hip (K slices dealt to workgroups; M <= 512) instead of the tile engine
+    if (skinny_parts) splits = -splits;
+    if (!a_f32 || !w_f32_nk || !resid_f32 || !gamma || !beta || !c_f32 || M <= 0 || splits == 0 || K % (64 * (splits < 0 ? -splits : splits))) { g_err = "mms_dbg_proj_ln_splitk: bad argument"; return MMS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     bf16 *ap = nullptr, *wp = nullptr, *rp = nullptr, *cp = nullptr;
     float* parts = nullptr;
@@ -2012,7 +2016,7 @@ int mms_dbg_proj_ln_splitk(const float* a_f32, int64_t M, int64_t K, const float
     p.w = wp; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = ACT_NONE;
     p.out_kind = OUT_F32; p.c_f32 = parts; p.ldc = (int)N;
     p.k_splits = splits; p.c_split_stride = (long long)M * N;
-    p.variant = 4;
+    p.variant = skinny_parts && splits > 1 ? 55 : 4;
     if (splits == 1) p.bias = bias;
     launch_gemm(p, 2, st);
     LnResid r;

@@ -35,6 +35,7 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
 #endif
     if (nsplit == 3) {   // three passes: 256x128 ping-pong phases for large M (variant 27 forces it), 128x128 tile otherwise; a handful of rows: skinny kernel (api.hip names it)
         if (variant == 5 && launch_gemm_skinny(p, 3, st)) return;
+        if (variant == 55 && launch_gemm_skinny_parts(p, 3, st)) return;
         if (variant == 54 || variant == 58) { GemmParams q = p; q.k_splits = variant - 50; if (launch_gemm_skinny(q, 3, st)) return; }
         if ((variant == 27 || (variant == 99 && p.M >= 16384)) && launch_gemm_ppw(p, st)) return;
         launch_gemm_tile(p, 3, 1, st);
@@ -47,7 +48,7 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         variant = 99;
     }
 #endif
-    if (variant != 1 && variant != 3 && variant != 4 && variant != 5 && variant != 54 && variant != 58 && variant != 16 && variant != 20 && variant != 26
+    if (variant != 1 && variant != 3 && variant != 4 && variant != 5 && variant != 54 && variant != 55 && variant != 58 && variant != 16 && variant != 20 && variant != 26
 #ifdef MMS_LAB
         && variant != 28
 #endif
@@ -69,6 +70,7 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     if (variant == 28) { if (launch_gemm_dw(p, nsplit, st)) return; variant = 26; }
 #endif
     if (variant == 5) { if (launch_gemm_skinny(p, nsplit, st)) return; variant = 4; }      // a handful of rows (api.hip names it with its K-slice count in k_splits; never the per-shape default here)
+    if (variant == 55) { if (launch_gemm_skinny_parts(p, nsplit, st)) return; variant = 4; }      // split-K partials from the skinny kernel (api.hip proj_ln); the tile engine honours the same k_splits contract
     if (variant == 54 || variant == 58) {      // kernel tests: the skinny kernel with 4 / 8 K slices
         GemmParams q = p; q.k_splits = variant - 50;
         if (launch_gemm_skinny(q, nsplit, st)) return;

@@ -27,12 +27,13 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const GemmParams p
     const int fr = lane & 15, fk = lane >> 4;
     int Meff = p.M;
     if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
-    if (p.flop_counter && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+    if (p.flop_counter && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
         atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)p.N * (unsigned long long)p.K);
     const int r0 = blockIdx.y * (FM * 16);      // row block (launches of more than 128 rows: blocks of 128, FM = 8)
     if (Meff <= r0) return;
     const int n0 = blockIdx.x * 16;
-    const int nk = p.K >> 5, per = nk / KS, kt0 = wave * per;
+    // K slices: KS waves of this workgroup x gridDim.z workgroups (gridDim.z > 1: the slice sums leave as fp32 partials, GemmParams::c_split_stride apart)
+    const int nk = p.K >> 5, per = nk / (KS * (int)gridDim.z), kt0 = ((int)blockIdx.z * KS + wave) * per;
 
     f32x4 acc[FM];
 #pragma unroll
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const GemmParams p
         const long long orow = p.cmap(r0 + row);
         if (p.out_kind == OUT_F32) {
             float* dst = p.hm_rows ? p.c_f32 + ((long long)((p.hm_col0 + col) >> 6) * p.hm_rows + orow) * 64 + ((p.hm_col0 + col) & 63)
-                                   : p.c_f32 + orow * p.ldc + col;
+                                   : p.c_f32 + (long long)blockIdx.z * p.c_split_stride + orow * p.ldc + col;
             *reinterpret_cast<f32x4*>(dst) = v;
         } else {
             bf16x4 h, l;
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const GemmParams p
 }
 
 template <int FM, int KS, int U, int WPL>
-void launch_act(const GemmParams& p, hipStream_t st) {
-    const dim3 grid(p.N / 16, (p.M + FM * 16 - 1) / (FM * 16)), block(64 * KS);
+void launch_act(const GemmParams& p, int slices, hipStream_t st) {
+    const dim3 grid(p.N / 16, (p.M + FM * 16 - 1) / (FM * 16), slices), block(64 * KS);
     switch (p.act) {
         case ACT_RELU: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_RELU, U, WPL>), grid, block, 0, st, p); break;
         case ACT_GELU_TANH: hipLaunchKernelGGL((gemm_skinny_kernel<FM, KS, ACT_GELU_TANH, U, WPL>), grid, block, 0, st, p); break;
@@ -121,27 +122,27 @@ void launch_act(const GemmParams& p, hipStream_t st) {
     }
 }
 template <int FM, int KS, int WPL>
-void launch_fm(const GemmParams& p, hipStream_t st) {
+void launch_fm(const GemmParams& p, int slices, hipStream_t st) {
     // K steps in flight per wave: what the register file holds (operand registers at WPL = 1: FM = 2: 120, FM = 4: 216, FM = 6: 156, FM = 8: 136; the lo
     // weight fragment of mode 3 adds 4 per step: FM = 4 runs three steps per trip there)
     constexpr int DEEP = FM <= 2 ? 6 : FM <= 4 ? (WPL == 2 ? 3 : 6) : FM <= 6 ? 3 : 2;
-    const int per = (p.K >> 5) / KS;
-    if (per % DEEP == 0) launch_act<FM, KS, DEEP, WPL>(p, st);
-    else launch_act<FM, KS, 2, WPL>(p, st);
+    const int per = (p.K >> 5) / (KS * slices);
+    if (per % DEEP == 0) launch_act<FM, KS, DEEP, WPL>(p, slices, st);
+    else launch_act<FM, KS, 2, WPL>(p, slices, st);
 }
 
 template <int KS, int WPL>
-void launch_ks(const GemmParams& p, hipStream_t st) {
-    if (p.M <= 32) launch_fm<2, KS, WPL>(p, st);
-    else if (p.M <= 64) launch_fm<4, KS, WPL>(p, st);
-    else if (p.M <= 96) launch_fm<6, KS, WPL>(p, st);      // (zk's label-text projection of a 1-pair call: 8 positions x 10 labels = 80 rows, K = 6144)
-    else launch_fm<8, KS, WPL>(p, st);      // more than 128 rows: row blocks of 128
+void launch_ks(const GemmParams& p, int slices, hipStream_t st) {
+    if (p.M <= 32) launch_fm<2, KS, WPL>(p, slices, st);
+    else if (p.M <= 64) launch_fm<4, KS, WPL>(p, slices, st);
+    else if (p.M <= 96) launch_fm<6, KS, WPL>(p, slices, st);      // (zk's label-text projection of a 1-pair call: 8 positions x 10 labels = 80 rows, K = 6144)
+    else launch_fm<8, KS, WPL>(p, slices, st);      // more than 128 rows: row blocks of 128
 }
 template <int WPL>
 bool launch_wpl(const GemmParams& p, int ks, hipStream_t st) {
-    if (ks == 1) launch_ks<1, WPL>(p, st);
-    else if (ks == 4) launch_ks<4, WPL>(p, st);
-    else if (ks == 8) launch_ks<8, WPL>(p, st);
+    if (ks == 1) launch_ks<1, WPL>(p, 1, st);
+    else if (ks == 4) launch_ks<4, WPL>(p, 1, st);
+    else if (ks == 8) launch_ks<8, WPL>(p, 1, st);
     else return false;
     return true;
 }
@@ -161,4 +162,18 @@ bool launch_gemm_skinny(const GemmParams& p, int nsplit, hipStream_t st) {
     if (nsplit == 3 && !p.w_lo) return false;
     if (p.out_kind != OUT_F32 && p.out_kind != OUT_PLANES) return false;
     return nsplit == 3 ? launch_wpl<2>(p, ks, st) : launch_wpl<1>(p, ks, st);
+}
+
+// The same kernel with the K slices dealt to WORKGROUPS instead of waves (GemmParams::k_splits of them, one wave each: N / 16 x k_splits workgroups): slice s
+// leaves as an fp32 partial at c_f32 + s * c_split_stride -- the split-K contract of gemm_tile.hip (no bias / activation / residual; the LayerNorm kernel behind
+// it sums the partials).  For the N = 768 projections: 48 column blocks are too few workgroups to stream a K = 3072 weight matrix (98 KB each: 9 us); 384 single-wave
+// workgroups of 12 KB each take half.  Same slices, same order, same sum in k_ln_to_planes: bit-identical to both the in-workgroup form and the tile route.
+bool launch_gemm_skinny_parts(const GemmParams& p, int nsplit, hipStream_t st) {
+    if (p.M <= 0) return true;
+    const int S = p.k_splits;
+    if (S < 2 || (nsplit != 2 && nsplit != 3) || p.M > SKINNY_MAX_ROWS || p.N % 16 || p.K % (64 * S) || p.f8 || p.r_hi || p.ln_gamma) return false;
+    if (nsplit == 3 && !p.w_lo) return false;
+    if (p.out_kind != OUT_F32 || p.hm_rows || p.bias || p.act != ACT_NONE || p.cmap.grp) return false;
+    if (nsplit == 3) launch_ks<1, 2>(p, S, st); else launch_ks<1, 1>(p, S, st);
+    return true;
 }

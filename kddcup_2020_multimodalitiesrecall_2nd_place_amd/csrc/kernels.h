@@ -59,6 +59,7 @@ struct GemmParams {
 int device_cu_count();
 void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
+bool launch_gemm_skinny_parts(const GemmParams& p, int nsplit, hipStream_t st);        // ... with the K slices dealt to workgroups: k_splits fp32 partials, c_split_stride apart (variant 55; the LayerNorm kernel sums them)
 bool launch_gemm_skinny(const GemmParams& p, int nsplit, hipStream_t st);              // gemm_skinny.hip: a handful of rows (api.hip: <= 128), precision modes 2 and 3, one workgroup per 16 output columns, K split over its waves (variant 5); false: not taken
 #ifdef MMS_LAB
 bool launch_gemm_dw(const GemmParams& p, int nsplit, hipStream_t st);                                                       // lab: gemm_dw.hip (variant 28: 128x256 tiles, two 4-wave workgroups per CU)

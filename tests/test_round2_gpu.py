@@ -459,6 +459,32 @@ def test_split_k_projection_with_partials_summed_in_the_layernorm(case):
     assert err < 3e-5, err
 
 
+@pytest.mark.parametrize("case", [(1, 768, 4), (30, 768, 4), (30, 3072, 8), (65, 3072, 8), (120, 768, 4), (128, 3072, 8), (200, 768, 4)])
+def test_skinny_partials_equal_the_tile_engines_bit_for_bit(case):
+    """Launches of <= 128 rows of the LayerNorm-followed N = 768 projections: the split-K partials come from gemm_skinny.hip with the K slices dealt to
+    single-wave workgroups (launch_gemm_skinny_parts) -- same slices, same accumulation order, same sum in k_ln_to_planes as the tile engine's: bit-identical."""
+    M, K, S = case
+    l = lib.load()
+    a = weights.normal("skp/a/%d/%d" % (M, K), (M, K), 1)
+    w = weights.round_to_bf16(weights.normal("skp/w/%d" % K, (768, K), 1, 1.0 / np.sqrt(K)))
+    bias = weights.normal("skp/b", (768,), 1, 0.1)
+    r = weights.normal("skp/r/%d" % M, (M, 768), 1) + 0.3
+    gamma = weights.normal("skp/g", (768,), 1, 0.1, 1.0)
+    beta = weights.normal("skp/be", (768,), 1, 0.1)
+    da, dw, db, dr, dg, dbe = _dev(a), _dev(w), _dev(bias), _dev(r), _dev(gamma), _dev(beta)
+    outs = []
+    for splits in (S, -S):
+        out = torch.empty((M, 768), device="cuda", dtype=torch.float32)
+        rc = l.mms_dbg_proj_ln_splitk(da.data_ptr(), M, K, dw.data_ptr(), db.data_ptr(), dr.data_ptr(), dg.data_ptr(), dbe.data_ptr(), splits, out.data_ptr(), None)
+        assert rc == 0, l.mms_global_error()
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]), case
+    v = a.astype(np.float64) @ w.astype(np.float64).T + bias + r
+    mu = v.mean(1, keepdims=True)
+    ref = (v - mu) / np.sqrt(((v - mu) ** 2).mean(1, keepdims=True) + 1e-12) * gamma + beta
+    assert np.abs(outs[1] - ref).max() / np.abs(ref).max() < 3e-5
+
+
 SKINNY_SHAPES = [  # K, N, act, planes
     (768, 2304, lib.ACT_NONE, False),       # Q | K | V
     (768, 3072, lib.ACT_GELU_TANH, True),   # FFN up, planes out
