@@ -612,7 +612,10 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     // K steps, 170 us per call whatever the batch) and kdd_conv2 / visn_fc / featureemb (K = 2048) below TALL_ROWS box rows: eight K slices
     constexpr int64_t TALL_ROWS = 4096;
     const bool tall = splittable && !wide && M < TALL_ROWS && N == H && K >= 2048 && K % 512 == 0;
-    const bool tiny = (wide || tall) && !skinny;
+    // a long-K projection of a few rows (kdd_conv1 as im2col: 80 rows x K = 6144 in a 1-pair call): its K slices go to single-wave WORKGROUPS of the skinny
+    // kernel and k_splitk_reduce sums them -- in one workgroup per 16 columns every workgroup pulls all rows x all of K (2 MB) through one CU: 40 us
+    const bool skinny_tall = skinny && tall;
+    const bool tiny = (wide || tall) && (!skinny || skinny_tall);
     // the skinny kernel slices K the way this projection's tile route does for launches of up to 255 rows, so that it is bit-identical to it
     const int skinny_ks = force_ks ? force_ks : wide ? 4 : tall ? 8 : 1;
     GemmParams p{};
@@ -633,16 +636,17 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     const long long part_stride = (tall ? TALL_ROWS : TINY_ROWS) * (long long)N;      // <= 8 x 4096 x 768 floats: inside kparts (KSPLIT_MAX x SPLITK_ROWS x 768)
     if (tiny) {      // K slices into fp32 partials; the reduce kernel below applies what the epilogue would have
         if (int rc = ensure_kparts(h)) return rc;
-        h->splitk_launches += 1;
+        (skinny_tall ? h->skinny_launches : h->splitk_launches) += 1;
         p.bias = nullptr; p.act = ACT_NONE; p.out_kind = OUT_F32; p.c_f32 = h->kparts; p.ldc = N; p.hm_rows = 0; p.hm_col0 = 0;
         p.k_splits = TINY_S; p.c_split_stride = part_stride;
+        if (skinny_tall) p.variant = 55;
     }
     auto tiny_reduce = [&]() {
         if (tiny) launch_splitk_reduce(h->kparts, TINY_S, part_stride, (int)M, N, m_dev, bias, act, out.f32, out.ldc, out.hm_rows, out.hm_col0,
                                        out.pl.hi, out.pl.lo, out.ldp, st);
     };
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
-    if (skinny) { p.variant = 5; p.k_splits = skinny_ks; h->skinny_launches += 1; }
+    if (skinny && !skinny_tall) { p.variant = 5; p.k_splits = skinny_ks; h->skinny_launches += 1; }
     if (h->timing) {
         if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
         p.flop_counter = h->flop_counter;   // executed algorithmic FLOPs (2*M_live*N*K), counted on the device
