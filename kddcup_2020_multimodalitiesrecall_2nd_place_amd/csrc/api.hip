@@ -138,6 +138,7 @@ struct mms_handle {
     size_t ev_used = 0;
     int64_t gemm_launches = 0;
     int64_t fused_attn_launches = 0;     // qkv_attn.hip launches since mms_create (mms_dbg_counter)
+    bool zk_plans_merged = false;        // zk_image_tokens() already built this launch wave's token plan (small waves: launch_zk_plans_small)
     int64_t skinny_launches = 0;         // gemm_skinny.hip launches (launches of <= 128 padded rows) since mms_create
     int64_t ln_fused_launches = 0, splitk_launches = 0;      // LayerNorm-fused GEMM launches / split-K launches (small-call routes) since mms_create
     std::vector<hipEvent_t> ev_fused; size_t ev_fused_used = 0; int64_t fused_timed = 0;     // timing of the fused launches, apart from the GEMMs' (mms_fused_timing)
@@ -1099,8 +1100,13 @@ int zk_image_tokens(mms_handle* h, hipStream_t st, const mms_zk_batch* b, const 
     Planes featp = h->mid;
     const int* box_idx = nullptr;
     const int* box_rows = nullptr;
+    h->zk_plans_merged = false;
     if (compact) {      // stream 1's plan buffers are idle in a zk handle
-        launch_zk_box_plan(b->len_query + p0, b->num_boxes + p0, h->cfg.text_len, (int)n, h->pk_cnt[1], h->pk_off[1], h->pk_src[1], h->pk_rows + 1, st);
+        // small launch waves: the token plan of zk_encode() rides along (one launch instead of six; nothing in between touches its tables)
+        h->zk_plans_merged = launch_zk_plans_small(b->len_query + p0, b->num_boxes + p0, h->cfg.text_len, (int)n, h->pk_cnt[1], h->pk_off[1], h->pk_src[1],
+                                                   h->pk_cnt[0], h->pk_off[0], h->pk_src[0], h->key_add, h->pk_rows, st);
+        if (!h->zk_plans_merged)
+            launch_zk_box_plan(b->len_query + p0, b->num_boxes + p0, h->cfg.text_len, (int)n, h->pk_cnt[1], h->pk_off[1], h->pk_src[1], h->pk_rows + 1, st);
         box_idx = h->pk_src[1]; box_rows = h->pk_rows + 1;
         launch_split_f32_rows(b->feats + p0 * MMS_NBOX * MMS_FEAT, box_idx, box_rows, (int)NB, MMS_FEAT, featp.hi, featp.lo, st);
     } else if (featp_shared) featp = *featp_shared;
@@ -1121,8 +1127,10 @@ int zk_encode(mms_handle* h, hipStream_t st, const mms_zk_batch* b, int64_t p0, 
     // --- embeddings + mask (packed: live tokens only, laid out contiguously) ---
     Pack pk;
     if (c.pack_tokens) {
-        launch_zk_pack_plan(b->len_query + p0, b->num_boxes + p0, T, (int)n, h->pk_off[0], h->pk_cnt[0], h->pk_src[0], h->key_add,
-                            h->pk_rows, st);
+        if (!h->zk_plans_merged)
+            launch_zk_pack_plan(b->len_query + p0, b->num_boxes + p0, T, (int)n, h->pk_off[0], h->pk_cnt[0], h->pk_src[0], h->key_add,
+                                h->pk_rows, st);
+        h->zk_plans_merged = false;
         pk.off = h->pk_off[0]; pk.cnt = h->pk_cnt[0]; pk.rows = h->pk_rows;
         launch_zk_embed_packed(h->E, h->type_tab, h->pos_tab, h->emb_g, h->emb_b, b->query_ids + p0 * T, b->segment_ids + p0 * S, tok,
                                T, c.vocab, h->pk_src[0], h->pk_rows, (int)(n * S), h->x.hi, h->x.lo, st, box_off);

@@ -144,6 +144,9 @@ void launch_zk_tokpre(const float* labfeat, const int* lab_index, int n_labels, 
                       const int* src = nullptr, const int* rows_dev = nullptr);      // src: compact rows, row r stands for box src[r]; r < *rows_dev
 // live boxes of a packed zk wave: cnt / off per pair, box_idx[off[b] + j] = b * 10 + j, *rows_dev = their number (rowops.hip)
 void launch_zk_box_plan(const int* len_query, const int* num_boxes, int T, int n, int* cnt, int* off, int* box_idx, int* rows_dev, hipStream_t st);
+// n <= 1024 pairs: box plan + token plan (launch_zk_pack_plan) in ONE single-block launch; rows_dev[0] = live tokens, rows_dev[1] = live boxes; false: n too large
+bool launch_zk_plans_small(const int* len_query, const int* num_boxes, int T, int n, int* b_cnt, int* b_off, int* box_idx, int* t_cnt, int* t_off,
+                           int* tok_src, float* key_add, int* rows_dev, hipStream_t st);
 void launch_split_f32_rows(const float* in, const int* idx, const int* rows_dev, int max_rows, int width, bf16* o_hi, bf16* o_lo, hipStream_t st);
 void launch_zk_embed(const float* E, const float* type_tab, const float* pos_tab, const float* gamma,
                      const float* beta, const int* query_ids, const int* segment_ids, const float* tok,

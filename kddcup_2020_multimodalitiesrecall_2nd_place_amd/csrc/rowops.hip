@@ -860,6 +860,35 @@ void launch_zk_box_plan(const int* len_query, const int* num_boxes, int T, int n
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PLAN_THREADS), 0, st, cnt, n, off, rows_dev);
     hipLaunchKernelGGL(k_zk_box_fill, grid, dim3(256), 0, st, cnt, off, n, box_idx);
 }
+// Small launch waves (n <= 1024 pairs: the reference's call sizes): the box plan and the token plan above -- six launches of ~4.5 us each in a chain that is
+// all latency -- as ONE single-block kernel (one thread per pair, two block scans).  Same tables, same totals.
+__global__ __launch_bounds__(PLAN_THREADS) void k_zk_plans_small(const int* len_query, const int* num_boxes, int T, int n, int* b_cnt, int* b_off, int* box_idx,
+                                                                 int* t_cnt, int* t_off, int* tok_src, float* key_add, int* rows_dev) {
+    __shared__ int sh[PLAN_THREADS];
+    const int b = threadIdx.x;
+    const bool valid = b < n;
+    const int S = T + MMS_NBOX;
+    const int lq = valid ? min(max(len_query[b], 0), T) : 0, nb = valid ? min(max(num_boxes[b], 0), MMS_NBOX) : 0;
+    const bool dense = (lq + nb == 0);
+    const int nt = dense ? T : max(lq, 1), nv = dense ? MMS_NBOX : nb;      // k_zk_plan_fill's / k_zk_box_count's rule: a pair with nothing live keeps everything
+    int total;
+    const int boff = plan_scan(valid ? nv : 0, sh, &total);
+    if (b == 0) rows_dev[1] = total;
+    const int toff = plan_scan(valid ? nt + nv : 0, sh, &total);
+    if (b == 0) rows_dev[0] = total;
+    if (!valid) return;
+    b_cnt[b] = nv; b_off[b] = boff;
+    for (int j = 0; j < nv; ++j) box_idx[boff + j] = b * MMS_NBOX + j;
+    t_cnt[b] = nt + nv; t_off[b] = toff;
+    for (int s = 0; s < nt; ++s) { tok_src[toff + s] = b * S + s; key_add[toff + s] = s < lq ? 0.f : -10000.f; }
+    for (int j = 0; j < nv; ++j) { tok_src[toff + nt + j] = b * S + T + j; key_add[toff + nt + j] = j < nb ? 0.f : -10000.f; }
+}
+bool launch_zk_plans_small(const int* len_query, const int* num_boxes, int T, int n, int* b_cnt, int* b_off, int* box_idx, int* t_cnt, int* t_off,
+                           int* tok_src, float* key_add, int* rows_dev, hipStream_t st) {
+    if (n <= 0 || n > PLAN_THREADS) return false;
+    hipLaunchKernelGGL(k_zk_plans_small, dim3(1), dim3(PLAN_THREADS), 0, st, len_query, num_boxes, T, n, b_cnt, b_off, box_idx, t_cnt, t_off, tok_src, key_add, rows_dev);
+    return true;
+}
 __global__ __launch_bounds__(256) void k_zk_embed_packed(const float* E, const float* type_tab, const float* pos_tab,
                                                          const float* gamma, const float* beta, const int* query_ids,
                                                          const int* segment_ids, const float* tok, int T, int vocab,
