@@ -569,9 +569,10 @@ struct GemmOut {
 
 int ensure_kparts(mms_handle* h);
 // Launches of at most SKINNY_ROWS padded rows in precision modes 2 and 3 (the reference's zk call size: 1 pair = 30 token rows; up to 4 zk / 3 lds / 6 lxmert pairs,
-// and the box-row projections of up to 12 pairs): gemm_skinny.hip -- one workgroup per 16 output columns, K split over its waves, no LDS staging, no
-// partial buffer, ONE launch where the split-K routes below need two.  128, measured (profiles/rd4r_skinny_gemm.txt): above it a workgroup's A panel
-// (> 393 KB through one CU's fill path) costs more than the second launch saves.
+// and the box-row projections of up to 12 pairs): gemm_skinny.hip -- one workgroup per 16 output columns, no LDS staging; K split over the workgroup's waves
+// (wide projections: ONE launch where the split-K tile route needs two) or, where a LayerNorm / reduce launch follows anyway, over single-wave workgroups
+// that leave the tile engine's partials.  128, measured (profiles/rd4r_skinny_gemm.txt): above it the rows a workgroup pulls through one CU's fill path cost
+// more than the launch saved.
 constexpr int64_t SKINNY_ROWS_DEFAULT = 128;
 int64_t skinny_rows() {
 #ifdef MMS_LAB
@@ -617,7 +618,7 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     // kernel and k_splitk_reduce sums them -- in one workgroup per 16 columns every workgroup pulls all rows x all of K (2 MB) through one CU: 40 us
     const bool skinny_tall = skinny && tall;
     const bool tiny = (wide || tall) && (!skinny || skinny_tall);
-    // the skinny kernel slices K the way this projection's tile route does for launches of up to 255 rows, so that it is bit-identical to it
+    // the skinny kernel slices K the way this projection's tile route does for launches below TINY_ROWS, so that it is bit-identical to it
     const int skinny_ks = force_ks ? force_ks : wide ? 4 : tall ? 8 : 1;
     GemmParams p{};
     p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.amap = amap;
