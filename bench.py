@@ -652,6 +652,23 @@ def secondary(a, local, dev, ps, feats, members, scorer, feed, value):
                        "note": "rank 0's query block of the N = 8 job scored alone on this GPU; 8 x that = the 8-GPU rate if ranks do not disturb each other (the gather is 15 KB per rank)"}
         del fd, f_
     out["shard_rates"] = shard
+    # ---- the reference's own call sizes through the same handle (zk scores ONE pair per sess.run, evaluate_normal.py:15; lds 5, lxmert 256): latency of a
+    # synchronised call; `--batch-sweep` has the three models and the larger sizes ----
+    whole = synth.make_pairs(9, 30, tag="/bench0", with_feats=False)
+    f_all = device_feats(whole, dev, 20200823)
+    calls = {}
+    for B in (1, 5, 256):
+        ps_ = whole.take(slice(0, B))
+        fd = device_feed("zk", {"zk": zcfg}, ps_, f_all[:B], dev)
+        for _ in range(3):
+            zs.score_prepared(prepare(zs, "zk", fd))
+        torch.cuda.synchronize()
+        n, t0 = 100, time.perf_counter()
+        for _ in range(n):
+            zs.score_prepared(prepare(zs, "zk", fd))
+            torch.cuda.synchronize()
+        calls[str(B)] = round((time.perf_counter() - t0) / n * 1e3, 4)
+    out["call_latency_ms"] = {"model": "zk", "pairs_per_call": calls, "note": "one synchronised scoring call of B pairs (device-resident inputs); small launches run on gemm_skinny.hip / split-K tiles (DESIGN.md section 3)"}
     return out
 
 

@@ -46,6 +46,8 @@ def test_bench_prints_one_contract_line():
     assert sec["dense"]["live_token_fraction"] == 1.0
     sh = sec["shard_rates"]
     assert sh["bench_strong_n8"]["predicted_strong_8"] == round(8 * sh["bench_strong_n8"]["value_one_gpu"], 1) and sh["testB_n8"]["pairs_rank0"] > 0
+    cl = sec["call_latency_ms"]["pairs_per_call"]      # the reference's own call sizes through the same handle
+    assert 0 < cl["1"] < cl["256"] and cl["1"] < 5.0, cl
     assert d["value_fp32_checkpoint"] == p3     # mode 3 also as a top-level value
     # the line runs the LIBRARY defaults: what make_scorer(cfg, weights) gives a user
     assert d["config"]["fuse_attention"] == 2 and d["config"]["fuse_layernorm"] == 3
