@@ -99,10 +99,11 @@ struct mms_handle {
     float* ln_stats = nullptr; int* ln_ctl = nullptr; int ln_slot = 0; unsigned ln_tag = 0;
 
     static constexpr int LN_SLOTS = 2048;
-    float* kparts = nullptr; int64_t kparts_rows = 0;      // fp32 partials of the split-K launches (small N = 768 projections), KSPLIT_MAX x rows x 768
+    float* kparts = nullptr; int64_t kparts_floats = 0;    // fp32 partials of the split-K launches (small calls): slices x launch rows x N, sized with the workspace (ensure_kparts)
     int fuse_ln = 0;       // mms_config.fuse_layernorm (lab build: env MMS_FUSE_LN overrides)
     int fuse_attn = 0;     // mms_config.fuse_attention: QKV projection + self-attention in one kernel (qkv_attn.hip; precision mode 2)
-    int4* qa_sub[2] = {nullptr, nullptr}; int* qa_nsub = nullptr;     // sub-tile tables of the (up to two) token streams of a launch wave
+    int* qa_rec[3] = {nullptr, nullptr, nullptr};      // per-pair records of the tables (split-bf16 attention route)
+    int4* qa_sub[4] = {nullptr, nullptr, nullptr, nullptr}; int* qa_nsub = nullptr;     // sub-tile tables of the (up to two) token streams of a launch wave; [2], [3]: the CROSS table of the stream pair (lxmert X layers)
     // label-text workspace, sized for lab_cap unique labels
     int64_t lab_cap = 0;
     Planes lab_planes; float *lab_f32 = nullptr, *lab_feat = nullptr; int64_t lab_feat_cap = 0;
@@ -466,6 +467,9 @@ int alloc_planes(mms_handle* h, std::vector<void*>& pool, Planes* p, int64_t ele
     return MMS_OK;
 }
 
+int ensure_kparts(mms_handle* h, int64_t floats);
+int64_t kparts_need(const mms_handle* h, int64_t pairs, int64_t rows);
+
 int ensure_workspace(mms_handle* h, int64_t pairs) {
     if (pairs <= h->ws_pairs) return MMS_OK;
     free_pool(h->ws_allocs);
@@ -521,9 +525,13 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     }
     if (int rc = dev_alloc(h, h->ws_allocs, &p, 16)) return rc;
     h->pk_rows = (int*)p;
-    for (int s = 0; s < 2; ++s) {      // a sub-tile holds at least one pair
+    for (int s = 0; s < (c.model == MMS_MODEL_LXMERT ? 4 : 2); ++s) {      // a sub-tile holds at least one pair
         if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(pairs + 2) * sizeof(int4))) return rc;
         h->qa_sub[s] = (int4*)p;
+    }
+    for (int s = 0; s < (c.model == MMS_MODEL_LXMERT ? 3 : 1); ++s) {
+        if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(pairs + 2) * 4)) return rc;
+        h->qa_rec[s] = (int*)p;
     }
     if (int rc = dev_alloc(h, h->ws_allocs, &p, 16)) return rc;
     h->qa_nsub = (int*)p;
@@ -532,6 +540,7 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     HIP_TRY(h, hipMemset(p, 0, (size_t)(rows + 256) * 3 * 2 * 8));
     if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)mms_handle::LN_SLOTS * 2 * 4)) return rc;
     h->ln_ctl = (int*)p;
+    if (int rc = ensure_kparts(h, kparts_need(h, pairs, rows))) return rc;
     h->ws_pairs = pairs;
     return MMS_OK;
 }
@@ -567,7 +576,7 @@ struct GemmOut {
     RowMap cmap{0, 0, 0};
 };
 
-int ensure_kparts(mms_handle* h);
+int ensure_kparts(mms_handle* h, int64_t floats);
 // Launches of at most SKINNY_ROWS padded rows in precision modes 2 and 3 (the reference's zk call size: 1 pair = 30 token rows; up to 4 zk / 3 lds / 6 lxmert pairs,
 // and the box-row projections of up to 12 pairs): gemm_skinny.hip -- one workgroup per 16 output columns, no LDS staging; K split over the workgroup's waves
 // (wide projections: ONE launch where the split-K tile route needs two) or, where a LayerNorm / reduce launch follows anyway, over single-wave workgroups
@@ -635,9 +644,9 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     if (resid && !h->resid_in_ln) { p.r_hi = resid->hi; p.r_lo = resid->lo; p.ldr = H; }
     p.m_dev = m_dev; p.a_index = a_index; p.rmap = rmap; p.r_index = r_index;
     const int TINY_S = tall ? 8 : 4;
-    const long long part_stride = (tall ? TALL_ROWS : TINY_ROWS) * (long long)N;      // <= 8 x 4096 x 768 floats: inside kparts (KSPLIT_MAX x SPLITK_ROWS x 768)
+    const long long part_stride = (long long)M * N;      // the launch's own row bound: a 1-pair call needs a few MB of partials, not the 200 MB of the largest split launch
     if (tiny) {      // K slices into fp32 partials; the reduce kernel below applies what the epilogue would have
-        if (int rc = ensure_kparts(h)) return rc;
+        if (int rc = ensure_kparts(h, TINY_S * part_stride)) return rc;      // (no-op: ensure_workspace sized it for every split launch of this workspace)
         (skinny_tall ? h->skinny_launches : h->splitk_launches) += 1;
         p.bias = nullptr; p.act = ACT_NONE; p.out_kind = OUT_F32; p.c_f32 = h->kparts; p.ldc = N; p.hm_rows = 0; p.hm_col0 = 0;
         p.k_splits = TINY_S; p.c_split_stride = part_stride;
@@ -653,14 +662,14 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
         if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
         p.flop_counter = h->flop_counter;   // executed algorithmic FLOPs (2*M_live*N*K), counted on the device
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
-        launch_gemm(p, nsplit, st);
+        if (!launch_gemm(p, nsplit, st)) return h->fail(MMS_ERR_ARG, "gemm: no engine takes this shape");
         tiny_reduce();
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
         h->ev_cls.resize(h->ev_used / 2 + 1); h->ev_cls[h->ev_used / 2] = 0;
         h->ev_used += 2;
         h->gemm_launches += 1;
     } else {
-        launch_gemm(p, nsplit, st);
+        if (!launch_gemm(p, nsplit, st)) return h->fail(MMS_ERR_ARG, "gemm: no engine takes this shape");
         tiny_reduce();
     }
     return MMS_OK;
@@ -787,12 +796,25 @@ int splitk_for(const mms_handle* h, int64_t M, int K) {
     const int S = K >= 2048 ? 8 : 4;
     return K % (64 * S) == 0 ? S : 1;
 }
-int ensure_kparts(mms_handle* h) {
-    if (h->kparts) return MMS_OK;
-    void* p;
-    if (int rc = dev_alloc(h, h->w_allocs, &p, (size_t)KSPLIT_MAX * SPLITK_ROWS * H * 4)) return rc;     // 200 MB, once per handle, at its first small call
-    h->kparts = (float*)p; h->kparts_rows = SPLITK_ROWS;
+int ensure_kparts(mms_handle* h, int64_t floats) {
+    if (floats <= h->kparts_floats) return MMS_OK;
+    if (h->kparts) { (void)hipFree(h->kparts); h->kparts = nullptr; h->kparts_floats = 0; }      // (hipFree waits for the work that may still read it)
+    void* p = nullptr;
+    HIP_TRY(h, hipMalloc(&p, (size_t)floats * 4));
+    h->kparts = (float*)p; h->kparts_floats = floats;
     return MMS_OK;
+}
+// Partials of every split-K launch a workspace of `pairs` pairs can issue (sized here, with the workspace, so that a scoring call on a warmed-up
+// handle never allocates; a 1-pair handle holds ~2 MB instead of a fixed 200 MB): the N = 768 projections of launches below SPLITK_ROWS token rows (8 slices x rows x 768), the
+// wide projections below TINY_ROWS (4 x rows x max(2304, inter)), the long-K projections in front of the encoder below 4096 box / label-text rows (8 x rows x 768)
+int64_t kparts_need(const mms_handle* h, int64_t pairs, int64_t rows) {
+    const int64_t r_ln = rows < SPLITK_ROWS ? rows : SPLITK_ROWS, r_wide = rows < TINY_ROWS ? rows : TINY_ROWS;
+    const int64_t lab = pairs * MMS_NBOX * MMS_LABEL_LEN, r_tall = lab < 4096 ? lab : 4096;
+    const int64_t nmax = h->cfg.inter > 3 * H ? h->cfg.inter : 3 * H;
+    int64_t need = (int64_t)KSPLIT_MAX * r_ln * H;
+    if (4 * r_wide * nmax > need) need = 4 * r_wide * nmax;
+    if ((int64_t)KSPLIT_MAX * r_tall * H > need) need = (int64_t)KSPLIT_MAX * r_tall * H;
+    return need;
 }
 
 // out = LayerNorm(A W^T + bias + resid) for a bf16 N = 768 projection on the two-kernel route: split-K partials (small M) or the plain fp32
@@ -803,7 +825,7 @@ int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap
     const int S = splitk_for(h, M, K);
     const bool skinny = skinny_shape(h, M, K);      // <= 128 rows: the partials come from the skinny kernel, one single-wave workgroup per (16 columns, K slice)
     if (S > 1) {
-        if (int rc = ensure_kparts(h)) return rc;
+        if (int rc = ensure_kparts(h, (int64_t)S * M * H)) return rc;
         (skinny ? h->skinny_launches : h->splitk_launches) += 1;
         GemmParams p{};
         p.a_hi = a.hi; p.a_lo = a.lo; p.lda = lda; p.amap = amap; p.a_index = a_index;
@@ -814,19 +836,19 @@ int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap
             if (!p.w_lo) return h->fail(MMS_ERR_STATE, "proj_ln: weight has no lo plane");
         }
         p.out_kind = OUT_F32; p.c_f32 = h->kparts; p.ldc = H; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
-        p.k_splits = S; p.c_split_stride = (long long)h->kparts_rows * H;
+        p.k_splits = S; p.c_split_stride = (long long)M * H;
         p.m_dev = m_dev;
         if (skinny) p.variant = 55;      // gemm_skinny.hip, K slices dealt to workgroups (same partials as the tile engine's: bit-identical)
         if (h->timing) {
             if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
             p.flop_counter = h->flop_counter;
             HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
-            launch_gemm(p, h->nsplit, st);
+            if (!launch_gemm(p, h->nsplit, st)) return h->fail(MMS_ERR_ARG, "proj_ln: no engine takes this shape");
             HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], st));
             h->ev_cls.resize(h->ev_used / 2 + 1); h->ev_cls[h->ev_used / 2] = 0;
             h->ev_used += 2;
             h->gemm_launches += 1;
-        } else launch_gemm(p, h->nsplit, st);
+        } else if (!launch_gemm(p, h->nsplit, st)) return h->fail(MMS_ERR_ARG, "proj_ln: no engine takes this shape");
         LnResid r;
         r.hi = resid.hi; r.lo = resid.lo; r.ld = H; r.rmap = rmap; r.r_index = r_index;
         r.nparts = S; r.part_stride = p.c_split_stride; r.bias = bias;
@@ -843,14 +865,41 @@ int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap
 // Packed-stream descriptor: per-pair first row / live count (relative to the stream's first row) and the
 // device-side number of live rows.  off == nullptr: dense layout (row of (b, s) = b * S + s).
 struct Pack { const int* off = nullptr; const int* cnt = nullptr; const int* rows = nullptr;
-              const int4* sub = nullptr; const int* n_sub = nullptr; };     // sub-tile table of the fused QKV + attention kernel (plan_tiles)
+              const int4* sub = nullptr; const int* n_sub = nullptr;      // sub-tile table of the fused QKV + attention kernel (plan_tiles)
+              const int4* sub2 = nullptr;                                // CROSS table (plan_cross_tiles): the sub-tiles' rows in the second stream
+              const int* rec = nullptr; };                               // per-pair records of the table
 
 // sub-tile table of one token stream (n pairs of at most S tokens; packed or dense) for qkv_attn.hip, in table slot `slot`
 void plan_tiles(mms_handle* h, hipStream_t st, Pack& pk, int64_t n, int S, int slot) {
     if (!h->fuse_attn || (h->nsplit != 2 && h->nsplit != 3) || h->f8 || S > 48) return;
-    if (n * S < 16384 || S < 16) return;      // att_block() takes the fused kernel only for launches of >= 16384 rows with pairs of >= 16 tokens (the plan is 68 us: 2.4 % of a 256-pair call)
-    launch_qkv_tile_plan(pk.off, pk.cnt, pk.rows, (int)n, S, h->qa_sub[slot], h->qa_nsub + slot, h->nsplit, st);
-    pk.sub = h->qa_sub[slot]; pk.n_sub = h->qa_nsub + slot;
+    // att_block() takes the fused kernel only for launches of >= 16384 rows (the plan is 68 us: 2.4 % of a 256-pair call); the exact-fp32 attention route
+    // (fuse_attention = 1: one work item per pair and 16-query tile) only for pairs of >= 16 tokens -- the split-bf16 route works on 16-row tiles of the sub-tile
+    // whatever the pairs' lengths (lxmert's 10-token box stream included)
+    if (n * S < 16384 || (S < 16 && h->fuse_attn != 2)) return;
+    launch_qkv_tile_plan(pk.off, pk.cnt, pk.rows, (int)n, S, h->qa_sub[slot], h->qa_nsub + slot, h->nsplit, st, h->qa_rec[slot]);
+    pk.sub = h->qa_sub[slot]; pk.n_sub = h->qa_nsub + slot; pk.rec = h->qa_rec[slot];
+}
+// ... of a PAIR of streams for the fused cross-attention launches of lxmert's X layers (fuse_attention = 2): a sub-tile = the rows of its pairs in both streams
+void plan_cross_tiles(mms_handle* h, hipStream_t st, Pack& px, const Pack& p1, const Pack& p2, int64_t n, int S1, int S2) {
+    if (h->fuse_attn != 2 || (h->nsplit != 2 && h->nsplit != 3) || h->f8 || !h->qa_sub[2] || n * (S1 + S2) < 16384) return;
+    launch_qkv_cross_plan(p1.off, p1.cnt, p1.rows, p2.off, p2.cnt, (int)n, S1, S2, h->qa_sub[2], h->qa_sub[3], h->qa_nsub + 2, h->nsplit, st, h->qa_rec[2]);
+    px.sub = h->qa_sub[2]; px.sub2 = h->qa_sub[3]; px.n_sub = h->qa_nsub + 2; px.rec = h->qa_rec[2];
+}
+
+// one fused QKV + attention launch, timed apart from the GEMM launches (its duration includes the attention of its pairs)
+int fused_attn_launch(mms_handle* h, hipStream_t st, QkvAttnParams& q) {
+    if (h->alternate) { q.reverse = h->flip; h->flip ^= 1; }
+    if (h->timing) {
+        if (h->ev_fused_used + 2 > h->ev_fused.size()) { if (int rc = grow_event_pair(h, h->ev_fused)) return rc; }
+        q.flop_counter = h->flop_counter + 1;
+        HIP_TRY(h, hipEventRecord(h->ev_fused[h->ev_fused_used], st));
+        if (!launch_qkv_attn(q, st)) return h->fail(MMS_ERR_ARG, "qkv_attn: shape not supported");
+        HIP_TRY(h, hipEventRecord(h->ev_fused[h->ev_fused_used + 1], st));
+        h->ev_fused_used += 2;
+        h->fused_timed += 1;
+    } else if (!launch_qkv_attn(q, st)) return h->fail(MMS_ERR_ARG, "qkv_attn: shape not supported");
+    h->fused_attn_launches += 1;
+    return MMS_OK;
 }
 
 int attend(mms_handle* h, AttnParams& a, hipStream_t st) {
@@ -869,26 +918,16 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
     // one kernel for projection + attention (qkv_attn.hip) when the launch is big enough for a persistent grid and runs two-pass bf16
     // (streams of very short pairs -- lxmert's 10 box tokens -- stay on the two-kernel route: a dozen attention items per sub-tile make the
     // fused epilogue cost more than the attention launch it replaces, profiles/r03q_*)
-    const bool fused_attn = pk.sub && w.wqkv_hm && !f8 && M >= 16384 && S >= 16 && ((h->nsplit == 2 && !(h->x1_mask & 1)) || h->nsplit == 3);
+    const bool fused_attn = pk.sub && w.wqkv_hm && !f8 && M >= 16384 && (S >= 16 || h->fuse_attn == 2) && ((h->nsplit == 2 && !(h->x1_mask & 1)) || h->nsplit == 3);
     if (fused_attn) {
         QkvAttnParams q{};
         const Planes a_in = in.at(row0 * H), c_out = h->ctx.at(row0 * H);
         q.a_hi = a_in.hi; q.lda = H; q.w = w.wqkv_hm; q.bias = w.bqkv_hm; q.K = H;
         if (h->nsplit == 3) q.w_lo = w.wqkv_hm + (long long)3 * H * H;       // upload_mat keeps the lo plane right behind the hi plane
-        q.sub = pk.sub; q.n_sub = pk.n_sub; q.pair_off = pk.off; q.pair_cnt = pk.cnt; q.S = S;
+        q.sub = pk.sub; q.n_sub = pk.n_sub; q.pair_rec = pk.rec; q.pair_off = pk.off; q.pair_cnt = pk.cnt; q.S = S;
         q.key_add = key_add; q.o_hi = c_out.hi; q.o_lo = c_out.lo; q.ldo = H;
         q.M = (int)M; q.m_dev = pk.rows; q.fast = h->fuse_attn == 2;
-        if (h->alternate) { q.reverse = h->flip; h->flip ^= 1; }
-        if (h->timing) {      // timed apart from the GEMM launches: this launch's duration includes the attention of its pairs
-            if (h->ev_fused_used + 2 > h->ev_fused.size()) { if (int rc = grow_event_pair(h, h->ev_fused)) return rc; }
-            q.flop_counter = h->flop_counter + 1;
-            HIP_TRY(h, hipEventRecord(h->ev_fused[h->ev_fused_used], st));
-            if (!launch_qkv_attn(q, st)) return h->fail(MMS_ERR_ARG, "qkv_attn: shape not supported");
-            HIP_TRY(h, hipEventRecord(h->ev_fused[h->ev_fused_used + 1], st));
-            h->ev_fused_used += 2;
-            h->fused_timed += 1;
-        } else if (!launch_qkv_attn(q, st)) return h->fail(MMS_ERR_ARG, "qkv_attn: shape not supported");
-        h->fused_attn_launches += 1;
+        if (int rc = fused_attn_launch(h, st, q)) return rc;
     } else {
     if (f8) {
         if (int rc = gemm_f8(h, st, in.f8 + row0 * H, H, w.wqkv8, w.wqkvs, w.bqkv, M, 3 * H, H, ACT_NONE, to_qkv(h, row0, M), pk.rows)) return rc;
@@ -1346,6 +1385,8 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
     }
     plan_tiles(h, st, pl, n, T, 0);
     plan_tiles(h, st, pv, n, V, 1);
+    Pack px;
+    if (c.x_layers > 1 || (c.x_layers > 0 && c.stop_after >= 0)) plan_cross_tiles(h, st, px, pl, pv, n, T, V);      // (the last X layer of a full run is trimmed to what the pooler reads: two-kernel route)
     if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, R * H, st);
     int budget = c.stop_after >= 0 ? c.stop_after : (1 << 30);
     for (int i = 0; i < c.layers && budget > 0 && !h->lq_active; ++i, --budget) {
@@ -1380,6 +1421,20 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
         }
         // cross attention, both directions with the SAME weights (modeling.py:460-464): the QKV projection and
         // the output dense + LN run over both streams (one launch when dense, one per stream when packed)
+        const bool cross_fused = px.sub && w.cross.wqkv_hm && !(h->x1_mask & 1);
+        if (cross_fused) {
+            // ONE launch: [Q | K | V] of both streams' rows with the shared weights, per head, K / V staged in LDS, both directions attended from there
+            // (qkv_attn.hip CROSS mode) -- the fp32 [rows][2304] tensor and the two attention launches are gone
+            QkvAttnParams q{};
+            q.a_hi = h->x.hi; q.lda = H; q.w = w.cross.wqkv_hm; q.bias = w.cross.bqkv_hm; q.K = H;
+            if (h->nsplit == 3) q.w_lo = w.cross.wqkv_hm + (long long)3 * H * H;
+            q.sub = px.sub; q.sub2 = px.sub2; q.n_sub = px.n_sub; q.pair_rec = px.rec;
+            q.pair_off = pl.off; q.pair_cnt = pl.cnt; q.S = T; q.pair_off2 = pv.off; q.pair_cnt2 = pv.cnt; q.S2 = V;
+            q.key_add = lang_add; q.key_add2 = visn_add; q.row0_b = ML;
+            q.o_hi = h->ctx.hi; q.o_lo = h->ctx.lo; q.ldo = H;
+            q.M = (int)ML; q.m_dev = pl.rows; q.M2 = (int)MV; q.m_dev2 = pv.rows; q.fast = 1;
+            if (int rc = fused_attn_launch(h, st, q)) return rc;
+        } else {
         if (c.pack_tokens) {
             if (int rc = gemm(h, st, h->x, H, ID, w.cross.wqkv, w.cross.bqkv, ML, 3 * H, H, ACT_NONE, to_qkv(h, 0, ML), nullptr, pl.rows)) return rc;
             if (int rc = gemm(h, st, h->x.at(ML * H), H, ID, w.cross.wqkv, w.cross.bqkv, MV, 3 * H, H, ACT_NONE,
@@ -1401,6 +1456,7 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
         a.o_hi = h->ctx.at(ML * H).hi; a.o_lo = h->ctx.at(ML * H).lo;
         a.q_off = pv.off; a.q_cnt = pv.cnt; a.kv_off = pl.off; a.kv_cnt = pl.cnt;
         if (int rc = attend(h, a, st)) return rc;
+        }
         if (c.pack_tokens) {
             // per stream: the fused bias + residual + LayerNorm epilogue on big launches (mms_config.fuse_layernorm bit 0), else GEMM -> LayerNorm kernel
             const Planes rv = h->x.at(ML * H);
@@ -1511,6 +1567,7 @@ void mms_destroy(mms_handle* h) {
     free_pool(h->lq_allocs);
     free_pool(h->lq_sub_allocs);
     if (h->lq_store.hi) (void)hipFree(h->lq_store.hi);
+    if (h->kparts) (void)hipFree(h->kparts);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     for (auto e : h->ev_fused) (void)hipEventDestroy(e);
     delete h;
@@ -1888,11 +1945,12 @@ int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const fl
     } else {
         p.out_kind = OUT_F32; p.c_f32 = c_f32; p.ldc = (int)N;
     }
-    launch_gemm(p, nsplit, st);
-    if (out_planes) launch_planes_to_f32(cp, cp + MMS_PLANE_LO, c_f32, M * N, st);
+    const bool taken = launch_gemm(p, nsplit, st);
+    if (taken && out_planes) launch_planes_to_f32(cp, cp + MMS_PLANE_LO, c_f32, M * N, st);
     DBG_TRY(hipStreamSynchronize(st));
     DBG_TRY(hipGetLastError());
     (void)hipFree(ap); (void)hipFree(wp); (void)hipFree(rp); (void)hipFree(cp); (void)wtmp;
+    if (!taken) { g_err = "mms_dbg_gemm: no engine takes this shape / variant"; return MMS_ERR_ARG; }
     return MMS_OK;
 }
 

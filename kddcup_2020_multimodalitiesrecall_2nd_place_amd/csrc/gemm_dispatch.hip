@@ -27,24 +27,28 @@ int device_cu_count() {
     return v;
 }
 
-void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
-    if (p.M <= 0 || p.N <= 0) return;
+// false: no engine took the launch (nothing was enqueued) -- the caller turns that into MMS_ERR_ARG instead of letting the next kernel read an unwritten buffer
+bool launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0) return true;
     int variant = p.variant ? p.variant : 99;
 #ifdef MMS_LAB
     if (!p.variant) { static const int env_variant = getenv("MMS_GEMM_VARIANT") ? atoi(getenv("MMS_GEMM_VARIANT")) : 99; variant = env_variant; }
 #endif
     if (nsplit == 3) {   // three passes: 256x128 ping-pong phases for large M (variant 27 forces it), 128x128 tile otherwise; a handful of rows: skinny kernel (api.hip names it)
-        if (variant == 5 && launch_gemm_skinny(p, 3, st)) return;
-        if (variant == 55 && launch_gemm_skinny_parts(p, 3, st)) return;
-        if (variant == 54 || variant == 58) { GemmParams q = p; q.k_splits = variant - 50; if (launch_gemm_skinny(q, 3, st)) return; }
-        if ((variant == 27 || (variant == 99 && p.M >= 16384)) && launch_gemm_ppw(p, st)) return;
-        launch_gemm_tile(p, 3, 1, st);
-        return;
+        if (variant == 5) {      // (k_splits is the skinny kernel's wave-level K slicing there: the tile engines below must not read it as their split-K contract)
+            if (launch_gemm_skinny(p, 3, st)) return true;
+            GemmParams q = p; q.k_splits = 0;
+            return launch_gemm_tile(q, 3, 1, st);
+        }
+        if (variant == 55 && launch_gemm_skinny_parts(p, 3, st)) return true;
+        if (variant == 54 || variant == 58) { GemmParams q = p; q.k_splits = variant - 50; if (launch_gemm_skinny(q, 3, st)) return true; }
+        if ((variant == 27 || (variant == 99 && p.M >= 16384)) && launch_gemm_ppw(p, st)) return true;
+        return launch_gemm_tile(p, 3, 1, st);
     }
 #ifdef MMS_LAB
     if (variant > 100) {   // timing diagnostics (201-232 ping-pong): WRONG results on purpose, only with MMS_GEMM_DIAG
         static const bool diag_ok = getenv("MMS_GEMM_DIAG") != nullptr;
-        if (diag_ok && variant > 200 && (variant < 233 || variant == 264) && launch_gemm_pp(p, nsplit, variant - 200, st)) return;
+        if (diag_ok && variant > 200 && (variant < 233 || variant == 264) && launch_gemm_pp(p, nsplit, variant - 200, st)) return true;
         variant = 99;
     }
 #endif
@@ -67,17 +71,24 @@ void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         }
     }
 #ifdef MMS_LAB
-    if (variant == 28) { if (launch_gemm_dw(p, nsplit, st)) return; variant = 26; }
+    if (variant == 28) { if (launch_gemm_dw(p, nsplit, st)) return true; variant = 26; }
 #endif
-    if (variant == 5) { if (launch_gemm_skinny(p, nsplit, st)) return; variant = 4; }      // a handful of rows (api.hip names it with its K-slice count in k_splits; never the per-shape default here)
-    if (variant == 55) { if (launch_gemm_skinny_parts(p, nsplit, st)) return; variant = 4; }      // split-K partials from the skinny kernel (api.hip proj_ln); the tile engine honours the same k_splits contract
+    if (variant == 5) {      // a handful of rows (api.hip names it with its K-slice count in k_splits; never the per-shape default here)
+        if (launch_gemm_skinny(p, nsplit, st)) return true;
+        // not taken: k_splits was the skinny kernel's wave-level K slicing (bias and activation still in the epilogue) -- the tile engine's k_splits means
+        // "fp32 partials, no epilogue", so it must not see it
+        GemmParams q = p; q.k_splits = 0;
+        if (launch_gemm_tile(q, nsplit, 4, st)) return true;
+        return launch_gemm_tile(q, nsplit, 1, st);
+    }
+    if (variant == 55) { if (launch_gemm_skinny_parts(p, nsplit, st)) return true; variant = 4; }      // split-K partials from the skinny kernel (api.hip proj_ln); the tile engine honours the same k_splits contract
     if (variant == 54 || variant == 58) {      // kernel tests: the skinny kernel with 4 / 8 K slices
         GemmParams q = p; q.k_splits = variant - 50;
-        if (launch_gemm_skinny(q, nsplit, st)) return;
+        if (launch_gemm_skinny(q, nsplit, st)) return true;
         variant = 4;
     }
-    if (variant == 26) { if (launch_gemm_pp(p, nsplit, 0, st, true)) return; variant = 4; }
-    if (variant == 20) { if (launch_gemm_pp(p, nsplit, 0, st)) return; variant = 4; }
-    if (launch_gemm_tile(p, nsplit, variant, st)) return;
-    launch_gemm_tile(p, nsplit, 1, st);   // N % 256 != 0: 128x128 tile
+    if (variant == 26) { if (launch_gemm_pp(p, nsplit, 0, st, true)) return true; variant = 4; }
+    if (variant == 20) { if (launch_gemm_pp(p, nsplit, 0, st)) return true; variant = 4; }
+    if (launch_gemm_tile(p, nsplit, variant, st)) return true;
+    return launch_gemm_tile(p, nsplit, 1, st);   // N % 256 != 0: 128x128 tile
 }

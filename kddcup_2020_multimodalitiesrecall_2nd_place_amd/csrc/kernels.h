@@ -57,7 +57,7 @@ struct GemmParams {
 };
 // CUs of the CURRENT device rounded down to a multiple of 8 (one per XCD-slot), cached per device ordinal; thread-safe (gemm_dispatch.hip)
 int device_cu_count();
-void launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);
+bool launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);      // false: no engine took the shape, nothing was launched
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
 bool launch_gemm_skinny_parts(const GemmParams& p, int nsplit, hipStream_t st);        // ... with the K slices dealt to workgroups: k_splits fp32 partials, c_split_stride apart (variant 55; the LayerNorm kernel sums them)
 bool launch_gemm_skinny(const GemmParams& p, int nsplit, hipStream_t st);              // gemm_skinny.hip: a handful of rows (api.hip: <= 128), precision modes 2 and 3, one workgroup per 16 output columns, K split over its waves (variant 5); false: not taken
@@ -111,11 +111,24 @@ struct QkvAttnParams {
     int M; const int* m_dev;                 // rows of the stream (upper bound / device-side live count): grid size, FLOP count
     int reverse;
     int fast;                                // 1: attention on split-bf16 MFMAs (three products per operand pair) instead of exact-fp32 MFMAs
+    // CROSS mode (fast only; lxmert X layers, lxrt/modeling.py:460-464: ONE attention module, both directions): a sub-tile holds the rows of its
+    // pairs in BOTH streams -- sub[u] = {first row, rows, first pair, pairs} of stream 1, sub2[u] = {first row, rows, -, -} of stream 2 (rows
+    // relative to their stream); stream 2 starts at row row0_b of the plane buffers (a_hi, o_hi).  Queries of one stream attend the keys of
+    // the OTHER stream of their pair.  sub2 == nullptr: self-attention of one stream.
+    const int4* sub2;
+    const int* pair_rec;                     // fast: per pair, its rows inside its sub-tile (launch_qkv_tile_plan / launch_qkv_cross_plan write it next to the table)
+    const int* pair_off2; const int* pair_cnt2; int S2;     // stream 2: first row / live tokens per pair (nullptr: dense, S2 tokens per pair)
+    const float* key_add2;                   // additive key mask of stream 2 by stream row, or nullptr
+    long long row0_b;
+    int M2; const int* m_dev2;               // rows of stream 2 (upper bound / device-side live count)
     unsigned long long* flop_counter;
     unsigned long long* trace;               // lab builds: per-tile timeline (qkv_attn.hip), nullptr otherwise
     int lab_flags;                           // lab builds: timing-only knock-outs
 };
-void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, int passes, hipStream_t st);   // rows_dev: device-side row total of a packed stream (or nullptr)
+void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, int passes, hipStream_t st, int* pair_rec = nullptr);   // rows_dev: device-side row total of a packed stream (or nullptr); pair_rec: int[n] (QkvAttnParams::pair_rec)
+// ... of a PAIR of streams (cross mode): a pair brings cnt[b] + cnt2[b] rows, sub / sub2 as QkvAttnParams describes them
+void launch_qkv_cross_plan(const int* off, const int* cnt, const int* rows_dev, const int* off2, const int* cnt2, int n, int S, int S2,
+                           int4* sub, int4* sub2, int* n_sub, int passes, hipStream_t st, int* pair_rec);
 bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st);   // false: shape not supported (S > 48, K % 64)
 
 // ---------------------------------------------------------------------------------------------

@@ -54,6 +54,30 @@ __device__ __forceinline__ void qa_barrier() {
 constexpr int QA_SUB = 128;          // rows of a sub-tile: two-pass kernel (96 in the three-pass one: QA_SUB3)
 constexpr int QA_SUB3 = 96;
 constexpr int QA_LDROW = 196;        // floats per staged row: 192 + 4 (784 B = 16 B mod 256 B)
+// FAST staging: a row is [Q_hi 64 | Q_lo 64 | K_hi 64 | K_lo 64 | V_hi 64 | V_lo 64] bf16 (split once, in the dump; Q pre-scaled by 1/8) + 16 B = the same 784 bytes
+constexpr int QA_LDB = QA_LDROW * 4;
+typedef short qa_s16x4 __attribute__((ext_vector_type(4)));
+typedef short qa_s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// min / max over the 16 lanes of a DPP row (every lane gets the result): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ int qa_row16_min(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    return min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int qa_row16_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    return max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+}
+// [4 keys][16 columns] bf16 block -> lane c of the 16-lane group gets column c (ds_read_b64_tr_b16: element j of lane c comes from the address of lane
+// 4 j + c / 4 of the group, sub-element c % 4 -- tools/probes/tr16_probe.hip); every lane passes the address of ITS quad: row c / 4, columns 4 (c % 4) ..
+__device__ __forceinline__ qa_s16x4 qa_tr16(const unsigned char* lds_quad) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) qa_s16x4*)(lds_quad));
+}
 
 }  // namespace
 
@@ -62,20 +86,25 @@ constexpr int QA_LDROW = 196;        // floats per staged row: 192 + 4 (784 B = 
 // The stream is cut into SEGMENTS of about QA_SEG rows at pair boundaries (binary search in the row offsets); one thread packs the pairs
 // of its segment greedily in pair order (first pass: count; block scan; second pass: write).  Only a segment's last sub-tile is left
 // underfull by the cut: ~0.5 sub-tiles of 64.  (A single greedy chain over all pairs is 30 000 dependent steps: 2 ms per plan.)
+// CROSS plans (sub2 != nullptr; lxmert X layers): a pair brings the rows of BOTH its streams (cnt[b] + cnt2[b]) into the sub-tile;
+// sub2[u] = {first row of stream 2, its rows, 0, 0}.  The segments are cut by the rows of stream 1.
 constexpr int QA_PLAN_THREADS = 1024;
 constexpr int QA_SEG = 8192;
 
 __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __restrict__ off, const int* __restrict__ cnt, int n, int S,
-                                                                   const int* __restrict__ rows_dev, int4* __restrict__ sub, int* __restrict__ n_sub, int sub_rows) {
+                                                                   const int* __restrict__ rows_dev, int4* __restrict__ sub, int* __restrict__ n_sub, int sub_rows,
+                                                                   const int* __restrict__ off2, const int* __restrict__ cnt2, int S2, int4* __restrict__ sub2,
+                                                                   int* __restrict__ pair_rec) {
     __shared__ int sh[QA_PLAN_THREADS];
     // the per-pair token counts (<= 48) as bytes in LDS: each thread then walks its ~500 pairs twice without a global access in the loop
     // (530 us -> ~60 us per plan); streams of more pairs than fit read them from memory
-    constexpr int QA_PLAN_CACHE = 96 * 1024;
-    __shared__ unsigned char cnt8[QA_PLAN_CACHE];
+    constexpr int QA_PLAN_CACHE = 72 * 1024;
+    __shared__ unsigned char cnt8[QA_PLAN_CACHE], cnt8b[QA_PLAN_CACHE];
     const int tid = threadIdx.x;
-    const bool cached = cnt && n <= QA_PLAN_CACHE;
+    const bool cross = sub2 != nullptr;
+    const bool cached = cnt && n <= QA_PLAN_CACHE && (!cross || cnt2);
     if (cached) {
-        for (int b = tid; b < n; b += QA_PLAN_THREADS) cnt8[b] = (unsigned char)cnt[b];
+        for (int b = tid; b < n; b += QA_PLAN_THREADS) { cnt8[b] = (unsigned char)cnt[b]; if (cross) cnt8b[b] = (unsigned char)cnt2[b]; }
         __syncthreads();
     }
     const long long total = off ? (rows_dev ? (long long)*rows_dev : (long long)off[n - 1] + cnt[n - 1]) : (long long)n * S;
@@ -91,23 +120,28 @@ __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __
     int p0 = n, p1 = n;
     if (tid < nseg) { p0 = first_pair((long long)tid * seg); p1 = tid + 1 < nseg ? first_pair((long long)(tid + 1) * seg) : n; }
     auto pack = [&](int out) {       // out < 0: count only
-        int rows = 0, row0 = 0, pair0 = p0, ns = 0;
+        int rows = 0, rows2 = 0, row0 = 0, row02 = 0, pair0 = p0, ns = 0;
         // first row of pair b: the offsets are the running sum of the counts, so one load per thread replaces a dependent global load
         // at every sub-tile start (those loads, not the walk, were most of the plan's 360 us)
         int cursor = p0 < p1 ? (off ? off[p0] : p0 * S) : 0;
+        int cursor2 = (cross && p0 < p1) ? (off2 ? off2[p0] : p0 * S2) : 0;
         for (int b = p0; b < p1; ++b) {
             const int c = cached ? (int)cnt8[b] : cnt ? cnt[b] : S;
-            if (rows + c > sub_rows || (rows > 0 && b - pair0 >= QA_SUB3)) {      // (the kernel keeps at most 128 pair records per sub-tile)
-                if (out >= 0) sub[out + ns] = make_int4(row0, rows, pair0, b - pair0);
+            const int c2 = !cross ? 0 : cached ? (int)cnt8b[b] : cnt2 ? cnt2[b] : S2;
+            if (rows + rows2 + c + c2 > sub_rows || (rows + rows2 > 0 && b - pair0 >= QA_SUB3)) {      // (the kernel keeps at most 128 pair records per sub-tile)
+                if (out >= 0) { sub[out + ns] = make_int4(row0, rows, pair0, b - pair0); if (cross) sub2[out + ns] = make_int4(row02, rows2, 0, 0); }
                 ++ns;
-                rows = 0;
+                rows = rows2 = 0;
             }
-            if (rows == 0) { row0 = cursor; pair0 = b; }
-            rows += c;
-            cursor += c;
+            if (rows + rows2 == 0) { row0 = cursor; row02 = cursor2; pair0 = b; }
+            // the pair's place inside its sub-tile, as the fused kernel's split-bf16 attention wants it (one dword, no arithmetic in front of the kernel's main
+            // loop): first row | rows << 8 in stream 1, first row << 16 | rows << 24 in stream 2 (rows relative to the sub-tile's part of the stream)
+            if (out >= 0 && pair_rec) pair_rec[b] = (cursor - row0) | (c << 8) | ((cursor2 - row02) << 16) | (c2 << 24);
+            rows += c; rows2 += c2;
+            cursor += c; cursor2 += c2;
         }
-        if (rows > 0) {
-            if (out >= 0) sub[out + ns] = make_int4(row0, rows, pair0, p1 - pair0);
+        if (rows + rows2 > 0) {
+            if (out >= 0) { sub[out + ns] = make_int4(row0, rows, pair0, p1 - pair0); if (cross) sub2[out + ns] = make_int4(row02, rows2, 0, 0); }
             ++ns;
         }
         return ns;
@@ -124,8 +158,14 @@ __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __
     if (mine > 0) pack(sh[tid] - mine);
     if (tid == QA_PLAN_THREADS - 1) *n_sub = sh[tid];
 }
-void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, int passes, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(k_qkv_tile_plan, dim3(1), dim3(QA_PLAN_THREADS), 0, st, off, cnt, n, S, rows_dev, sub, n_sub, passes == 3 ? QA_SUB3 : QA_SUB);
+void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, int passes, hipStream_t st, int* pair_rec) {
+    if (n > 0) hipLaunchKernelGGL(k_qkv_tile_plan, dim3(1), dim3(QA_PLAN_THREADS), 0, st, off, cnt, n, S, rows_dev, sub, n_sub, passes == 3 ? QA_SUB3 : QA_SUB,
+                                  (const int*)nullptr, (const int*)nullptr, 0, (int4*)nullptr, pair_rec);
+}
+void launch_qkv_cross_plan(const int* off, const int* cnt, const int* rows_dev, const int* off2, const int* cnt2, int n, int S, int S2,
+                           int4* sub, int4* sub2, int* n_sub, int passes, hipStream_t st, int* pair_rec) {
+    if (n > 0) hipLaunchKernelGGL(k_qkv_tile_plan, dim3(1), dim3(QA_PLAN_THREADS), 0, st, off, cnt, n, S, rows_dev, sub, n_sub, passes == 3 ? QA_SUB3 : QA_SUB,
+                                  off2, cnt2, S2, sub2, pair_rec);
 }
 
 // MAXT: 16-token tiles per side of the attention (2: pairs of <= 32 tokens, 3: <= 48)
@@ -145,9 +185,10 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     // per-tile metadata of the epilogue, fetched with the tile's addresses (setup) and parked here after the main loop: a dependent
     // global load inside the attention phase costs a full memory latency with only eight waves on the CU (the phase took 16 k cycles per
     // sub-tile with the pair offsets / key mask / bias read from memory where they are used: profiles/r03n_qa_trace.txt)
-    __shared__ __attribute__((aligned(16))) float m_keyadd[256];     // additive key mask by tile row (BM <= 256)
+    __shared__ __attribute__((aligned(16))) float m_keyadd[256 + 64];     // additive key mask by tile row (BM <= 256; + 64: a 32-key chunk may run past the sub-tile)
     __shared__ __attribute__((aligned(16))) float m_bias[192];       // this head's [Q | K | V] bias
-    __shared__ int2 m_pair[256 + 64];                                // [sub-tile][pair]: first stream row, live tokens (+ 64: whole-wave reads)
+    __shared__ int2 m_pair[FAST ? 1 : 256 + 64];                     // exact route: [sub-tile][pair]: first stream row, live tokens (+ 64: whole-wave reads)
+    __shared__ int m_rowmeta[FAST ? 256 : 1];                        // FAST route: per tile row, the sub-tile rows [kbeg, kend) its query attends (kbeg | kend << 16)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,21 +198,27 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     if (p.flop_counter && blockIdx.x == 0 && tid == 0) {
         int Meff = p.M;
         if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
+        if (FAST && p.sub2) { int m2 = p.M2; if (p.m_dev2) { const int md = *p.m_dev2; m2 = md < m2 ? md : m2; } Meff += m2; }
         atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)(3 * MMS_HIDDEN) * (unsigned long long)p.K);
     }
     int vb = blockIdx.x;
     if (vb >= nblk) return;
+    if (tid < 64) m_keyadd[256 + tid] = 0.f;      // (read by chunks that run past a sub-tile's rows; those keys are masked by their range)
 
     const int gr_l = lane >> 2, gc = lane & 3;
     const bf16* a_src[NAP];
     const bf16* w_src[WPL][2];
     int head;
     int4 sub0, sub1;
+    int2 sub0b = make_int2(0, 0), sub1b = sub0b;     // CROSS: {first row, rows} of the sub-tiles' stream-2 part
     int meta_a = 0, meta_b = 0;          // thread < 256: key mask of tile row tid, bias[tid]; else pair (tid - 256): first row, tokens
+                                         // FAST, pair threads: meta_a = the plan's pair record (rows of the pair inside its sub-tile)
+    const bool cross = FAST && p.sub2 != nullptr;
     // where virtual block v works: head and the two sub-tile records (uniform: scalar loads).  Done one tile ahead (top of the main loop), so
     // that the address set-up behind the loop has no dependent memory access in front of it
     int nhead = 0;
     int4 nsub0 = make_int4(0, 0, 0, 0), nsub1 = nsub0;
+    int2 nsub0b = make_int2(0, 0), nsub1b = nsub0b;
     auto locate = [&](int v) {
         // bijective XCD remap (virtual block v runs on XCD v % 8): the twelve heads of a row tile stay on one XCD's L2
         const int q = nblk >> 3, r8 = nblk & 7, xcd = v & 7, loc = v >> 3;
@@ -186,28 +233,45 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
         nhead = __builtin_amdgcn_readfirstlane(nhead);
         nsub0 = uni(p.sub[2 * nb]);
         nsub1 = 2 * nb + 1 < n_sub ? uni(p.sub[2 * nb + 1]) : make_int4(nsub0.x, 0, 0, 0);
+        if (cross) {
+            const int4 a = uni(p.sub2[2 * nb]), b = 2 * nb + 1 < n_sub ? uni(p.sub2[2 * nb + 1]) : make_int4(a.x, 0, 0, 0);
+            nsub0b = make_int2(a.x, a.y); nsub1b = make_int2(b.x, b.y);
+        }
+    };
+    // row of the plane buffers (a_hi / o_hi) behind row lr of a sub-tile: its stream-1 rows first, then (CROSS) its stream-2 rows
+    auto grow = [&](const int4& sa, const int2& sb2, int lr) -> long long {
+        return lr < sa.y ? (long long)(sa.x + lr) : p.row0_b + (long long)(sb2.x + (lr - sa.y));
     };
     auto setup = [&]() {
-        head = nhead; sub0 = nsub0; sub1 = nsub1;
+        head = nhead; sub0 = nsub0; sub1 = nsub1; sub0b = nsub0b; sub1b = nsub1b;
 #pragma unroll
         for (int q4 = 0; q4 < NAP; ++q4) {
             const int r = q4 * 64 + wave * 8 + (lane >> 3);          // tile row: sub-tile r / SUB, its row r % SUB (clamped to the last live one)
             const int4 sb = (r / SUB) ? sub1 : sub0;
+            const int2 sb2 = make_int2((r / SUB) ? sub1b.x : sub0b.x, (r / SUB) ? sub1b.y : sub0b.y);     // (component selects: a struct select goes through scratch)
+            const int nlive = sb.y + sb2.y;
             int lr = r % SUB;
-            lr = lr < sb.y ? lr : (sb.y > 0 ? sb.y - 1 : 0);
-            a_src[q4] = p.a_hi + 2 * ((long long)(sb.x + lr) * (long long)p.lda) + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+            lr = lr < nlive ? lr : (nlive > 0 ? nlive - 1 : 0);
+            const long long gr = nlive > 0 ? grow(sb, sb2, lr) : (long long)sb.x;
+            a_src[q4] = p.a_hi + 2 * (gr * (long long)p.lda) + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
         }
         {
             const int t = tid & 255;
             const int u = tid < 256 ? (t >= SUB) : (t >> 7), i = tid < 256 ? t - u * SUB : (t & 127);   // key-mask rows by tile row, pair records [sub-tile][128]
             const int4 sb = u ? sub1 : sub0;
+            const int2 sb2 = make_int2(u ? sub1b.x : sub0b.x, u ? sub1b.y : sub0b.y);
             if (tid < 256) {
-                meta_a = (p.key_add && t < BM && i < sb.y) ? __float_as_int(p.key_add[sb.x + i]) : 0;
+                meta_a = 0;
+                if (t < BM && i < sb.y) { if (p.key_add) meta_a = __float_as_int(p.key_add[sb.x + i]); }
+                else if (t < BM && i < sb.y + sb2.y) { if (p.key_add2) meta_a = __float_as_int(p.key_add2[sb2.x + (i - sb.y)]); }
                 meta_b = tid < BN ? __float_as_int(p.bias[head * BN + tid]) : 0;
             } else if (i < sb.w) {
                 const int b = sb.z + i;
-                meta_a = p.pair_off ? p.pair_off[b] : b * p.S;
-                meta_b = p.pair_cnt ? p.pair_cnt[b] : p.S;
+                if constexpr (FAST) meta_a = p.pair_rec[b];      // launch_qkv_tile_plan's record: no arithmetic on a fresh load here (setup runs while the other waves wait at a barrier)
+                else {
+                    meta_a = p.pair_off ? p.pair_off[b] : b * p.S;
+                    meta_b = p.pair_cnt ? p.pair_cnt[b] : p.S;
+                }
             }
         }
 #pragma unroll
@@ -299,11 +363,13 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
 #ifdef MMS_LAB
     // lab: per-tile timeline of thread 0 (shader-clock stamps: loop start, loop end, dump 0, attention 0, dump 1, attention 1, next
     // prologue done), first 8 tiles of every workgroup -> p.trace[(blockIdx.x * 8 + tile) * 8 + k]   (tools/qa_trace.py)
-    unsigned long long tr[7];
+    unsigned long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // [8..]: wave 0's own progress inside dump 0 (8: body done, 9: stores landed) and attention 1 (10: range + Q fragments, 11: first step, 12: all steps, 13: stores issued)
+#define QA_SUB_STAMP(k) do { if (p.trace) tr[k] = __builtin_readcyclecounter(); } while (0)
     int tile_i = 0;
 #define QA_STAMP(k) do { if (p.trace) tr[k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define QA_STAMP(k) do { } while (0)
+#define QA_SUB_STAMP(k) do { } while (0)
 #endif
     for (;;) {
 #pragma unroll
@@ -323,10 +389,30 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
         ++s;
         // park this tile's metadata in LDS; every wave passes a barrier between its own writes and the first read (waves 4-7: the last
         // stage's; waves 0-3: the re-aligning one)
-        if (wave >= NW / 2) m_pair[tid - 256] = make_int2(meta_a, meta_b);
+        if (wave >= NW / 2) {
+            if constexpr (FAST) {
+                // the pair's rows learn which sub-tile rows their queries attend: self-attention -> the pair's own rows; CROSS -> its rows in the other stream
+                const int t = tid - 256, u = t >> 7;
+                const int4 sa = u ? sub1 : sub0;
+                if ((t & 127) < sa.w) {
+                    const int r1 = meta_a & 255, c1 = (meta_a >> 8) & 255;
+                    if (cross) {
+                        const int r2 = sa.y + ((meta_a >> 16) & 255), c2 = (meta_a >> 24) & 255;
+                        for (int r = 0; r < c1; ++r) m_rowmeta[u * SUB + r1 + r] = r2 | ((r2 + c2) << 16);
+                        for (int r = 0; r < c2; ++r) m_rowmeta[u * SUB + r2 + r] = r1 | ((r1 + c1) << 16);
+                    } else {
+                        for (int r = 0; r < c1; ++r) m_rowmeta[u * SUB + r1 + r] = r1 | ((r1 + c1) << 16);
+                    }
+                }
+            } else m_pair[tid - 256] = make_int2(meta_a, meta_b);
+        }
         stage(std::false_type{}, std::integral_constant<int, -1>{}, s, slot);        // stage ns-1
         if (wave < NW / 2) {
             m_keyadd[tid] = __int_as_float(meta_a);
+            if constexpr (FAST) {      // rows behind the last pair of a sub-tile attend nothing
+                const int u = tid >= SUB, i = tid - u * SUB;
+                if (tid < BM && i >= (u ? sub1.y + sub1b.y : sub0.y + sub0b.y)) m_rowmeta[tid] = 0;
+            }
             if (tid < BN) m_bias[tid] = __int_as_float(meta_b);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             qa_barrier();     // re-align the halves: nobody reads the ring any more
@@ -336,12 +422,52 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
         // this tile's identity for the epilogue; then the next tile's addresses and its stage 0 (slot 0 is idle and below the staging area)
         const int ehead = head;
         const int4 esub0 = sub0, esub1 = sub1;
+        const int2 esub0b = sub0b, esub1b = sub1b;
         if (more) vb += (int)gridDim.x;
         // ---- epilogue: per sub-tile  accumulators -> LDS, attention of its pairs for this head ----
         const int mrow = lane & 15, nq = lane >> 4;
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             if ((wm >> 1) == half) {
+                if constexpr (FAST) {
+                    // split ONCE here: the attention reads MFMA operands (bf16x8) straight from LDS, a staged row = [Q_hi | Q_lo | K_hi | K_lo | V_hi | V_lo] (QA_LDB)
+                    // One 16-byte store per plane: v_permlane16_swap between the lane rows nq = (0, 1) and (2, 3) gives every lane EIGHT consecutive d of ONE of the two
+                    // column fragments j / j + 1 (lane rows 0, 2: fragment j, d 0..7 / 8..15; rows 1, 3: fragment j + 1).  8-byte stores (16 rows x 8 B per lane group:
+                    // two-way bank conflicts at this row stride) made the dump LDS-write-bound at 4.5 k cycles per sub-tile; the arithmetic did not matter.
+                    static_assert(FN % 2 == 0 && TN % 32 == 0, "column fragments are stored in pairs that share a Q / K / V section");
+                    unsigned char* rowp = reinterpret_cast<unsigned char*>(stg) + ((wm & 1) * TM + mrow) * QA_LDB + (nq & 1) * 32 + (nq >> 1) * 16;
+#pragma unroll
+                    for (int j = 0; j < FN; j += 2) {
+                        const int col = wn * TN + 16 * j;      // wave-uniform: section col / 64 (0 Q, 1 K, 2 V); the pair covers d = col % 64 + 0..31 of it
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(m_bias + col + nq * 4), b1 = *reinterpret_cast<const f32x4*>(m_bias + col + 16 + nq * 4);
+                        unsigned char* dst = rowp + (col >> 6) * 256 + (col & 63) * 2;
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+                            unsigned w[2][2][2];      // [plane][fragment of the pair][dword]
+#pragma unroll
+                            for (int t2 = 0; t2 < 2; ++t2) {
+                                f32x4 v = acc[i][j + t2];
+                                v += t2 ? b1 : b0;
+                                bf16x4 hi, lo;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { bf16 x, y; split_bf16(v[e], x, y); hi[e] = x; lo[e] = y; }
+                                if (QA_FLAGS & 64) { hi = __builtin_bit_cast(bf16x4, f32x2_t{v[0], v[1]}); lo = __builtin_bit_cast(bf16x4, f32x2_t{v[2], v[3]}); }      // lab: no split arithmetic
+                                const u32x2_t h2 = __builtin_bit_cast(u32x2_t, hi), l2 = __builtin_bit_cast(u32x2_t, lo);
+                                w[0][t2][0] = h2[0]; w[0][t2][1] = h2[1]; w[1][t2][0] = l2[0]; w[1][t2][1] = l2[1];
+                            }
+#pragma unroll
+                            for (int pl2 = 0; pl2 < 2; ++pl2) {
+                                u32x4 out;
+#pragma unroll
+                                for (int dw = 0; dw < 2; ++dw) {
+                                    const auto sw = __builtin_amdgcn_permlane16_swap(w[pl2][0][dw], w[pl2][1][dw], false, false);
+                                    out[dw] = sw[0]; out[2 + dw] = sw[1];
+                                }
+                                if (!(QA_FLAGS & 32)) *reinterpret_cast<u32x4*>(dst + 16 * i * QA_LDB + 128 * pl2) = out;      // (lab flag 32: no staging stores)
+                            }
+                        }
+                    }
+                } else {
                 const float* bias = m_bias + wn * TN + nq * 4;
                 float* dst = stg + ((wm & 1) * TM + mrow) * QA_LDROW + wn * TN + nq * 4;
 #pragma unroll
@@ -354,7 +480,10 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                         *reinterpret_cast<f32x4*>(dst + 16 * i * QA_LDROW + 16 * j) = v;
                     }
                 }
+                }
+                if (half == 0) QA_SUB_STAMP(8);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (half == 0) QA_SUB_STAMP(9);
             } else if (more) {
                 // the four waves that have nothing to write in this phase set up their next tile and send out its stage 0 (slot 0 lies below
                 // the staging area)
@@ -367,6 +496,151 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
             if (p.trace) tr[2 + 2 * half] = __builtin_readcyclecounter();
 #endif
             const int4 sb = half ? esub1 : esub0;
+            if constexpr (FAST) {
+            // ---- FAST: one 16-query tile of the sub-tile per wave, block-diagonal over the pairs it touches.  Query row i attends the sub-tile rows
+            // [kbeg_i, kend_i) (m_rowmeta: its pair's rows; CROSS: its pair's rows in the other stream); the wave walks the union of its 16 queries' ranges in
+            // chunks of 32 keys with an online softmax: S^T = K Q^T and O^T = V^T P^T on split-bf16 MFMAs (hi hi, hi lo, lo hi), K / Q fragments by ds_read_b128,
+            // V^T fragments by ds_read_b64_tr_b16 from the row-major staged V.  Every lane's scores, probabilities and outputs belong to ONE query (i = lane & 15):
+            // running maximum, sum and rescale are per-lane scalars. ----
+            const int2 sb2 = make_int2(half ? esub1b.x : esub0b.x, half ? esub1b.y : esub0b.y);
+            const int nlive = sb.y + sb2.y;
+            if (wave * 16 < nlive && wave * 16 < SUB && !(QA_FLAGS & 16)) {
+                const unsigned char* stgb = reinterpret_cast<const unsigned char*>(stg);
+                const int i = wave * 16 + fr;
+                const bool live = i < nlive;
+                const int ic = live ? i : nlive - 1;
+                const int rm = m_rowmeta[half * SUB + ic];
+                const int kbeg = rm & 0xffff, kend = (int)((unsigned)rm >> 16);
+                const int kb = __builtin_amdgcn_readfirstlane(qa_row16_min(live ? kbeg : 0x7fff)) & ~3;
+                const int ke = __builtin_amdgcn_readfirstlane(qa_row16_max(live ? kend : 0));
+                const unsigned char* qrow = stgb + ic * QA_LDB + 16 * fk;          // lane: d = 32 ds + 8 fk + 0..7
+                const bf16x8 qh0 = *reinterpret_cast<const bf16x8*>(qrow), qh1 = *reinterpret_cast<const bf16x8*>(qrow + 64);
+                const bf16x8 ql0 = *reinterpret_cast<const bf16x8*>(qrow + 128), ql1 = *reinterpret_cast<const bf16x8*>(qrow + 192);
+                const float* kadd = m_keyadd + half * SUB;
+                float m = -INFINITY, l = 0.f;
+                f32x4 o[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // one step = NH halves of 32 keys (compile-time: no branch inside, so the 2 NH score tiles' LDS reads and MFMA chains interleave -- with a
+                // wave-uniform branch per tile every tile was its own basic block and the phase ran at the latency of one dependent chain after the other)
+                auto step = [&](auto nh_tag, const int kc) {
+                    constexpr int NH = decltype(nh_tag)::value;
+                    // S^T tile t: first operand = K rows (key j = kc + 16 t + fr), second = the Q rows; lane gets keys kc + 16 t + 4 fk + r of query fr
+                    f32x4 sc[2 * NH];
+#pragma unroll
+                    for (int t = 0; t < 2 * NH; ++t) {
+                        f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+                        if (!(QA_FLAGS & 2)) {
+                            int j = kc + 16 * t + fr;
+                            j = j < SUB ? j : SUB - 1;
+                            const unsigned char* kr = stgb + j * QA_LDB + 256 + 16 * fk;
+                            const bf16x8 kh0 = *reinterpret_cast<const bf16x8*>(kr), kh1 = *reinterpret_cast<const bf16x8*>(kr + 64);
+                            const bf16x8 kl0 = *reinterpret_cast<const bf16x8*>(kr + 128), kl1 = *reinterpret_cast<const bf16x8*>(kr + 192);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, qh0, a4, 0, 0, 0);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, ql0, a4, 0, 0, 0);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl0, qh0, a4, 0, 0, 0);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, qh1, a4, 0, 0, 0);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, ql1, a4, 0, 0, 0);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl1, qh1, a4, 0, 0, 0);
+                        }
+                        sc[t] = a4;
+                        if (t & 1) __builtin_amdgcn_sched_barrier(0);      // two tiles' fragments (32 registers) in flight at a time: the other sub-tile's accumulators are still live
+                    }
+                    // 1 / sqrt(64) and the additive key mask; keys outside the query's own range do not exist for it
+                    const int j0 = kc + 4 * fk;
+                    float sv[8 * NH];
+                    float cm = -INFINITY;
+#pragma unroll
+                    for (int t = 0; t < 2 * NH; ++t) {
+                        const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + j0 + 16 * t);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int j = j0 + 16 * t + r;
+                            const float v = (j >= kbeg && j < kend) ? __builtin_fmaf(sc[t][r], 0.125f, ka[r]) : -INFINITY;
+                            sv[4 * t + r] = v;
+                            cm = fmaxf(cm, v);
+                        }
+                    }
+                    cm = rows4_max(cm);
+                    const float mn = fmaxf(m, cm);
+                    const float ms = mn == -INFINITY ? 0.f : mn;          // (no key of this query so far)
+                    const float alpha = __builtin_amdgcn_exp2f((m - ms) * 1.44269504088896340736f);
+                    float ps = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8 * NH; ++e) {
+                        sv[e] = __builtin_amdgcn_exp2f((sv[e] - ms) * 1.44269504088896340736f);
+                        ps += sv[e];
+                    }
+                    ps = rows4_sum(ps);
+                    l = l * alpha + ps;
+                    m = mn;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+                    // O^T += V^T P^T over each half's 32 key slots: slot (fk, e) = key kc + 32 h + 16 (e >> 2) + 4 fk + (e & 3) -- the lane's own probabilities are the
+                    // second operand; first operand = V^T[d = 16 dt + fr][slot]: two transposing reads of the [4 keys][16 d] blocks at keys + 4 fk and + 16 + 4 fk
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        if (QA_FLAGS & 1) continue;
+                        bf16x8 ph, pl;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { bf16 x, y; split_bf16(sv[8 * h + e], x, y); ph[e] = x; pl[e] = y; }
+                        int r0 = kc + 32 * h + 4 * fk + (fr >> 2), r1 = r0 + 16;
+                        r0 = r0 < SUB ? r0 : SUB - 1;      // (P is exactly 0 there)
+                        r1 = r1 < SUB ? r1 : SUB - 1;
+                        const unsigned char* v0 = stgb + r0 * QA_LDB + 512 + (fr & 3) * 8;
+                        const unsigned char* v1 = stgb + r1 * QA_LDB + 512 + (fr & 3) * 8;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            const bf16x8 vh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(qa_tr16(v0 + 32 * dt), qa_tr16(v1 + 32 * dt), 0, 1, 2, 3, 4, 5, 6, 7));
+                            const bf16x8 vl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(qa_tr16(v0 + 128 + 32 * dt), qa_tr16(v1 + 128 + 32 * dt), 0, 1, 2, 3, 4, 5, 6, 7));
+                            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[dt], 0, 0, 0);
+                            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[dt], 0, 0, 0);
+                            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[dt], 0, 0, 0);
+                        }
+                    }
+                };
+                if (half == 1) QA_SUB_STAMP(10);
+#pragma unroll 1
+                for (int kc = kb; kc < ke; kc += 64) {
+                    if (kc + 32 < ke) step(std::integral_constant<int, 2>{}, kc);
+                    else step(std::integral_constant<int, 1>{}, kc);
+                    if (half == 1 && kc == kb) QA_SUB_STAMP(11);
+                }
+                if (half == 1) QA_SUB_STAMP(12);
+                // lane holds O[query i][d = 16 dt + 4 fk + r].  v_permlane16_swap between the lane rows fk = (0, 1) and (2, 3) trades the dt = 2 c + 1 quad of the even row for
+                // the dt = 2 c quad of the odd one: every lane then owns EIGHT consecutive d (32 c + {0, 16, 8, 24}[fk] + 0..7) = one 16-byte store per plane, the four
+                // lanes of a query write one whole 64-byte block of the hl32 planes (8-byte stores of half blocks took 1.1 k of the phase's 6.3 k cycles and held up
+                // the next tile's first stages behind them)
+                {
+                    const float inv = __builtin_amdgcn_rcpf(l);
+                    const int dsel = (fk & 1) * 16 + (fk >> 1) * 8;
+                    const long long off = (live ? grow(sb, sb2, i) : 0) * p.ldo + ehead * MMS_HEAD_DIM + dsel;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        unsigned w[2][2][2];      // [plane][dt within the pair][dword]: two bf16 each
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            bf16x4 hi, lo;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { bf16 x, y; split_bf16(o[2 * c + t2][r] * inv, x, y); hi[r] = x; lo[r] = y; }
+                            const u32x2_t h2 = __builtin_bit_cast(u32x2_t, hi), l2 = __builtin_bit_cast(u32x2_t, lo);
+                            w[0][t2][0] = h2[0]; w[0][t2][1] = h2[1]; w[1][t2][0] = l2[0]; w[1][t2][1] = l2[1];
+                        }
+#pragma unroll
+                        for (int pl2 = 0; pl2 < 2; ++pl2) {
+                            u32x4 out;
+#pragma unroll
+                            for (int dw = 0; dw < 2; ++dw) {
+                                const auto sw = __builtin_amdgcn_permlane16_swap(w[pl2][0][dw], w[pl2][1][dw], false, false);
+                                out[dw] = sw[0]; out[2 + dw] = sw[1];
+                            }
+                            if (live && !(QA_FLAGS & 8)) *reinterpret_cast<u32x4*>(plane_ptr(pl2 ? p.o_lo : p.o_hi, off + 32 * c)) = out;
+                        }
+                    }
+                    if (half == 1) QA_SUB_STAMP(13);
+                }
+            }
+            } else {
             // work items = (pair, 16-query tile), dealt round-robin to the eight waves in pair order: a pair of 17 .. 32 tokens is two items
             // (four times the MFMAs of a short pair), and the phase lasts as long as its slowest wave
             int item = 0;
@@ -396,121 +670,6 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                     if (qt * 16 >= S || ((first + qt) & (NW - 1)) != wave) continue;
                     f32x4 sc[MAXT];
                     f32x4 o[4];
-                    if constexpr (FAST) {
-                        // ---- split-bf16 MFMA route (mms_config.fuse_attention = 2): Q, K, P, V as hi + lo bf16, three products each
-                        // (hi hi, hi lo, lo hi) on v_mfma_f32_16x16x32_bf16: 1/5 of the matrix-pipe time of the exact-fp32 route ----
-                        auto split8 = [](const float4& u, const float4& v, bf16x8& h, bf16x8& l) {
-                            const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) { bf16 a, c; split_bf16(x[e], a, c); h[e] = a; l[e] = c; }
-                        };
-                        // S^T = K Q^T: first operand = K rows (j = 16 jt + fr), second = Q rows (i = 16 qt + fr); lane: d = 32 ds + 8 fk + 0..7
-                        bf16x8 qh[2], ql[2];
-                        {
-                            int i = qt * 16 + fr;
-                            i = i < S ? i : S - 1;
-                            const float* qp = base + i * QA_LDROW + 8 * fk;
-#pragma unroll
-                            for (int ds = 0; ds < 2; ++ds)
-                                split8(*reinterpret_cast<const float4*>(qp + 32 * ds), *reinterpret_cast<const float4*>(qp + 32 * ds + 4), qh[ds], ql[ds]);
-                        }
-#pragma unroll
-                        for (int jt = 0; jt < MAXT; ++jt) {
-                            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-                            if (jt * 16 < S && !(QA_FLAGS & 2)) {
-                                int j = jt * 16 + fr;
-                                j = j < S ? j : S - 1;
-                                const float* kp = base + j * QA_LDROW + 64 + 8 * fk;
-#pragma unroll
-                                for (int ds = 0; ds < 2; ++ds) {
-                                    bf16x8 kh, kl;
-                                    split8(*reinterpret_cast<const float4*>(kp + 32 * ds), *reinterpret_cast<const float4*>(kp + 32 * ds + 4), kh, kl);
-                                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ds], a4, 0, 0, 0);
-                                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ds], a4, 0, 0, 0);
-                                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ds], a4, 0, 0, 0);
-                                }
-                            }
-                            sc[jt] = a4;
-                        }
-                        // softmax over the keys (lane: key j = 16 jt + 4 fk + r of query i = fr): v_exp_f32 / v_rcp_f32 forms
-                        float m = -INFINITY;
-#pragma unroll
-                        for (int jt = 0; jt < MAXT; ++jt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float v = sc[jt][r] * 0.125f + add[jt][r];
-                                sc[jt][r] = v;
-                                m = fmaxf(m, v);
-                            }
-                        m = rows4_max(m);
-                        float sum = 0.f;
-#pragma unroll
-                        for (int jt = 0; jt < MAXT; ++jt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float e = __builtin_amdgcn_exp2f((sc[jt][r] - m) * 1.44269504088896340736f);
-                                sc[jt][r] = e;
-                                sum += e;
-                            }
-                        sum = rows4_sum(sum);
-                        const float inv = __builtin_amdgcn_rcpf(sum);
-#pragma unroll
-                        for (int jt = 0; jt < MAXT; ++jt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) sc[jt][r] *= inv;
-#pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if constexpr (MAXT > 2) {
-                        // pairs of 33 .. 48 tokens: O = P V on the exact-fp32 MFMAs (attn.hip's form) -- the eight V rows a lane would hold for the
-                        // split-bf16 form do not fit beside three score tiles.  (For MAXT = 2 this form measured 1 % SLOWER than the split-bf16 one
-                        // although it needs no operand conversion: profiles/r03v_bench_pv.txt)
-#pragma unroll
-                        for (int jt = 0; jt < MAXT; ++jt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                if (jt * 16 >= S || (QA_FLAGS & 1)) continue;
-                                int j = jt * 16 + fk * 4 + r;
-                                j = j < S ? j : S - 1;       // P is exactly 0 there
-                                const float4 vf = *reinterpret_cast<const float4*>(base + j * QA_LDROW + 128 + fr * 4);
-                                const float pv = sc[jt][r];
-                                o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.x, o[0], 0, 0, 0);
-                                o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.y, o[1], 0, 0, 0);
-                                o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.z, o[2], 0, 0, 0);
-                                o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.w, o[3], 0, 0, 0);
-                            }
-                        } else {
-                        // O = P V, contraction over 32 key slots per MFMA: slot (fk, e) = key 16 (e >> 2) + 4 fk + (e & 3) of key-tile pair kp2 --
-                        // exactly the lane's own probabilities as first operand; second operand = V[key][d = 4 fr + dt], one MFMA triple per dt
-#pragma unroll
-                        for (int kp2 = 0; kp2 < (MAXT + 1) / 2; ++kp2) {
-                            if (kp2 * 32 >= S || (QA_FLAGS & 1)) continue;
-                            const bool two = 2 * kp2 + 1 < MAXT;
-                            bf16x8 ph, pl;
-                            {
-                                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                                const f32x4 p0 = sc[2 * kp2], p1 = two ? sc[2 * kp2 + 1 < MAXT ? 2 * kp2 + 1 : 0] : z;
-                                split8(float4{p0[0], p0[1], p0[2], p0[3]}, float4{p1[0], p1[1], p1[2], p1[3]}, ph, pl);
-                            }
-                            float4 vrow[8];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                int j = (2 * kp2 + (e >> 2)) * 16 + fk * 4 + (e & 3);
-                                j = j < S ? j : S - 1;       // P is exactly 0 there
-                                vrow[e] = *reinterpret_cast<const float4*>(base + j * QA_LDROW + 128 + fr * 4);
-                            }
-#pragma unroll
-                            for (int dt = 0; dt < 4; ++dt) {
-                                auto comp = [&](const float4& v) { return dt == 0 ? v.x : dt == 1 ? v.y : dt == 2 ? v.z : v.w; };
-                                bf16x8 vh, vl;
-                                split8(float4{comp(vrow[0]), comp(vrow[1]), comp(vrow[2]), comp(vrow[3])},
-                                       float4{comp(vrow[4]), comp(vrow[5]), comp(vrow[6]), comp(vrow[7])}, vh, vl);
-                                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh, o[dt], 0, 0, 0);
-                                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl, o[dt], 0, 0, 0);
-                                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh, o[dt], 0, 0, 0);
-                            }
-                        }
-                        }
-                    } else {
                     float4 qf[4];
                     {
                         int i = qt * 16 + fr;
@@ -581,7 +740,6 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                             o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.z, o[2], 0, 0, 0);
                             o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vf.w, o[3], 0, 0, 0);
                         }
-                    }
                     // lane holds O[i = 16 qt + 4 fk + r][d = 4 fr + dt]
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -601,6 +759,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                     }
                 }
             }
+            }
             qa_barrier();
 #ifdef MMS_LAB
             if (p.trace) tr[3 + 2 * half] = __builtin_readcyclecounter();
@@ -610,7 +769,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
         auto dump_trace = [&]() {
             if (p.trace && tid == 0 && tile_i < 8) {
 #pragma unroll
-                for (int k = 0; k < 7; ++k) p.trace[((long long)blockIdx.x * 8 + tile_i) * 8 + k] = tr[k];
+                for (int k = 0; k < 16; ++k) p.trace[((long long)blockIdx.x * 8 + tile_i) * 16 + k] = tr[k];
             }
             ++tile_i;
         };
@@ -633,18 +792,23 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
 
 bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st) {
     if (p.M <= 0) return true;
-    if (p.K % 64 || p.K < 128 || p.S > 48 || p.S <= 0 || !p.sub || !p.n_sub) return false;
+    if (p.K % 64 || p.K < 128 || p.S <= 0 || !p.sub || !p.n_sub || (p.fast && !p.pair_rec)) return false;
+    const bool cross = p.sub2 != nullptr;
+    const int sub_rows = p.w_lo ? QA_SUB3 : QA_SUB;
+    // exact-fp32 route: per-pair score tiles in registers (<= 48 tokens), one stream; fast route: any pair that fits a sub-tile, one stream or a pair of them
+    if (p.fast ? (p.S + (cross ? p.S2 : 0) > sub_rows) : (p.S > 48 || cross)) return false;
     const int n_cu = device_cu_count();
-    // an upper bound of the tile count (the live count is on the device): every sub-tile but the last of a stream holds > 128 - S rows
-    const long long max_sub = p.M / ((p.w_lo ? QA_SUB3 : QA_SUB) - p.S + 1) + p.M / QA_SEG + 3, max_blk = (max_sub + 1) / 2 * MMS_HEADS;
+    // an upper bound of the tile count (the live count is on the device): every sub-tile but the last of a stream holds > sub_rows - S rows
+    const long long rows = (long long)p.M + (cross ? p.M2 : 0), smax = p.S + (cross ? p.S2 : 0);
+    const long long max_sub = rows / (sub_rows - smax + 1) + p.M / QA_SEG + 3, max_blk = (max_sub + 1) / 2 * MMS_HEADS;
     const dim3 grid((unsigned)(max_blk < n_cu ? max_blk : n_cu)), block(512);
     auto go = [&](const QkvAttnParams& q) {
         const bool fast = q.fast != 0, big = q.S > 32;
         if (q.w_lo) {      // three-pass projection (precision mode 3)
-            if (fast) { if (big) hipLaunchKernelGGL((qkv_attn_kernel<3, true, 2>), grid, block, 0, st, q); else hipLaunchKernelGGL((qkv_attn_kernel<2, true, 2>), grid, block, 0, st, q); }
+            if (fast) hipLaunchKernelGGL((qkv_attn_kernel<2, true, 2>), grid, block, 0, st, q);
             else if (big) hipLaunchKernelGGL((qkv_attn_kernel<3, false, 2>), grid, block, 0, st, q);
             else hipLaunchKernelGGL((qkv_attn_kernel<2, false, 2>), grid, block, 0, st, q);
-        } else if (fast) { if (big) hipLaunchKernelGGL((qkv_attn_kernel<3, true, 1>), grid, block, 0, st, q); else hipLaunchKernelGGL((qkv_attn_kernel<2, true, 1>), grid, block, 0, st, q); }
+        } else if (fast) hipLaunchKernelGGL((qkv_attn_kernel<2, true, 1>), grid, block, 0, st, q);
         else if (big) hipLaunchKernelGGL((qkv_attn_kernel<3, false, 1>), grid, block, 0, st, q);
         else hipLaunchKernelGGL((qkv_attn_kernel<2, false, 1>), grid, block, 0, st, q);
     };
@@ -653,7 +817,7 @@ bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st) {
     static bool traced = false;
     if (want_trace && !traced) {
         traced = true;
-        const size_t bytes = (size_t)grid.x * 8 * 8 * 8;
+        const size_t bytes = (size_t)grid.x * 8 * 16 * 8;
         unsigned long long* buf = nullptr;
         if (hipMalloc((void**)&buf, bytes) != hipSuccess) return false;
         (void)hipMemsetAsync(buf, 0, bytes, st);

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def report(path="/tmp/qa_trace.bin"):
-    t = np.fromfile(path, dtype=np.uint64).reshape(-1, 8, 8).astype(np.int64)
+    t = np.fromfile(path, dtype=np.uint64).reshape(-1, 8, 16).astype(np.int64)
     names = ["main loop", "dump 0", "attention 0", "dump 1", "attention 1", "next prologue"]
     for tile in range(1, 6):
         x = t[:, tile, :7]
@@ -17,6 +17,13 @@ def report(path="/tmp/qa_trace.bin"):
         d = np.diff(x[ok], axis=1)
         print("tile %d (%d workgroups): " % (tile, ok.sum()) + "  ".join("%s %d" % (n, np.median(d[:, i])) for i, n in enumerate(names))
               + "   | total %d ticks" % np.median(x[ok, 6] - x[ok, 0]))
+        y = t[:, tile, :]
+        sub = y[ok][:, 8] > 0
+        if sub.any():      # wave 0's own progress (split-bf16 route): inside dump 0 and inside attention 1
+            z = y[ok][sub]
+            print("        wave 0: dump body %d  stores landed +%d  barrier +%d   || attention 1: range + Q %d  first step +%d  steps done +%d  stores issued +%d  barrier +%d" % (
+                np.median(z[:, 8] - z[:, 1]), np.median(z[:, 9] - z[:, 8]), np.median(z[:, 2] - z[:, 9]),
+                np.median(z[:, 10] - z[:, 4]), np.median(z[:, 11] - z[:, 10]), np.median(z[:, 12] - z[:, 11]), np.median(z[:, 13] - z[:, 12]), np.median(z[:, 5] - z[:, 13])))
 
 
 if __name__ == "__main__":
