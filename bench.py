@@ -132,8 +132,8 @@ def cpu_baseline(cfg, w, hip_logits_fn=None, budget_s=20.0):
         ref.append(np.asarray(out[0], np.float64))
         done = hi
     res = {"value": round(done / dt, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
-           "sample": "%d of config 1's 3000 pairs (100 queries x 30 candidates) in batches of 256, torch fp32 restatement of %s on %d "
-                     "threads, %.1f s" % (done, cfg.name, cores, dt)}
+           "sample": "%d of config 1's 3000 pairs (100 queries x 30 candidates) in batches of 256, %s fp32 restatement of %s on %d "
+                     "threads, %.1f s" % (done, "numpy (BLAS)" if cfg.name == "lxmert" else "torch", cfg.name, cores, dt)}
     if hip_logits_fn is not None:
         got = hip_logits_fn(cut(0, done))
         ref = np.concatenate(ref)
@@ -280,7 +280,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of host CPU work spent on the cpu_baseline sample (default 20; the contract test uses less)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (precision 3 on fp32 weights, lds, lxmert, H2D-inclusive)")
     ap.add_argument("--fp32-weights", action="store_true", help="seeded weights NOT rounded to bf16 (what a real checkpoint looks like)")
-    ap.add_argument("--fuse-attn", type=int, default=-1, help="mms_config.fuse_attention (default: the LIBRARY default, scorers.make_scorer's \"auto\": 2 for zk / lds, 0 for lxmert): QKV projection + self-attention in one kernel; 1 = exact-fp32 attention MFMAs (bit-identical to the two-kernel route), 2 = split-bf16 MFMAs")
+    ap.add_argument("--fuse-attn", type=int, default=-1, help="mms_config.fuse_attention (default: the LIBRARY default, scorers.make_scorer's \"auto\": 2 in precision mode 2, 1 in mode 3): QKV projection + attention in one kernel; 1 = exact-fp32 attention MFMAs (bit-identical to the two-kernel route), 2 = split-bf16 MFMAs")
     ap.add_argument("--box-mu", type=float, default=1.1, help="location of the lognormal box count of the synthetic pairs (1.1 = the documented workload, mean 3.5 boxes)")
     ap.add_argument("--batch-sweep", action="store_true", help="instead of the headline run: pairs/s and per-call latency of the three drop-in call surfaces at the reference's own call sizes")
     ap.add_argument("--fuse-ln", type=int, nargs="?", const=3, default=-1, help="LayerNorm fused into the N = 768 GEMM epilogues (mms_config.fuse_layernorm mask: 1 attention output, 2 FFN down, 3 both; default: the library default)")
@@ -601,7 +601,7 @@ def secondary(a, local, dev, ps, feats, members, scorer, feed, value):
         return fd, {"value": round(ps_.n * steps / dt, 1), "unit": "pairs/s", "precision_mode": s.precision, "fuse_attention": s.fuse_attention,
                     "gemm_tflops": round(gfl / (gms * 1e-3) / 1e12, 1), "frac": round(gfl / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
-    def quick(name, precision, fp32_weights, note=None, **skw):
+    def quick(name, precision, fp32_weights, note=None, cpu=False, **skw):
         cfg = CFGS[name]()
         w = weights.make_weights(cfg, bf16_matrices=not fp32_weights)
         s = scorers.make_scorer(cfg, w, precision=precision, device=local, chunk_pairs=a.chunk,
@@ -612,10 +612,13 @@ def secondary(a, local, dev, ps, feats, members, scorer, feed, value):
         if note:
             r["weights"] = note
         s.close()
+        if cpu and not a.no_cpu:
+            # VERDICT r4 item 7 / BASELINE.md section 3: the same model's CPU restatement timed on this box's host cores (bounded sample, as the line's cpu_baseline)
+            r["cpu_port"] = cpu_baseline(cfg, w, None, budget_s=max(2.0, a.cpu_budget / 2))
         return r
     out["precision3"] = quick("zk", "auto", True, "seeded fp32, NOT bf16-rounded (a real checkpoint's situation); precision auto -> mode 3")
-    out["lds"] = quick("lds", 2, False)
-    out["lxmert"] = quick("lxmert", 2, False)
+    out["lds"] = quick("lds", 2, False, cpu=True)
+    out["lxmert"] = quick("lxmert", 2, False, cpu=True)
     # ---- SURVEY.md section 8(d)'s other workload shapes on the same code: the reference's padded layout, the all-10-boxes worst case, and
     # how the rate moves with the box count (live_token_fraction is a property of the synthetic distribution, not of the kernels) ----
     zcfg, zw, zs = members["zk"]

@@ -95,8 +95,12 @@ typedef struct mms_config {
                                  result columns in LDS and attends from there), so the fp32 [rows][2304] Q | K | V tensor never goes
                                  through HBM.  Precision modes 2 and 3 (mode 3: a 192-row tile variant with the weights' lo plane in the ring); context
                                  rows bit-identical to the two-kernel route.
-                                 2: the same with the attention's Q K^T and P V on split-bf16 MFMAs (hi + lo operands, three products,
-                                 v_exp_f32 / v_rcp_f32 softmax) instead of exact-fp32 MFMAs: ~2^-16 relative on the scores */
+                                 2: the attention's Q K^T and P V on split-bf16 MFMAs (hi + lo operands, three products, v_exp_f32 / v_rcp_f32 softmax)
+                                 instead of exact-fp32 MFMAs: ~2^-16 relative on the scores.  Precision mode 2 runs the 8 x 1-wave kernel (Q operands
+                                 straight from the accumulators, K / V staged as bf16 planes in LDS, 16-query tiles attended block-diagonally over the
+                                 pairs they touch with an online softmax): any pair length that fits a 128-row sub-tile, lxmert's 10-token box stream
+                                 included, and BOTH directions of lxmert's cross-attention (lxrt/modeling.py:460-464) in one launch per X layer.
+                                 scorers.py's "auto": 2 in precision mode 2, 1 in mode 3 */
 } mms_config;
 
 /* zk feed, code/imagebert_zk/evaluate_normal.py:141-152.  np_idx_class_labels [B,10,8] is either passed as the reference
@@ -185,10 +189,23 @@ int mms_finalize(mms_handle* h);
 
 /* logits / probs: device fp32 [B,2] (probs may be NULL).
  * Pairs are independent: how a caller groups them into calls (or mms_config.chunk_pairs into launch waves) changes a logit by fp32 summation
- * order at most (~1e-5 relative), and not at all between launches of the same size regime -- < 1024, < 8192, < 16384 padded token rows
- * (pairs x sequence length) and above: each regime has its own GEMM routes (split-K tiles for small calls -- and, bit-identical to them, the skinny
- * kernel for launches of <= 128 rows --, persistent ping-pong engines with the fused QKV + attention / LayerNorm epilogues for big ones; DESIGN.md
- * section 3).  A call is ~110 (zk, lds) to ~220 (lxmert) dependent launches: 0.6 - 1.1 ms at 1 pair, so batch thousands of pairs per call when
+ * order at most (~1e-5 relative), and not at all between launches of the same SIZE REGIME.  A launch's regime is decided by its PADDED row bound
+ * (pairs x sequence length of the stream; the live count stays on the device), per projection class -- every boundary that changes a summation order:
+ *   rows <= 128              every projection on the skinny kernel (gemm_skinny.hip), K sliced exactly as the tile route of the same projection would
+ *                            slice it: bit-identical to the next regime (128 is a speed boundary only)
+ *   rows <  1024             wide projections (N >= 1536, K = 768: QKV, K | V, FFN-up): K in 4 slices, summed in fixed order (k_splitk_reduce)
+ *   rows <  4096             the long-K projections in front of the encoder (K >= 2048, N = 768: zk kdd_conv1 as im2col over 8 x distinct label texts,
+ *                            kdd_conv2 / visn_fc / featureemb over the box rows): K in 8 slices
+ *   rows <  8192             the N = 768 projections that a LayerNorm follows (attention output, FFN-down): K in 4 (K = 768) / 8 (K >= 2048) slices,
+ *                            summed by the LayerNorm kernel
+ *   rows <  16384            register-staged / LDS-DMA 128 x 256 tiles (bit-identical to each other), one pass over K; attention = the two-kernel route
+ *   rows >= 16384            persistent ping-pong engines; mms_config.fuse_layernorm: bias + residual + LayerNorm in the GEMM epilogue (one-pass variance);
+ *                            mms_config.fuse_attention: projection + attention in one kernel (2: split-bf16 attention arithmetic, online softmax)
+ * Batch composition enters in two more places: lxmert with pack_tokens runs its language layers once per DISTINCT query when at least half of the pairs
+ * share theirs (the rows of that stage = distinct queries x text_len), and label texts are encoded once per distinct 8-id tuple (rows = tuples).
+ * Not numerical boundaries (same arithmetic, tested bit-identical): the LDS-DMA tile variant taken when a launch has no more workgroups than CUs, the
+ * read-back-free label de-duplication of calls of <= 51 pairs, packed vs. dense token layout.
+ * A call is ~110 (zk, lds) to ~220 (lxmert) dependent launches: 0.6 - 1.1 ms at 1 pair, so batch thousands of pairs per call when
  * throughput matters ("Call sizes"). */
 int mms_score_zk(mms_handle* h, const mms_zk_batch* b, float* logits, float* probs, void* stream);
 int mms_score_lds(mms_handle* h, const mms_lds_batch* b, float* logits, float* probs, void* stream);

@@ -1287,7 +1287,7 @@ int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int
         while (cap < 2 * B) cap <<= 1;
         void* p;
         auto get = [&](size_t bytes, void** out) { int rc = dev_alloc(h, h->lq_allocs, &p, bytes); *out = p; return rc; };
-        if (int rc = get((size_t)cap * 4, (void**)&h->lq_slots)) return rc;
+        if (int rc = get((size_t)cap * 2 * 4, (void**)&h->lq_slots)) return rc;      // hash table + per-slot smallest row (launch_query_dedup)
         if (int rc = get((size_t)B * 4, (void**)&h->lq_rep)) return rc;
         if (int rc = get((size_t)B * 4, (void**)&h->lq_uid)) return rc;
         if (int rc = get((size_t)B * 4, (void**)&h->lq_rows_of)) return rc;

@@ -130,8 +130,12 @@ __device__ __forceinline__ bool qeq(const int64_t* a, const int64_t* am, const i
     for (int i = 0; i < T; ++i) e = e && a[i] == b[i] && am[i] == bm[i];
     return e;
 }
+// The distinct queries are numbered in the order of their FIRST occurrence in the batch, whatever the order in which the threads reach the hash table: the
+// table slot of a key remembers the smallest row that holds it (atomicMin), a prefix count over the "I am that row" flags gives the numbers.  (Numbering by an
+// atomic counter made the row order of the distinct-query stage -- and with it the sub-tile a query lands in -- differ from call to call; the split-bf16
+// attention route sums a query's keys in an order that depends on its place in the sub-tile, so identical calls were not bit-identical.)
 __global__ __launch_bounds__(256) void k_qdedup_insert(const int64_t* ids, const int64_t* mask, int T, int rows, int* slots, unsigned cmask,
-                                                       int* rep) {
+                                                       int* slot_of, int* min_row) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
     const int64_t *mi = ids + (long long)r * T, *mm = mask + (long long)r * T;
@@ -142,17 +146,21 @@ __global__ __launch_bounds__(256) void k_qdedup_insert(const int64_t* ids, const
             const int old = atomicCAS(&slots[h], -1, r);
             s = old < 0 ? r : old;
         }
-        if (s == r || qeq(ids + (long long)s * T, mask + (long long)s * T, mi, mm, T)) { rep[r] = s; return; }
+        if (s == r || qeq(ids + (long long)s * T, mask + (long long)s * T, mi, mm, T)) { slot_of[r] = (int)h; atomicMin(&min_row[h], r); return; }
         h = (h + 1) & cmask;
     }
 }
-// claimants take consecutive numbers; rows_of[u] = the pair row that holds distinct query u
-__global__ __launch_bounds__(256) void k_qdedup_number(int rows, const int* rep, int* uid, int* counter, int* rows_of) {
+__global__ __launch_bounds__(256) void k_qdedup_flag(int rows, const int* slot_of, const int* min_row, int* flag) {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows || rep[r] != r) return;
-    const int u = atomicAdd(counter, 1);
-    uid[r] = u;
-    rows_of[u] = r;
+    if (r < rows) flag[r] = min_row[slot_of[r]] == r ? 1 : 0;
+}
+// index[] holds the exclusive prefix count of the flags: the number of a query's first row IS its distinct-query number; rows_of[u] = that row
+__global__ __launch_bounds__(256) void k_qdedup_fill(int rows, const int* slot_of, const int* min_row, int* rows_of, int* index) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const int c = min_row[slot_of[r]];
+    if (c == r) rows_of[index[r]] = r;
+    else index[r] = index[c];      // (index[c] is the same value before and after row c's own pass)
 }
 __global__ __launch_bounds__(256) void k_gather_i64_rows(const int64_t* in, const int* rows_of, int T, long long n, int64_t* out) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = in[(long long)rows_of[i / T] * T + i % T];
@@ -284,12 +292,15 @@ void launch_label_dedup_i64(const int64_t* ids, int rows, int* slots, int cap, i
 void launch_query_dedup(const int64_t* ids, const int64_t* mask, int T, int rows, int* slots, int cap, int* rep, int* uid, int* counter,
                         int* rows_of, int* index, hipStream_t st) {
     if (rows <= 0) return;
+    // slots: int[2 * cap] -- the hash table and, behind it, the smallest row of every slot's key
+    int* min_row = slots + cap;
     (void)hipMemsetAsync(slots, 0xFF, (size_t)cap * 4, st);
-    (void)hipMemsetAsync(counter, 0, 4, st);
+    (void)hipMemsetAsync(min_row, 0x7F, (size_t)cap * 4, st);
     const dim3 grid((rows + 255) / 256), block(256);
-    hipLaunchKernelGGL(k_qdedup_insert, grid, block, 0, st, ids, mask, T, rows, slots, (unsigned)(cap - 1), rep);
-    hipLaunchKernelGGL(k_qdedup_number, grid, block, 0, st, rows, rep, uid, counter, rows_of);
-    hipLaunchKernelGGL(k_dedup_index, grid, block, 0, st, rows, rep, uid, index);
+    hipLaunchKernelGGL(k_qdedup_insert, grid, block, 0, st, ids, mask, T, rows, slots, (unsigned)(cap - 1), rep, min_row);
+    hipLaunchKernelGGL(k_qdedup_flag, grid, block, 0, st, rows, rep, min_row, uid);
+    launch_plan_scan(uid, rows, index, counter, st);
+    hipLaunchKernelGGL(k_qdedup_fill, grid, block, 0, st, rows, rep, min_row, rows_of, index);
 }
 void launch_gather_i64_rows(const int64_t* in, const int* rows_of, int T, long long n_rows, int64_t* out, hipStream_t st) {
     if (n_rows > 0) hipLaunchKernelGGL(k_gather_i64_rows, flat_grid(n_rows * T), dim3(256), 0, st, in, rows_of, T, n_rows * T, out);

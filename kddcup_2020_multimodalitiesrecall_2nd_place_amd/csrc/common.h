@@ -105,8 +105,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case ACT_RELU: return fmaxf(v, 0.0f);
         case ACT_GELU_TANH: {  // pixelbert.py:326-328: v * 0.5 * (1 + tanh(c (v + 0.044715 v^3))) = v - v / (exp(2u) + 1)
             const float k1 = 2.0f * 0.7978845608028654f * 1.4426950408889634f, k2 = k1 * 0.044715f;     // exp(2u) = exp2(v (k1 + k2 v^2))
-            const float r = fast_rcp(fast_exp2(v * (k1 + k2 * v * v)) + 1.0f);
-            return v - v * r;
+            // the fused multiply-adds are WRITTEN, operation for operation as in gelu_tanh2() below: the small-call routes (k_splitk_reduce: this scalar form) and the
+            // tile engines (packed form) are bit-identical by construction, not by what -ffp-contract happens to fuse
+            const float t = v * k2;
+            const float u = __builtin_fmaf(v, t, k1);
+            const float r = fast_rcp(fast_exp2(v * u) + 1.0f);
+            return __builtin_fmaf(-v, r, v);
         }
         case ACT_GELU_ERF:     // lxrt/modeling.py:119
             return v * 0.5f * (1.0f + fast_erf(v * 0.70710678118654752f));

@@ -220,7 +220,8 @@ void launch_label_dedup_i32(const int32_t* ids, int rows, int* slots, int cap, i
                             int64_t* uniq64, int* index, hipStream_t st);
 void launch_label_dedup_i64(const int64_t* ids, int rows, int* slots, int cap, int* rep, int* uid, int* counter, int32_t* uniq32,
                             int64_t* uniq64, int* index, hipStream_t st);
-// distinct (input_ids, input_mask) rows of a lxmert batch: index[b] = distinct-query number of pair b, rows_of[u] = a pair row holding query u
+// distinct (input_ids, input_mask) rows of a lxmert batch: index[b] = distinct-query number of pair b, rows_of[u] = the FIRST pair row holding query u; the queries
+// are numbered in the order of their first occurrence (deterministic).  slots: int[2 * cap]
 void launch_query_dedup(const int64_t* ids, const int64_t* mask, int T, int rows, int* slots, int cap, int* rep, int* uid, int* counter,
                         int* rows_of, int* index, hipStream_t st);
 void launch_gather_i64_rows(const int64_t* in, const int* rows_of, int T, long long n_rows, int64_t* out, hipStream_t st);

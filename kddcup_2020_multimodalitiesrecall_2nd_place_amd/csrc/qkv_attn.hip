@@ -790,6 +790,425 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     }
 }
 
+// =====================================================================================================================================
+// qkv_attn2_kernel: the split-bf16 route (mms_config.fuse_attention = 2) of precision mode 2, wave grid 8(M) x 1(N).
+//
+// Same projection engine (256-row tile = two sub-tiles of whole pairs, one head = 192 columns, 3-slot LDS-DMA ring, one phase of 48 MFMAs per wave and
+// stage), but every wave owns 16 rows of EACH sub-tile and all 192 columns of them: its accumulators hold Q, K and V of two 16-query tiles.  What that buys
+// (tools/qa_trace.py, profiles/rd5*_qa_trace*.txt: in the 4 x 2 layout a sub-tile's staging was written by four waves, one per SIMD -- a single wave issues one
+// VALU instruction per ~4.5 cycles, tools/probes/valu_rate_probe.hip -- and Q went through LDS like K and V):
+//  * Q never leaves the registers: accumulator fragment pairs (2 b, 2 b + 1) of lane (row, nq) ARE the second MFMA operand of S^T = K Q^T for the contraction
+//    slots d = 32 b + 16 h + 4 nq + e (h = fragment of the pair, e < 4), after one split into hi / lo bf16;
+//  * K and V are staged in that slot order ("positions": p = 32 b + 8 nq + 4 h + e), so a lane's two fragments of a pair are ONE 16-byte store per plane (no
+//    cross-lane exchange, conflict-free at the 528-byte row stride) and a K fragment is ONE ds_read_b128; all eight waves write, 16 rows each;
+//  * per sub-tile: stage K / V (8 stores per lane) -> barrier -> every wave attends its own 16 queries (block-diagonal over the pairs they belong to, online
+//    softmax over 64-key steps, V^T fragments by ds_read_b64_tr_b16) -> barrier.  The context comes out in position order: lane (query fr, fk) holds d = 32 b +
+//    16 (fk & 1) + 8 (dt & 1) + 4 (fk >> 1) + r of fragment dt = 2 b + (dt & 1); v_permlane32_swap pairs them into 16-byte stores.
+// Scores carry log2(e) / sqrt(64) (folded into Q before its split), the additive key mask log2(e): probabilities are one v_exp_f32 away.
+// =====================================================================================================================================
+__global__ __launch_bounds__(512) void qkv_attn2_kernel(const QkvAttnParams p) {
+    constexpr int SUB = QA_SUB, BM = 2 * SUB, NW = 8, FM = 2, FN = 12, BN = 192;
+    constexpr int AREG = BM * 128, WREG = BN * 64, SLOT = 48 * 1024, NAP = BM / 64, NSLOT = 3, D = 2, P = NAP + 2;
+    constexpr int LDK = 528;      // staged row: [K_hi | K_lo | V_hi | V_lo] x 64 bf16 in position order + 16 B (4 banks mod 32: 16-byte stores of 8 rows and fragment reads are conflict-free)
+    constexpr float QSCALE = 0.125f * 1.44269504088896340736f, LOG2E = 1.44269504088896340736f;
+    static_assert(AREG + WREG <= SLOT && NSLOT * SLOT - SUB * LDK >= AREG + WREG, "slot 0's stage lies below the K / V staging area");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * SLOT];
+    __shared__ __attribute__((aligned(16))) float m_keyadd[256 + 64];     // additive key mask (x log2 e) by tile row (+ 64: a step may run past the sub-tile)
+    __shared__ __attribute__((aligned(16))) float m_bias[192];            // this head's [Q | K | V] bias
+    __shared__ int m_rowmeta[256];                                        // per tile row: the sub-tile rows [kbeg, kend) its query attends (kbeg | kend << 16)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_sub = *p.n_sub;
+    const int nbm = (n_sub + 1) >> 1, nblk = nbm * MMS_HEADS;
+    const bool cross = p.sub2 != nullptr;
+    if (p.flop_counter && blockIdx.x == 0 && tid == 0) {
+        int Meff = p.M;
+        if (p.m_dev) { const int md = *p.m_dev; Meff = md < Meff ? md : Meff; }
+        if (cross) { int m2 = p.M2; if (p.m_dev2) { const int md = *p.m_dev2; m2 = md < m2 ? md : m2; } Meff += m2; }
+        atomicAdd(p.flop_counter, 2ull * (unsigned long long)Meff * (unsigned long long)(3 * MMS_HIDDEN) * (unsigned long long)p.K);
+    }
+    int vb = blockIdx.x;
+    if (vb >= nblk) return;
+    if (tid < 64) m_keyadd[256 + tid] = 0.f;
+
+    const int gr_l = lane >> 2, gc = lane & 3;
+    const bf16* a_src[NAP];
+    const bf16* w_src[2];
+    int head;
+    int4 sub0, sub1;
+    int2 sub0b = make_int2(0, 0), sub1b = sub0b;
+    int meta_a = 0, meta_b = 0;          // thread < 256: key mask of tile row tid, bias[tid]; else: the plan's record of pair (tid - 256) of the tile
+    int nhead = 0;
+    int4 nsub0 = make_int4(0, 0, 0, 0), nsub1 = nsub0;
+    int2 nsub0b = make_int2(0, 0), nsub1b = nsub0b;
+    auto locate = [&](int v) {      // bijective XCD remap (virtual block v runs on XCD v % 8): the twelve heads of a row tile stay on one XCD's L2
+        const int q = nblk >> 3, r8 = nblk & 7, xcd = v & 7, loc = v >> 3;
+        int bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+        if (p.reverse) bid = nblk - 1 - bid;
+        const int nb = bid / MMS_HEADS;
+        nhead = __builtin_amdgcn_readfirstlane(bid % MMS_HEADS);
+        auto uni = [](int4 v) {
+            return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z),
+                             __builtin_amdgcn_readfirstlane(v.w));
+        };
+        nsub0 = uni(p.sub[2 * nb]);
+        nsub1 = 2 * nb + 1 < n_sub ? uni(p.sub[2 * nb + 1]) : make_int4(nsub0.x, 0, 0, 0);
+        if (cross) {
+            const int4 a = uni(p.sub2[2 * nb]), b = 2 * nb + 1 < n_sub ? uni(p.sub2[2 * nb + 1]) : make_int4(a.x, 0, 0, 0);
+            nsub0b = make_int2(a.x, a.y); nsub1b = make_int2(b.x, b.y);
+        }
+    };
+    auto grow = [&](const int4& sa, const int2& sb2, int lr) -> long long {      // plane-buffer row behind row lr of a sub-tile (stream-1 rows first, then its stream-2 rows)
+        return lr < sa.y ? (long long)(sa.x + lr) : p.row0_b + (long long)(sb2.x + (lr - sa.y));
+    };
+    auto setup = [&]() {
+        head = nhead; sub0 = nsub0; sub1 = nsub1; sub0b = nsub0b; sub1b = nsub1b;
+#pragma unroll
+        for (int q4 = 0; q4 < NAP; ++q4) {
+            const int r = q4 * 64 + wave * 8 + (lane >> 3);
+            const int4 sb = (r / SUB) ? sub1 : sub0;
+            const int2 sb2 = make_int2((r / SUB) ? sub1b.x : sub0b.x, (r / SUB) ? sub1b.y : sub0b.y);
+            const int nlive = sb.y + sb2.y;
+            int lr = r % SUB;
+            lr = lr < nlive ? lr : (nlive > 0 ? nlive - 1 : 0);
+            const long long gr = nlive > 0 ? grow(sb, sb2, lr) : (long long)sb.x;
+            a_src[q4] = p.a_hi + 2 * (gr * (long long)p.lda) + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int r = h2 ? 128 + (wave & 3) * 16 + gr_l : wave * 16 + gr_l;
+            w_src[h2] = p.w + wtile_off(head * BN + r, 0, p.K) + (gc ^ qa_swz(r)) * 8;
+        }
+    };
+    // ... and its metadata (key mask, bias, pair records): fetched at the END of the epilogue, so that the values are live across the main loop only -- requested in front
+    // of the attention phases they were spilled to scratch at once, and every wave sat out the full latency of the loads (2.3 k cycles per tile)
+    auto setup_meta = [&]() -> int2 {      // (returned, not written through the capture: as captured variables the two values lived on the stack)
+        const int t = tid & 255;
+        const int u = tid < 256 ? (t >= SUB) : (t >> 7), i = tid < 256 ? t - u * SUB : (t & 127);
+        const int4 sb = u ? sub1 : sub0;
+        const int2 sb2 = make_int2(u ? sub1b.x : sub0b.x, u ? sub1b.y : sub0b.y);
+        int ma = 0, mb = 0;
+        if (tid < 256) {
+            if (i < sb.y) { if (p.key_add) ma = __float_as_int(p.key_add[sb.x + i]); }
+            else if (i < sb.y + sb2.y) { if (p.key_add2) ma = __float_as_int(p.key_add2[sb2.x + (i - sb.y)]); }
+            if (tid < BN) mb = __float_as_int(p.bias[head * BN + tid]);
+        } else if (i < sb.w) ma = p.pair_rec[sb.z + i];
+        return make_int2(ma, mb);
+    };
+    locate(vb);
+    setup();
+    { const int2 mm = setup_meta(); meta_a = mm.x; meta_b = mm.y; }
+    auto issue = [&](int q, int st, int slot) {
+        unsigned char* d;
+        const bf16* s;
+        if (q < NAP) { d = smem + slot * SLOT + q * 8192 + wave * 1024; s = a_src[q] + st * 64; }
+        else {
+            const int h2 = q - NAP;
+            d = smem + slot * SLOT + AREG + (h2 ? 8192 + (wave & 3) * 1024 : wave * 1024);
+            s = w_src[h2] + st * 512;
+        }
+        __builtin_amdgcn_global_load_lds((glb_void*)s, (lds_void*)d, 16, 0, 0);
+    };
+
+    f32x4 acc[FM][FN];
+    const int ns = p.K / 32;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int laneA = (wave * 16 + fr) * 128 + ((fk ^ ((fr >> 1) & 7)) << 4);      // rows 16 wave + fr of sub-tile 0; sub-tile 1: + SUB * 128; lo: chunk ^ 4
+    const int laneB = AREG + fr * 64 + ((fk ^ qa_swz(fr)) << 4);                    // column fragment j: + j * 16 * 64
+
+    auto stage = [&](auto pre_tag, auto wait_tag, int s, int slot) {
+        constexpr bool PRE = decltype(pre_tag)::value;
+        constexpr int WAITN = decltype(wait_tag)::value;
+        const unsigned char* sb = smem + slot * SLOT;
+        const int nslot = slot == 0 ? NSLOT - 1 : slot - 1;
+        bf16x8 a[2][FM], b[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + laneB + j * 16 * 64);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(sb + (laneA ^ (pl << 6)) + i * SUB * 128);
+        if (PRE) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) issue(q, s + D, nslot);
+        }
+        if (WAITN >= 0) qa_wait_vmcnt<(WAITN >= 0 ? WAITN : 0)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        qa_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[pass][i], acc[i][j], 0, 0, 0);   // swapped operands: C^T fragment
+        __builtin_amdgcn_s_setprio(0);
+        qa_barrier();
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) issue(q, d, d);
+    }
+    qa_wait_vmcnt<P>();
+    qa_barrier();
+    if (wave >= NW / 2) qa_barrier();     // stagger the two halves by one barrier
+
+    unsigned char* stgb = smem + NSLOT * SLOT - SUB * LDK;
+#ifdef MMS_LAB
+    const int QA_FLAGS = p.lab_flags;     // timing only (results WRONG): 1 no P V MFMAs, 2 no Q K^T MFMAs, 8 no context stores, 16 no attention, 32 no staging stores
+    unsigned long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int tile_i = 0;
+#define QA2_STAMP(k) do { if (p.trace) tr[k] = __builtin_readcyclecounter(); } while (0)
+#else
+    constexpr int QA_FLAGS = 0;
+#define QA2_STAMP(k) do { } while (0)
+#endif
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        QA2_STAMP(0);
+        const bool more = vb + (int)gridDim.x < nblk;
+        if (more) locate(vb + (int)gridDim.x);
+        int slot = 0, s = 0;
+        for (; s + D < ns; ++s) {
+            stage(std::true_type{}, std::integral_constant<int, (D - 1) * P>{}, s, slot);
+            slot = slot == NSLOT - 1 ? 0 : slot + 1;
+        }
+        stage(std::false_type{}, std::integral_constant<int, 0>{}, s, slot);         // stage ns-2: the last stage must have landed
+        slot = slot == NSLOT - 1 ? 0 : slot + 1;
+        ++s;
+        // park this tile's metadata in LDS (every wave passes a barrier between its own writes and the first read)
+        if (wave >= NW / 2) {
+            const int t = tid - 256, u = t >> 7;
+            const int4 sa = u ? sub1 : sub0;
+            if ((t & 127) < sa.w) {      // the pair's rows learn which sub-tile rows their queries attend: its own rows, or (CROSS) its rows in the other stream
+                const int r1 = meta_a & 255, c1 = (meta_a >> 8) & 255;
+                if (cross) {
+                    const int r2 = sa.y + ((meta_a >> 16) & 255), c2 = (meta_a >> 24) & 255;
+                    for (int r = 0; r < c1; ++r) m_rowmeta[u * SUB + r1 + r] = r2 | ((r2 + c2) << 16);
+                    for (int r = 0; r < c2; ++r) m_rowmeta[u * SUB + r2 + r] = r1 | ((r1 + c1) << 16);
+                } else {
+                    for (int r = 0; r < c1; ++r) m_rowmeta[u * SUB + r1 + r] = r1 | ((r1 + c1) << 16);
+                }
+            }
+        }
+        stage(std::false_type{}, std::integral_constant<int, -1>{}, s, slot);        // stage ns-1
+        if (wave < NW / 2) {
+            m_keyadd[tid] = __int_as_float(meta_a) * LOG2E;
+            const int u = tid >= SUB, i = tid - u * SUB;
+            if (i >= (u ? sub1.y + sub1b.y : sub0.y + sub0b.y)) m_rowmeta[tid] = 0;      // rows behind the last pair attend nothing
+            if (tid < BN) m_bias[tid] = __int_as_float(meta_b);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            qa_barrier();     // re-align the halves: nobody reads the ring any more
+        }
+        QA2_STAMP(1);
+
+        // this tile's identity for the epilogue; then the next tile's addresses and its stage 0 (slot 0 is idle and lies below the staging area)
+        const int ehead = head;
+        const int4 esub0 = sub0, esub1 = sub1;
+        const int2 esub0b = sub0b, esub1b = sub1b;
+        if (more) vb += (int)gridDim.x;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int4 sa = s2 ? esub1 : esub0;
+            const int2 sa2 = make_int2(s2 ? esub1b.x : esub0b.x, s2 ? esub1b.y : esub0b.y);
+            const int nlive = sa.y + sa2.y;
+            // ---- Q operands of this wave's 16 queries, from its own accumulators ----
+            bf16x8 qh[2], ql[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(m_bias + 16 * (2 * b + h) + 4 * fk);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bf16 x, y; split_bf16((acc[s2][2 * b + h][e] + b4[e]) * QSCALE, x, y); qh[b][4 * h + e] = x; ql[b][4 * h + e] = y; }
+                }
+            // ---- K / V rows of this wave -> staging, position order ----
+            {
+                unsigned char* dst = stgb + (wave * 16 + fr) * LDK + fk * 16;
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {      // fragment pairs (4, 5) (6, 7): K blocks 0, 1;  (8, 9) (10, 11): V blocks 0, 1
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = 4 + 2 * pr + h;
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(m_bias + 16 * j + 4 * fk);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { bf16 x, y; split_bf16(acc[s2][j][e] + b4[e], x, y); hi[4 * h + e] = x; lo[4 * h + e] = y; }
+                    }
+                    if (QA_FLAGS & 32) continue;
+                    *reinterpret_cast<bf16x8*>(dst + (pr >> 1) * 256 + (pr & 1) * 64) = hi;
+                    *reinterpret_cast<bf16x8*>(dst + (pr >> 1) * 256 + (pr & 1) * 64 + 128) = lo;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            qa_barrier();
+            QA2_STAMP(2 + 2 * s2);
+            // the next tile's addresses and its stage 0 (slot 0 lies below the staging area), half of the pieces in front of each attention phase: 48 pieces
+            // issued by all waves at once are a ~2.6 k cycle burst on the CU's one load path; spread, they land while the waves compute
+            if (more) {
+                if (s2 == 0) setup();
+#pragma unroll
+                for (int q = 0; q < P / 2; ++q) issue(s2 * (P / 2) + q, 0, 0);
+            }
+            // ---- attention of the wave's 16 queries: block-diagonal over the pairs they belong to ----
+            if (wave * 16 < nlive && !(QA_FLAGS & 16)) {
+                const int i = wave * 16 + fr;
+                const bool live = i < nlive;
+                const int rm = m_rowmeta[s2 * SUB + (live ? i : nlive - 1)];
+                const int kbeg = rm & 0xffff, kend = (int)((unsigned)rm >> 16);
+                const int kb = __builtin_amdgcn_readfirstlane(qa_row16_min(live ? kbeg : 0x7fff)) & ~3;
+                const int ke = __builtin_amdgcn_readfirstlane(qa_row16_max(live ? kend : 0));
+                const float* kadd = m_keyadd + s2 * SUB;
+                float m = -INFINITY, l = 0.f;
+                f32x4 o[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // one step = NH halves of 32 keys (compile-time: no branch inside, so the score tiles' LDS reads and MFMA chains interleave)
+                auto step = [&](auto nh_tag, const int kc) {
+                    constexpr int NH = decltype(nh_tag)::value;
+                    // S^T tile t: first operand = K rows (key j = kc + 16 t + fr), second = the Q rows; lane gets keys kc + 16 t + 4 fk + r of query fr
+                    f32x4 sc[2 * NH];
+#pragma unroll
+                    for (int t = 0; t < 2 * NH; ++t) {
+                        f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+                        if (!(QA_FLAGS & 2)) {
+                            int j = kc + 16 * t + fr;
+                            j = j < SUB ? j : SUB - 1;
+                            const unsigned char* kr = stgb + j * LDK + 16 * fk;
+                            const bf16x8 kh0 = *reinterpret_cast<const bf16x8*>(kr), kh1 = *reinterpret_cast<const bf16x8*>(kr + 64);
+                            const bf16x8 kl0 = *reinterpret_cast<const bf16x8*>(kr + 128), kl1 = *reinterpret_cast<const bf16x8*>(kr + 192);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, qh[0], a4, 0, 0, 0);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, ql[0], a4, 0, 0, 0);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl0, qh[0], a4, 0, 0, 0);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, qh[1], a4, 0, 0, 0);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, ql[1], a4, 0, 0, 0);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl1, qh[1], a4, 0, 0, 0);
+                        }
+                        sc[t] = a4;
+                    }
+                    // additive key mask; keys outside the query's own range do not exist for it
+                    const int j0 = kc + 4 * fk;
+                    float sv[8 * NH];
+                    float cm = -INFINITY;
+#pragma unroll
+                    for (int t = 0; t < 2 * NH; ++t) {
+                        const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + j0 + 16 * t);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int j = j0 + 16 * t + r;
+                            const float v = (j >= kbeg && j < kend) ? sc[t][r] + ka[r] : -INFINITY;
+                            sv[4 * t + r] = v;
+                            cm = fmaxf(cm, v);
+                        }
+                    }
+                    cm = rows4_max(cm);
+                    const float mn = fmaxf(m, cm);
+                    const float ms = mn == -INFINITY ? 0.f : mn;          // (no key of this query so far)
+                    float ps = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8 * NH; ++e) {
+                        sv[e] = __builtin_amdgcn_exp2f(sv[e] - ms);
+                        ps += sv[e];
+                    }
+                    ps = rows4_sum(ps);
+                    if (kc != kb) {      // (first step: the sums are still zero)
+                        const float alpha = __builtin_amdgcn_exp2f(m - ms);
+                        l *= alpha;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+                    }
+                    l += ps;
+                    m = mn;
+                    // O^T += V^T P^T over each half's 32 key slots: slot (fk, e) = key kc + 32 h + 16 (e >> 2) + 4 fk + (e & 3) -- the lane's own probabilities are the
+                    // second operand; first operand = V^T[position 16 dt + fr][slot]: two transposing reads of the [4 keys][16 positions] blocks at keys + 4 fk, + 16 + 4 fk
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        if (QA_FLAGS & 1) continue;
+                        bf16x8 ph, pl;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { bf16 x, y; split_bf16(sv[8 * h + e], x, y); ph[e] = x; pl[e] = y; }
+                        int r0 = kc + 32 * h + 4 * fk + (fr >> 2), r1 = r0 + 16;
+                        r0 = r0 < SUB ? r0 : SUB - 1;      // (P is exactly 0 there)
+                        r1 = r1 < SUB ? r1 : SUB - 1;
+                        const unsigned char* v0 = stgb + r0 * LDK + 256 + (fr & 3) * 8;
+                        const unsigned char* v1 = stgb + r1 * LDK + 256 + (fr & 3) * 8;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            const bf16x8 vh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(qa_tr16(v0 + 32 * dt), qa_tr16(v1 + 32 * dt), 0, 1, 2, 3, 4, 5, 6, 7));
+                            const bf16x8 vl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(qa_tr16(v0 + 128 + 32 * dt), qa_tr16(v1 + 128 + 32 * dt), 0, 1, 2, 3, 4, 5, 6, 7));
+                            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[dt], 0, 0, 0);
+                            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[dt], 0, 0, 0);
+                            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[dt], 0, 0, 0);
+                        }
+                    }
+                };
+#pragma unroll 1
+                for (int kc = kb; kc < ke; kc += 64) {
+                    if (kc + 32 < ke) step(std::integral_constant<int, 2>{}, kc);
+                    else step(std::integral_constant<int, 1>{}, kc);
+                }
+                // lane holds O[query fr][position 16 dt + 4 fk + r] = d 32 (dt >> 1) + 16 (fk & 1) + 8 (dt & 1) + 4 (fk >> 1) + r.  v_permlane32_swap of the fragments
+                // dt = 2 b (first) and 2 b + 1 (second) between the lane rows fk and fk + 2 leaves every lane EIGHT consecutive d: 32 b + 16 (fk & 1) + 8 (fk >> 1) + 0..7
+                {
+                    const float inv = __builtin_amdgcn_rcpf(l);
+                    const long long off = (live ? grow(sa, sa2, i) : 0) * p.ldo + ehead * MMS_HEAD_DIM + (fk & 1) * 16 + (fk >> 1) * 8;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        unsigned w[2][2][2];      // [plane][fragment of the pair][dword]: two bf16 each
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            bf16x4 hi, lo;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { bf16 x, y; split_bf16(o[2 * b + t2][r] * inv, x, y); hi[r] = x; lo[r] = y; }
+                            const u32x2_t h2 = __builtin_bit_cast(u32x2_t, hi), l2 = __builtin_bit_cast(u32x2_t, lo);
+                            w[0][t2][0] = h2[0]; w[0][t2][1] = h2[1]; w[1][t2][0] = l2[0]; w[1][t2][1] = l2[1];
+                        }
+#pragma unroll
+                        for (int pl2 = 0; pl2 < 2; ++pl2) {
+                            u32x4 out;
+#pragma unroll
+                            for (int dw = 0; dw < 2; ++dw) {
+                                const auto sw = __builtin_amdgcn_permlane32_swap(w[pl2][0][dw], w[pl2][1][dw], false, false);
+                                out[dw] = sw[0]; out[2 + dw] = sw[1];
+                            }
+                            if (live && !(QA_FLAGS & 8)) *reinterpret_cast<u32x4*>(plane_ptr(pl2 ? p.o_lo : p.o_hi, off + 32 * b)) = out;
+                        }
+                    }
+                }
+            }
+            qa_barrier();
+            QA2_STAMP(3 + 2 * s2);
+        }
+#ifdef MMS_LAB
+        auto dump_trace = [&]() {
+            if (p.trace && tid == 0 && tile_i < 8) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) p.trace[((long long)blockIdx.x * 8 + tile_i) * 16 + k] = tr[k];
+            }
+            ++tile_i;
+        };
+        if (!more) { tr[6] = tr[5]; dump_trace(); }
+#endif
+        if (!more) break;
+#pragma unroll
+        for (int q = 0; q < P; ++q) issue(q, 1, 1);       // slots 1 / 2 were under the staging area until the barrier above
+        qa_wait_vmcnt<P>();      // stage 0 has landed once at most P operations are outstanding (loads complete in issue order; the context stores only add to the count)
+        qa_barrier();
+        { const int2 mm = setup_meta(); meta_a = mm.x; meta_b = mm.y; }            // (behind the stage-1 pieces: the main loop's counted waits see these loads complete in front of every piece they wait for)
+#ifdef MMS_LAB
+        QA2_STAMP(6);
+        dump_trace();
+#endif
+        if (wave >= NW / 2) qa_barrier();    // stagger again
+    }
+}
+
 bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st) {
     if (p.M <= 0) return true;
     if (p.K % 64 || p.K < 128 || p.S <= 0 || !p.sub || !p.n_sub || (p.fast && !p.pair_rec)) return false;
@@ -808,7 +1227,13 @@ bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st) {
             if (fast) hipLaunchKernelGGL((qkv_attn_kernel<2, true, 2>), grid, block, 0, st, q);
             else if (big) hipLaunchKernelGGL((qkv_attn_kernel<3, false, 2>), grid, block, 0, st, q);
             else hipLaunchKernelGGL((qkv_attn_kernel<2, false, 2>), grid, block, 0, st, q);
-        } else if (fast) hipLaunchKernelGGL((qkv_attn_kernel<2, true, 1>), grid, block, 0, st, q);
+        } else if (fast) {      // 8 x 1 wave layout (qkv_attn_kernel<2, true, 1> is the same route in the 4 x 2 layout: lab A/B, MMS_QA_LAYOUT=42)
+#ifdef MMS_LAB
+            static const bool old_layout = getenv("MMS_QA_LAYOUT") && atoi(getenv("MMS_QA_LAYOUT")) == 42;
+            if (old_layout) { hipLaunchKernelGGL((qkv_attn_kernel<2, true, 1>), grid, block, 0, st, q); return; }
+#endif
+            hipLaunchKernelGGL(qkv_attn2_kernel, grid, block, 0, st, q);
+        }
         else if (big) hipLaunchKernelGGL((qkv_attn_kernel<3, false, 1>), grid, block, 0, st, q);
         else hipLaunchKernelGGL((qkv_attn_kernel<2, false, 1>), grid, block, 0, st, q);
     };

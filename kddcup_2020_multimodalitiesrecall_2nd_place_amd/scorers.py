@@ -39,11 +39,12 @@ class _Base:
             from .weights import auto_precision
             precision = auto_precision(weights)
         if fuse_attention == "auto":
-            # mms_config.fuse_attention = 2 (QKV projection + self-attention in one kernel, Q K^T / P V on split-bf16 MFMAs: the configuration
-            # bench.py measures; <= 4e-5 from the exact-fp32 attention at full depth, held to the oracle by tests/test_parity_gpu.py) wherever
-            # it is faster: zk / lds +5 % in precision modes 2 and 3, lxmert +-0.5 % (profiles/r03q_*, r04a_*) -> the two-kernel route there.
-            # 1 = the same kernel with exact-fp32 attention MFMAs (bit-identical to the two-kernel route), opt-in.
-            fuse_attention = 0 if cfg.name == "lxmert" else 2
+            # mms_config.fuse_attention = 2 (QKV projection + attention in one kernel, Q K^T / P V on split-bf16 MFMAs: the configuration bench.py measures; <= 4e-5
+            # from the exact-fp32 attention at full depth, held to the oracle by tests/test_parity_gpu.py): zk / lds +5 % over the two-kernel route, lxmert +6.5 % since
+            # round 5 (its 10-token box stream and BOTH directions of its cross-attention run in the fused kernel too: profiles/rd5*).  Precision mode 3 -- the mode
+            # that follows an arbitrary fp32 checkpoint -- keeps the attention arithmetic exact (1: the same kernel with exact-fp32 attention MFMAs, bit-identical
+            # to the two-kernel route; lxmert's cross-attention then stays on the two-kernel route): ADVICE r4.
+            fuse_attention = 1 if precision == 3 else 2
         if fuse_layernorm == "auto":
             # mms_config.fuse_layernorm mask 3: bias + residual + LayerNorm in the epilogue of the attention-output and FFN-down projections of
             # the big launches (precision mode 2; gemm_pp_ln.h) -- no LayerNorm launches, no fp32 round trip of the pre-LayerNorm tensor;

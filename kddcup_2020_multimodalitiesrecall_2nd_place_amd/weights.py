@@ -226,18 +226,26 @@ def make_lxmert_weights(cfg: LxmertConfig = LxmertConfig(), seed: int = 20200823
 
 
 _MEMO: dict = {}
+_MEMO_BYTES = 3 << 30      # host memory the memo may pin (twelve full models were ~10 GB); the oldest entries go first
 
 
-def make_weights(cfg, seed: int = 20200823, bf16_matrices: bool = True):
-    """Seeded weights of ``cfg``.  Memoised per process (a pure function of its arguments): callers get their own dict over SHARED, read-only
-    arrays -- replace an entry to change a tensor (``w[k] = w[k] * 2``), in-place edits raise."""
+def make_weights(cfg, seed: int = 20200823, bf16_matrices: bool = True, memo: bool = True):
+    """Seeded weights of ``cfg`` (synthetic: tests, bench.py, smoke()).  Memoised per process up to ``_MEMO_BYTES`` of host memory -- a pure function of its
+    arguments, and the test suite builds the same full-size models dozens of times.  Callers get their own dict over SHARED, READ-ONLY arrays: replace an
+    entry to change a tensor (``w[k] = w[k] * 2``); an in-place edit (``w[k] *= 2``) raises.  ``memo=False`` returns private, writeable arrays and leaves
+    the memo alone ("Synthetic weights")."""
+    maker = {"zk": make_zk_weights, "lds": make_lds_weights, "lxmert": make_lxmert_weights}[cfg.name]
+    if not memo:
+        return maker(cfg, seed, bf16_matrices)
     key = (repr(cfg), seed, bool(bf16_matrices))
     if key not in _MEMO:
-        w = {"zk": make_zk_weights, "lds": make_lds_weights, "lxmert": make_lxmert_weights}[cfg.name](cfg, seed, bf16_matrices)
+        w = maker(cfg, seed, bf16_matrices)
         for v in w.values():
             v.flags.writeable = False
-        if len(_MEMO) >= 12:                       # bound the host memory a long-lived process keeps (full models: 0.4 .. 0.8 GB each)
-            _MEMO.pop(next(iter(_MEMO)))
+        size = lambda d: sum(v.nbytes for v in d.values())
+        total = size(w) + sum(size(d) for d in _MEMO.values())
+        while _MEMO and total > _MEMO_BYTES:
+            total -= size(_MEMO.pop(next(iter(_MEMO))))
         _MEMO[key] = w
     return dict(_MEMO[key])
 

@@ -324,7 +324,14 @@ def test_full_size_workload_properties():
     l1b, _ = scorers.score_batch(s, b)
     torch.cuda.synchronize()
     assert torch.equal(l1, l1b)                                   # idempotent / deterministic
-    assert torch.equal(l1[-1], l1[7])                             # identical inputs -> identical logits
+    # identical inputs in two different slots of the batch: the library default (fuse_attention = 2) attends 16-query tiles of a sub-tile block-diagonally, so the
+    # order in which a pair's keys are summed depends on where the pair sits in its sub-tile: equal to fp32 summation order (far inside the 1e-3 contract) ...
+    assert vecrel(l1[-1:].cpu().numpy(), l1[7:8].cpu().numpy()).max() < 1e-4
+    # ... and bit-identical with the exact-fp32 attention arithmetic (fuse_attention = 1: one work item per pair, position-independent)
+    se = scorers.ZkScorer(cfg, w, chunk_pairs=8192, fuse_attention=1)
+    le, _ = scorers.score_batch(se, b)
+    assert se.handle.counter(0) > 0 and torch.equal(le[-1], le[7])
+    se.close()
     assert torch.isfinite(l1).all() and (p1.sum(1) - 1).abs().max() < 1e-6
     l1 = l1.cpu().numpy()
     # oracle on a random subset

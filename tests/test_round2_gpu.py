@@ -145,7 +145,14 @@ def test_full_size_workload_properties(name):
     l1, p1 = scorers.score_batch(s, b)
     l1b, _ = scorers.score_batch(s, b)
     torch.cuda.synchronize()
-    assert torch.equal(l1, l1b) and torch.equal(l1[-1], l1[7])
+    assert torch.equal(l1, l1b)                                      # deterministic (lxmert: the distinct queries are numbered in input order)
+    # a duplicated pair sits in another place of its sub-tile: the split-bf16 attention route (library default) sums its keys in another order -> fp32 round-off;
+    # the exact-fp32 attention route (fuse_attention = 1) is position-independent: bit-identical
+    assert vecrel(l1[-1:].cpu().numpy(), l1[7:8].cpu().numpy()).max() < 1e-4
+    se = scorers.make_scorer(cfg, w, chunk_pairs=8192, fuse_attention=1)
+    le, _ = scorers.score_batch(se, b)
+    assert torch.equal(le[-1], le[7])
+    se.close()
     assert torch.isfinite(l1).all() and (p1.sum(1) - 1).abs().max() < 1e-6
     l1 = l1.cpu().numpy()
     idx = np.sort(np.random.RandomState(0).choice(ps.n, 12, replace=False))
