@@ -462,7 +462,8 @@ def main():
             # pairs -- timed apart from the GEMM launches above, priced on the projection FLOPs alone
             f_ach = fused[2] / (fused[0] * 1e-3) / 1e12
             res["roofline"]["fused_qkv_attention"] = {
-                "kernel": "qkv_attn_kernel<*,%s> 256x192 tile (one head of [Q|K|V]) + in-LDS attention" % ("true" if a.fuse_attn == 2 else "false"),
+                "kernel": ("qkv_attn2_kernel (8 x 1 waves) 256x192 tile (one head of [Q|K|V]) + in-LDS split-bf16 attention" if a.fuse_attn == 2 and a.precision == 2
+                           else "qkv_attn_kernel<*,%s> 256x192 tile (one head of [Q|K|V]) + in-LDS attention" % ("true" if a.fuse_attn == 2 else "false")),
                 "launches": int(fused[1]), "avg_launch_ms": round(fused[0] / fused[1], 4),
                 "achieved": round(f_ach, 2), "frac": round(f_ach / peak, 4),
                 "traffic": round(fused_traffic, 1) if fused_traffic else None,

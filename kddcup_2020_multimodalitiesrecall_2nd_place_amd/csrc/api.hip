@@ -103,6 +103,7 @@ struct mms_handle {
     int fuse_ln = 0;       // mms_config.fuse_layernorm (lab build: env MMS_FUSE_LN overrides)
     int fuse_attn = 0;     // mms_config.fuse_attention: QKV projection + self-attention in one kernel (qkv_attn.hip; precision mode 2)
     int* qa_rec[3] = {nullptr, nullptr, nullptr};      // per-pair records of the tables (split-bf16 attention route)
+    int* qa_jump = nullptr;                            // scratch of the plan kernel (jump tables)
     int4* qa_sub[4] = {nullptr, nullptr, nullptr, nullptr}; int* qa_nsub = nullptr;     // sub-tile tables of the (up to two) token streams of a launch wave; [2], [3]: the CROSS table of the stream pair (lxmert X layers)
     // label-text workspace, sized for lab_cap unique labels
     int64_t lab_cap = 0;
@@ -533,6 +534,8 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
         if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(pairs + 2) * 4)) return rc;
         h->qa_rec[s] = (int*)p;
     }
+    if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)qkv_plan_scratch_ints((int)pairs) * 4)) return rc;
+    h->qa_jump = (int*)p;
     if (int rc = dev_alloc(h, h->ws_allocs, &p, 16)) return rc;
     h->qa_nsub = (int*)p;
     if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(rows + 256) * 3 * 2 * 8)) return rc;
@@ -876,13 +879,13 @@ void plan_tiles(mms_handle* h, hipStream_t st, Pack& pk, int64_t n, int S, int s
     // (fuse_attention = 1: one work item per pair and 16-query tile) only for pairs of >= 16 tokens -- the split-bf16 route works on 16-row tiles of the sub-tile
     // whatever the pairs' lengths (lxmert's 10-token box stream included)
     if (n * S < 16384 || (S < 16 && h->fuse_attn != 2)) return;
-    launch_qkv_tile_plan(pk.off, pk.cnt, pk.rows, (int)n, S, h->qa_sub[slot], h->qa_nsub + slot, h->nsplit, st, h->qa_rec[slot]);
+    if (!launch_qkv_tile_plan(pk.off, pk.cnt, (int)n, S, h->qa_sub[slot], h->qa_nsub + slot, h->nsplit, st, h->qa_rec[slot], h->qa_jump)) return;
     pk.sub = h->qa_sub[slot]; pk.n_sub = h->qa_nsub + slot; pk.rec = h->qa_rec[slot];
 }
 // ... of a PAIR of streams for the fused cross-attention launches of lxmert's X layers (fuse_attention = 2): a sub-tile = the rows of its pairs in both streams
 void plan_cross_tiles(mms_handle* h, hipStream_t st, Pack& px, const Pack& p1, const Pack& p2, int64_t n, int S1, int S2) {
     if (h->fuse_attn != 2 || (h->nsplit != 2 && h->nsplit != 3) || h->f8 || !h->qa_sub[2] || n * (S1 + S2) < 16384) return;
-    launch_qkv_cross_plan(p1.off, p1.cnt, p1.rows, p2.off, p2.cnt, (int)n, S1, S2, h->qa_sub[2], h->qa_sub[3], h->qa_nsub + 2, h->nsplit, st, h->qa_rec[2]);
+    if (!launch_qkv_cross_plan(p1.off, p1.cnt, p2.off, p2.cnt, (int)n, S1, S2, h->qa_sub[2], h->qa_sub[3], h->qa_nsub + 2, h->nsplit, st, h->qa_rec[2], h->qa_jump)) return;
     px.sub = h->qa_sub[2]; px.sub2 = h->qa_sub[3]; px.n_sub = h->qa_nsub + 2; px.rec = h->qa_rec[2];
 }
 

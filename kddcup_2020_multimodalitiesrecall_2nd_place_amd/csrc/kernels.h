@@ -125,10 +125,13 @@ struct QkvAttnParams {
     unsigned long long* trace;               // lab builds: per-tile timeline (qkv_attn.hip), nullptr otherwise
     int lab_flags;                           // lab builds: timing-only knock-outs
 };
-void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, int passes, hipStream_t st, int* pair_rec = nullptr);   // rows_dev: device-side row total of a packed stream (or nullptr); pair_rec: int[n] (QkvAttnParams::pair_rec)
+// sub-tile table of a token stream (n pairs; off / cnt: first row / live tokens per pair or nullptr = dense, S tokens each); pair_rec: int[n] (QkvAttnParams::pair_rec)
+// or nullptr; scratch: qkv_plan_scratch_ints(n) ints.  false: more pairs than one plan takes (40 K: the caller keeps the two-kernel attention route)
+bool launch_qkv_tile_plan(const int* off, const int* cnt, int n, int S, int4* sub, int* n_sub, int passes, hipStream_t st, int* pair_rec, int* scratch);
 // ... of a PAIR of streams (cross mode): a pair brings cnt[b] + cnt2[b] rows, sub / sub2 as QkvAttnParams describes them
-void launch_qkv_cross_plan(const int* off, const int* cnt, const int* rows_dev, const int* off2, const int* cnt2, int n, int S, int S2,
-                           int4* sub, int4* sub2, int* n_sub, int passes, hipStream_t st, int* pair_rec);
+bool launch_qkv_cross_plan(const int* off, const int* cnt, const int* off2, const int* cnt2, int n, int S, int S2,
+                           int4* sub, int4* sub2, int* n_sub, int passes, hipStream_t st, int* pair_rec, int* scratch);
+int qkv_plan_scratch_ints(int n);
 bool launch_qkv_attn(const QkvAttnParams& p, hipStream_t st);   // false: shape not supported (S > 48, K % 64)
 
 // ---------------------------------------------------------------------------------------------

@@ -83,90 +83,97 @@ __device__ __forceinline__ qa_s16x4 qa_tr16(const unsigned char* lds_quad) {
 
 // ---- tile plan: pairs -> sub-tiles of <= 128 rows ----
 // sub[u] = {first stream row, rows, first pair, pairs}; *n_sub = number of sub-tiles.  off == nullptr: dense stream (pair b = rows b*S ..).
-// The stream is cut into SEGMENTS of about QA_SEG rows at pair boundaries (binary search in the row offsets); one thread packs the pairs
-// of its segment greedily in pair order (first pass: count; block scan; second pass: write).  Only a segment's last sub-tile is left
-// underfull by the cut: ~0.5 sub-tiles of 64.  (A single greedy chain over all pairs is 30 000 dependent steps: 2 ms per plan.)
+// The packing is the greedy one in pair order (a sub-tile takes pairs until the next one would not fit, at most QA_SUB3 of them), computed in PARALLEL:
+//   1. next[b] = the pair at which a sub-tile that starts at pair b ends (monotone in b: every thread sweeps its ~30 consecutive pairs with one running pointer);
+//   2. pointer doubling in LDS: J_k[b] = next applied 2^k times (J_k+1[b] = J_k[J_k[b]], J[n] = n is the end; 16-bit entries, two levels ping-pong), and with every
+//      level the known sub-tile starts double: start[i + 2^k] = J_k[start[i]] for i < 2^k;
+//   3. one thread per sub-tile writes its record and the records of its pairs.
+// ~30 us per plan of 30 000 pairs, whatever their lengths.  (Rounds 3-4 cut the stream into 8192-row segments and let one thread pack each segment sequentially:
+// 60 us for zk's 15-row pairs, but 220-700 us for lxmert's 4-row box stream -- 1.8 % of its step once that stream and the cross plan were fused too -- and
+// every segment ended in an underfull sub-tile.)
 // CROSS plans (sub2 != nullptr; lxmert X layers): a pair brings the rows of BOTH its streams (cnt[b] + cnt2[b]) into the sub-tile;
-// sub2[u] = {first row of stream 2, its rows, 0, 0}.  The segments are cut by the rows of stream 1.
+// sub2[u] = {first row of stream 2, its rows, 0, 0}.
+// pair_rec[b]: the pair's place inside its sub-tile, as the fused kernel's split-bf16 attention wants it (one dword, no arithmetic in front of the kernel's main
+// loop): first row | rows << 8 in stream 1, first row << 16 | rows << 24 in stream 2 (rows relative to the sub-tile's part of the stream).
 constexpr int QA_PLAN_THREADS = 1024;
-constexpr int QA_SEG = 8192;
+constexpr int QA_SEG = 8192;         // (launch_qkv_attn's grid bound still allows for one underfull sub-tile per 8192 rows)
+constexpr int QA_PLAN_MAXN = 40 * 1024 - 8;      // pairs per plan: two 16-bit jump tables of n + 1 entries in LDS (chunk_pairs <= 32768)
 
 __global__ __launch_bounds__(QA_PLAN_THREADS) void k_qkv_tile_plan(const int* __restrict__ off, const int* __restrict__ cnt, int n, int S,
-                                                                   const int* __restrict__ rows_dev, int4* __restrict__ sub, int* __restrict__ n_sub, int sub_rows,
+                                                                   int4* __restrict__ sub, int* __restrict__ n_sub, int sub_rows,
                                                                    const int* __restrict__ off2, const int* __restrict__ cnt2, int S2, int4* __restrict__ sub2,
-                                                                   int* __restrict__ pair_rec) {
-    __shared__ int sh[QA_PLAN_THREADS];
-    // the per-pair token counts (<= 48) as bytes in LDS: each thread then walks its ~500 pairs twice without a global access in the loop
-    // (530 us -> ~60 us per plan); streams of more pairs than fit read them from memory
-    constexpr int QA_PLAN_CACHE = 72 * 1024;
-    __shared__ unsigned char cnt8[QA_PLAN_CACHE], cnt8b[QA_PLAN_CACHE];
+                                                                   int* __restrict__ pair_rec, int* start) {
+    __shared__ unsigned short jt[2][QA_PLAN_MAXN + 1];
+    __shared__ int s_nsub;
     const int tid = threadIdx.x;
     const bool cross = sub2 != nullptr;
-    const bool cached = cnt && n <= QA_PLAN_CACHE && (!cross || cnt2);
-    if (cached) {
-        for (int b = tid; b < n; b += QA_PLAN_THREADS) { cnt8[b] = (unsigned char)cnt[b]; if (cross) cnt8b[b] = (unsigned char)cnt2[b]; }
-        __syncthreads();
+    auto first1 = [&](int b) { return off ? off[b] : b * S; };
+    auto first2 = [&](int b) { return !cross ? 0 : off2 ? off2[b] : b * S2; };
+    auto rows1 = [&](int b) { return cnt ? cnt[b] : S; };
+    auto rows2 = [&](int b) { return !cross ? 0 : cnt2 ? cnt2[b] : S2; };
+    auto cum = [&](int b) { return b < n ? first1(b) + first2(b) : first1(n - 1) + first2(n - 1) + rows1(n - 1) + rows2(n - 1); };   // rows in front of pair b
+    // start[] lives in global memory and is written and read by this one workgroup: agent-scope accesses keep stale L1 lines out of the picture
+    auto sl = [&](int i) { return __hip_atomic_load(start + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ss = [&](int i, int v) { __hip_atomic_store(start + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // 1. next[] -> level 0; start[] = "no sub-tile" (n) except start[0] = pair 0
+    {
+        const int per = (n + QA_PLAN_THREADS - 1) / QA_PLAN_THREADS, b0 = tid * per, b1 = min(b0 + per, n);
+        int e = b0 + 1;
+        for (int b = b0; b < b1; ++b) {
+            const int base = cum(b), lim = min(n, b + QA_SUB3);      // (the kernel keeps at most 128 pair records per sub-tile)
+            if (e <= b) e = b + 1;
+            while (e < lim && cum(e + 1) - base <= sub_rows) ++e;
+            jt[0][b] = (unsigned short)e;
+        }
+        if (tid == 0) jt[0][n] = (unsigned short)n;
+        for (int i = tid; i <= n; i += QA_PLAN_THREADS) ss(i, i == 0 ? 0 : n);
     }
-    const long long total = off ? (rows_dev ? (long long)*rows_dev : (long long)off[n - 1] + cnt[n - 1]) : (long long)n * S;
-    long long seg = QA_SEG;
-    if (total > seg * QA_PLAN_THREADS) seg = ((total + QA_PLAN_THREADS - 1) / QA_PLAN_THREADS + 127) / 128 * 128;
-    const int nseg = (int)((total + seg - 1) / seg);
-    auto first_pair = [&](long long row) -> int {       // first pair whose first row is >= row
-        if (!off) { const long long b = (row + S - 1) / S; return b < n ? (int)b : n; }
-        int lo = 0, hi = n;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (off[mid] < row) lo = mid + 1; else hi = mid; }
-        return lo;
-    };
-    int p0 = n, p1 = n;
-    if (tid < nseg) { p0 = first_pair((long long)tid * seg); p1 = tid + 1 < nseg ? first_pair((long long)(tid + 1) * seg) : n; }
-    auto pack = [&](int out) {       // out < 0: count only
-        int rows = 0, rows2 = 0, row0 = 0, row02 = 0, pair0 = p0, ns = 0;
-        // first row of pair b: the offsets are the running sum of the counts, so one load per thread replaces a dependent global load
-        // at every sub-tile start (those loads, not the walk, were most of the plan's 360 us)
-        int cursor = p0 < p1 ? (off ? off[p0] : p0 * S) : 0;
-        int cursor2 = (cross && p0 < p1) ? (off2 ? off2[p0] : p0 * S2) : 0;
-        for (int b = p0; b < p1; ++b) {
-            const int c = cached ? (int)cnt8[b] : cnt ? cnt[b] : S;
-            const int c2 = !cross ? 0 : cached ? (int)cnt8b[b] : cnt2 ? cnt2[b] : S2;
-            if (rows + rows2 + c + c2 > sub_rows || (rows + rows2 > 0 && b - pair0 >= QA_SUB3)) {      // (the kernel keeps at most 128 pair records per sub-tile)
-                if (out >= 0) { sub[out + ns] = make_int4(row0, rows, pair0, b - pair0); if (cross) sub2[out + ns] = make_int4(row02, rows2, 0, 0); }
-                ++ns;
-                rows = rows2 = 0;
-            }
-            if (rows + rows2 == 0) { row0 = cursor; row02 = cursor2; pair0 = b; }
-            // the pair's place inside its sub-tile, as the fused kernel's split-bf16 attention wants it (one dword, no arithmetic in front of the kernel's main
-            // loop): first row | rows << 8 in stream 1, first row << 16 | rows << 24 in stream 2 (rows relative to the sub-tile's part of the stream)
-            if (out >= 0 && pair_rec) pair_rec[b] = (cursor - row0) | (c << 8) | ((cursor2 - row02) << 16) | (c2 << 24);
-            rows += c; rows2 += c2;
-            cursor += c; cursor2 += c2;
-        }
-        if (rows + rows2 > 0) {
-            if (out >= 0) { sub[out + ns] = make_int4(row0, rows, pair0, p1 - pair0); if (cross) sub2[out + ns] = make_int4(row02, rows2, 0, 0); }
-            ++ns;
-        }
-        return ns;
-    };
-    const int mine = pack(-1);
-    sh[tid] = mine;
     __syncthreads();
-    for (int o = 1; o < QA_PLAN_THREADS; o <<= 1) {
-        const int v = tid >= o ? sh[tid - o] : 0;
+    // 2. doubling
+    int cur = 0;
+    for (int k = 0; (1 << k) <= n; ++k) {
+        for (int i = tid; i < (1 << k); i += QA_PLAN_THREADS) {
+            const int b = sl(i);
+            if (b < n) { const int t = jt[cur][b]; if (t < n) ss(i + (1 << k), t); }
+        }
+        for (int b = tid; b <= n; b += QA_PLAN_THREADS) jt[cur ^ 1][b] = jt[cur][jt[cur][b]];
         __syncthreads();
-        sh[tid] += v;
-        __syncthreads();
+        cur ^= 1;
     }
-    if (mine > 0) pack(sh[tid] - mine);
-    if (tid == QA_PLAN_THREADS - 1) *n_sub = sh[tid];
+    // 3. count, then the records
+    for (int i = tid; i < n; i += QA_PLAN_THREADS)
+        if (sl(i) < n && (i + 1 == n || sl(i + 1) >= n)) { s_nsub = i + 1; *n_sub = i + 1; }
+    __syncthreads();
+    const int nsub = s_nsub;
+    for (int u = tid; u < nsub; u += QA_PLAN_THREADS) {
+        const int s0 = sl(u), e = u + 1 < nsub ? sl(u + 1) : n;
+        const int r1 = first1(s0), r2 = first2(s0);
+        int a1 = 0, a2 = 0;
+        for (int b = s0; b < e; ++b) {
+            const int c = rows1(b), c2 = rows2(b);
+            if (pair_rec) pair_rec[b] = a1 | (c << 8) | (a2 << 16) | (c2 << 24);
+            a1 += c; a2 += c2;
+        }
+        sub[u] = make_int4(r1, a1, s0, e - s0);
+        if (cross) sub2[u] = make_int4(r2, a2, 0, 0);
+    }
 }
-void launch_qkv_tile_plan(const int* off, const int* cnt, const int* rows_dev, int n, int S, int4* sub, int* n_sub, int passes, hipStream_t st, int* pair_rec) {
-    if (n > 0) hipLaunchKernelGGL(k_qkv_tile_plan, dim3(1), dim3(QA_PLAN_THREADS), 0, st, off, cnt, n, S, rows_dev, sub, n_sub, passes == 3 ? QA_SUB3 : QA_SUB,
-                                  (const int*)nullptr, (const int*)nullptr, 0, (int4*)nullptr, pair_rec);
+bool launch_qkv_tile_plan(const int* off, const int* cnt, int n, int S, int4* sub, int* n_sub, int passes, hipStream_t st, int* pair_rec, int* scratch) {
+    if (n <= 0) return true;
+    if (n > QA_PLAN_MAXN) return false;
+    hipLaunchKernelGGL(k_qkv_tile_plan, dim3(1), dim3(QA_PLAN_THREADS), 0, st, off, cnt, n, S, sub, n_sub, passes == 3 ? QA_SUB3 : QA_SUB,
+                       (const int*)nullptr, (const int*)nullptr, 0, (int4*)nullptr, pair_rec, scratch);
+    return true;
 }
-void launch_qkv_cross_plan(const int* off, const int* cnt, const int* rows_dev, const int* off2, const int* cnt2, int n, int S, int S2,
-                           int4* sub, int4* sub2, int* n_sub, int passes, hipStream_t st, int* pair_rec) {
-    if (n > 0) hipLaunchKernelGGL(k_qkv_tile_plan, dim3(1), dim3(QA_PLAN_THREADS), 0, st, off, cnt, n, S, rows_dev, sub, n_sub, passes == 3 ? QA_SUB3 : QA_SUB,
-                                  off2, cnt2, S2, sub2, pair_rec);
+bool launch_qkv_cross_plan(const int* off, const int* cnt, const int* off2, const int* cnt2, int n, int S, int S2,
+                           int4* sub, int4* sub2, int* n_sub, int passes, hipStream_t st, int* pair_rec, int* scratch) {
+    if (n <= 0) return true;
+    if (n > QA_PLAN_MAXN) return false;
+    hipLaunchKernelGGL(k_qkv_tile_plan, dim3(1), dim3(QA_PLAN_THREADS), 0, st, off, cnt, n, S, sub, n_sub, passes == 3 ? QA_SUB3 : QA_SUB,
+                       off2, cnt2, S2, sub2, pair_rec, scratch);
+    return true;
 }
+int qkv_plan_scratch_ints(int n) { return n + 1; }
 
 // MAXT: 16-token tiles per side of the attention (2: pairs of <= 32 tokens, 3: <= 48)
 // WPL: weight planes.  1 = precision mode 2 (bf16 weights; a_hi w + a_lo w), sub-tiles of 128 rows, 64 x 96 per wave;

@@ -16,7 +16,7 @@ for r in csv.DictReader(open("$R/gpurun_out/pmc/${tag}_mfma_counter_collection.c
     cnt[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for d, c in cnt.items():
-    if d not in dur or ("gemm_pp_kernel" not in dur[d][1] and "qkv_attn_kernel" not in dur[d][1]) or dur[d][0] < 200000: continue
+    if d not in dur or ("gemm_pp_kernel" not in dur[d][1] and "qkv_attn" not in dur[d][1]) or dur[d][0] < 200000: continue
     name = dur[d][1].split("(")[0].replace("void ", "")
     a = agg[name]
     for k, v in c.items(): a[k] += v
