@@ -608,9 +608,8 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
                 };
                 if (half == 1) QA_SUB_STAMP(10);
 #pragma unroll 1
-                for (int kc = kb; kc < ke; kc += 64) {
-                    if (kc + 32 < ke) step(std::integral_constant<int, 2>{}, kc);
-                    else step(std::integral_constant<int, 1>{}, kc);
+                for (int kc = kb; kc < ke; kc += 32) {      // (32-key steps here: with the other sub-tile's 96 accumulators live, a 64-key step spills)
+                    step(std::integral_constant<int, 1>{}, kc);
                     if (half == 1 && kc == kb) QA_SUB_STAMP(11);
                 }
                 if (half == 1) QA_SUB_STAMP(12);
