@@ -29,7 +29,10 @@ for name, cfg in (("zk", ZkConfig()), ("lds", LdsConfig()), ("lxmert", LxmertCon
         n = s.handle.counter(0)
         s.close()
         assert (n > 0) == (f > 0)
-    idx = np.sort(np.random.RandomState(5).choice(ps.n, 12, replace=False))
+    def vr0(a, c):
+        return np.linalg.norm(a - c, axis=1) / np.maximum(np.linalg.norm(c, axis=1), 1e-30)
+    worst = np.argsort(-vr0(out[2], out[0]))[:6]        # ... and the pairs that moved most: how far are THEY from the oracle?
+    idx = np.sort(np.unique(np.concatenate([np.random.RandomState(5).choice(ps.n, 12, replace=False), worst])))
     ti = torch.as_tensor(idx, device=dev)
     sub = {k: (v[ti].cpu().numpy() if torch.is_tensor(v) else (v[idx] if hasattr(v, "__len__") and len(v) == ps.n else v)) for k, v in b.items()}
     ref, _ = O.forward(cfg, w, sub, np.float64)
@@ -37,5 +40,9 @@ for name, cfg in (("zk", ZkConfig()), ("lds", LdsConfig()), ("lxmert", LxmertCon
     def vr(a, c):
         return np.linalg.norm(a - c, axis=1) / np.maximum(np.linalg.norm(c, axis=1), 1e-30)
     d1, d2 = vr(out[1], out[0]), vr(out[2], out[0])
-    print("%-6s %d pairs, full depth | fuse 1 vs two-kernel: max %.1e | fuse 2 vs two-kernel: median %.1e max %.1e | vs fp64 oracle (12 pairs): "
+    print("%-6s %d pairs, full depth | fuse 1 vs two-kernel: max %.1e | fuse 2 vs two-kernel: median %.1e max %.1e | vs fp64 oracle (12 random pairs + the 6 that moved most): "
           "two-kernel max %.1e, fuse 2 max %.1e" % (name, ps.n, d1.max(), np.median(d2), d2.max(), vr(out[0][idx], ref).max(), vr(out[2][idx], ref).max()), flush=True)
+    pos = np.searchsorted(idx, worst)
+    f = lambda a: " ".join("%.1e" % x for x in a)
+    print("       the 6 pairs that moved most: |logit| %s | fuse 2 vs two-kernel %s | two-kernel vs oracle %s | fuse 2 vs oracle %s" % (
+        " ".join("%.3f" % x for x in np.linalg.norm(out[0][worst], axis=1)), f(vr(out[2][worst], out[0][worst])), f(vr(out[0][worst], ref[pos])), f(vr(out[2][worst], ref[pos]))), flush=True)
