@@ -172,9 +172,9 @@ typedef struct mms_ensemble_batch {
 /* ABI revision of the structs and entry points declared in this header.  It changes whenever a struct gains a field or an entry
  * point changes its signature (r1: 1; r2 added mms_config.fuse_layernorm, mms_zk_batch.label_ids, mms_lxmert_batch.label_ids / x_norm
  * without bumping it; r3: 3, then 4 with mms_config.fuse_attention; r4: 5 -- mms_dbg_gemm takes the tile engine per call,
- * the process-global mms_set_gemm_variant and the lab engines' hooks left the product library, fuse_layernorm became a mask).  A caller built against another revision would make the library read past its structs, so compare
+ * the process-global mms_set_gemm_variant and the lab engines' hooks left the product library, fuse_layernorm became a mask; r5: 6 -- mms_dbg_qkv_attn added).  A caller built against another revision would make the library read past its structs, so compare
  * BEFORE the first mms_create:  if (mms_version() != MMS_ABI_VERSION) abort();   (lib.py's load() does) */
-#define MMS_ABI_VERSION 5
+#define MMS_ABI_VERSION 6
 int mms_version(void);
 const char* mms_global_error(void);              /* message of the last failing mms_create */
 
@@ -254,6 +254,14 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
                        int32_t variant, int32_t iters, float* ms_out);
 int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B, int32_t Sq, int32_t Sk,
                       const float* key_add, float* out_f32, void* stream);
+/* ONE fused QKV-projection + attention launch (qkv_attn.hip) on fp32 operands (all device pointers but n_sub_out): x [rows1 + rows2][768], the rows of stream 1
+ * first; a pair's tokens are consecutive rows of a stream -- off / cnt [n_pairs] per stream (first row relative to the stream, tokens), or NULL = dense, S tokens per
+ * pair; rows2 == 0: self-attention of stream 1, else CROSS attention: the queries of either stream attend the keys of the OTHER stream of their pair (lxmert X layers);
+ * w_qkv [2304][768] = [Wq; Wk; Wv] in torch Linear layout, bias_qkv [2304]; key_add: additive key mask by stream row or NULL; mode 1: exact-fp32 attention MFMAs
+ * (self-attention, pairs of <= 48 tokens), 2: the split-bf16 route (qkv_attn2_kernel).  ctx_f32 [rows1 + rows2][768]; *n_sub_out = sub-tiles the plan made */
+int mms_dbg_qkv_attn(const float* x, int64_t rows1, int64_t rows2, const int32_t* off1, const int32_t* cnt1, const int32_t* off2, const int32_t* cnt2,
+                     int64_t n_pairs, int32_t S1, int32_t S2, const float* w_qkv, const float* bias_qkv, const float* key_add1, const float* key_add2,
+                     int32_t mode, float* ctx_f32, int32_t* n_sub_out, void* stream);
 /* launch counters since mms_create: which = 0 -> fused QKV + attention launches (mms_config.fuse_attention took effect), 1 -> GEMM launches
  * with the fused LayerNorm epilogue (mms_config.fuse_layernorm), 2 -> split-K launches of the small-call routes, 3 -> skinny-GEMM launches (launches of <= 128
  * padded rows, precision modes 2 and 3); anything else: -1 */

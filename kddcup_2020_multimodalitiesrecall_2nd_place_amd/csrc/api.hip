@@ -2261,6 +2261,62 @@ int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B,
     return MMS_OK;
 }
 
+int mms_dbg_qkv_attn(const float* x, int64_t rows1, int64_t rows2, const int32_t* off1, const int32_t* cnt1, const int32_t* off2, const int32_t* cnt2,
+                     int64_t n_pairs, int32_t S1, int32_t S2, const float* w_qkv, const float* bias_qkv, const float* key_add1, const float* key_add2,
+                     int32_t mode, float* ctx_f32, int32_t* n_sub_out, void* stream) {
+    if (!x || !w_qkv || !bias_qkv || !ctx_f32 || rows1 <= 0 || rows2 < 0 || n_pairs <= 0 || S1 <= 0 || (rows2 > 0 && S2 <= 0) || (mode != 1 && mode != 2) ||
+        (off1 == nullptr) != (cnt1 == nullptr) || (off2 == nullptr) != (cnt2 == nullptr)) { g_err = "mms_dbg_qkv_attn: bad argument"; return MMS_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const bool cross = rows2 > 0;
+    const int64_t rows = rows1 + rows2;
+    bf16 *xp = nullptr, *cp = nullptr, *wt = nullptr;
+    float *whm = nullptr, *bhm = nullptr;
+    int4 *sub = nullptr, *sub2 = nullptr;
+    int *nsub = nullptr, *rec = nullptr, *scratch = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(xp); (void)hipFree(cp); (void)hipFree(wt); (void)hipFree(whm); (void)hipFree(bhm); (void)hipFree(sub); (void)hipFree(sub2);
+        (void)hipFree(nsub); (void)hipFree(rec); (void)hipFree(scratch);
+    };
+#define QA_TRY(expr) do { if ((expr) != hipSuccess) { cleanup(); return dbg_fail(#expr); } } while (0)
+    QA_TRY(hipMalloc((void**)&xp, (size_t)rows * H * 4));
+    QA_TRY(hipMalloc((void**)&cp, (size_t)rows * H * 4));
+    QA_TRY(hipMalloc((void**)&wt, (size_t)3 * H * H * 2));
+    QA_TRY(hipMalloc((void**)&whm, (size_t)3 * H * H * 4));
+    QA_TRY(hipMalloc((void**)&bhm, (size_t)3 * H * 4));
+    QA_TRY(hipMalloc((void**)&sub, (size_t)(n_pairs + 2) * sizeof(int4)));
+    QA_TRY(hipMalloc((void**)&sub2, (size_t)(n_pairs + 2) * sizeof(int4)));
+    QA_TRY(hipMalloc((void**)&nsub, 16));
+    QA_TRY(hipMalloc((void**)&rec, (size_t)(n_pairs + 2) * 4));
+    QA_TRY(hipMalloc((void**)&scratch, (size_t)qkv_plan_scratch_ints((int)n_pairs) * 4));
+    QA_TRY(hipMemsetAsync(cp, 0, (size_t)rows * H * 4, st));
+    launch_split_f32(x, xp, xp + MMS_PLANE_LO, rows * H, st);
+    // [Wq; Wk; Wv] (torch Linear rows) -> head-major [12][Q 64 | K 64 | V 64] rows, as load_att() builds it for the scorers
+    for (int hd = 0; hd < MMS_HEADS; ++hd)
+        for (int i = 0; i < 3; ++i) {
+            const size_t src = (size_t)i * H + (size_t)hd * MMS_HEAD_DIM, dst = ((size_t)hd * 3 + i) * MMS_HEAD_DIM;
+            QA_TRY(hipMemcpyAsync(whm + dst * H, w_qkv + src * H, (size_t)MMS_HEAD_DIM * H * 4, hipMemcpyDeviceToDevice, st));
+            QA_TRY(hipMemcpyAsync(bhm + dst, bias_qkv + src, (size_t)MMS_HEAD_DIM * 4, hipMemcpyDeviceToDevice, st));
+        }
+    launch_tile_weights(whm, wt, nullptr, 3 * H, H, st);
+    bool planned;
+    if (cross) planned = launch_qkv_cross_plan((const int*)off1, (const int*)cnt1, (const int*)off2, (const int*)cnt2, (int)n_pairs, S1, S2, sub, sub2, nsub, 2, st, rec, scratch);
+    else planned = launch_qkv_tile_plan((const int*)off1, (const int*)cnt1, (int)n_pairs, S1, sub, nsub, 2, st, rec, scratch);
+    if (!planned) { cleanup(); g_err = "mms_dbg_qkv_attn: too many pairs for one plan"; return MMS_ERR_ARG; }
+    QkvAttnParams q{};
+    q.a_hi = xp; q.lda = H; q.w = wt; q.bias = bhm; q.K = H;
+    q.sub = sub; q.n_sub = nsub; q.pair_rec = rec; q.pair_off = (const int*)off1; q.pair_cnt = (const int*)cnt1; q.S = S1;
+    q.key_add = key_add1; q.o_hi = cp; q.o_lo = cp + MMS_PLANE_LO; q.ldo = H; q.M = (int)rows1; q.fast = mode == 2;
+    if (cross) { q.sub2 = sub2; q.pair_off2 = (const int*)off2; q.pair_cnt2 = (const int*)cnt2; q.S2 = S2; q.key_add2 = key_add2; q.row0_b = rows1; q.M2 = (int)rows2; }
+    if (!launch_qkv_attn(q, st)) { cleanup(); g_err = "mms_dbg_qkv_attn: shape not supported by this route"; return MMS_ERR_ARG; }
+    launch_planes_to_f32(cp, cp + MMS_PLANE_LO, ctx_f32, rows * H, st);
+    QA_TRY(hipStreamSynchronize(st));
+    QA_TRY(hipGetLastError());
+    if (n_sub_out) QA_TRY(hipMemcpy(n_sub_out, nsub, 4, hipMemcpyDeviceToHost));
+#undef QA_TRY
+    cleanup();
+    return MMS_OK;
+}
+
 int mms_dbg_layernorm(const float* x, const float* gamma, const float* beta, int64_t M, float* out_f32, void* stream) {
     if (!x || !gamma || !beta || !out_f32 || M <= 0) { g_err = "mms_dbg_layernorm: bad argument"; return MMS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;

@@ -58,11 +58,11 @@ class EnsembleBatch(C.Structure):
                 ("lx_input_ids", C.c_void_p), ("lx_input_mask", C.c_void_p)]
 
 
-ABI_VERSION = 5     # include/mmscore.h MMS_ABI_VERSION
+ABI_VERSION = 6     # include/mmscore.h MMS_ABI_VERSION
 
 EXPORTS = ("mms_version", "mms_global_error", "mms_create", "mms_destroy", "mms_last_error", "mms_load_weight",
            "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_score_ensemble", "mms_gemm_timing", "mms_gemm_timing_class",
-           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_ln", "mms_dbg_proj_ln_splitk", "mms_dbg_attention", "mms_dbg_layernorm",
+           "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_ln", "mms_dbg_proj_ln_splitk", "mms_dbg_attention", "mms_dbg_qkv_attn", "mms_dbg_layernorm",
            "mms_dbg_gemm_bench", "mms_dbg_counter", "mms_fused_timing")
 LAB_EXPORTS = ("mms_dbg_gemm_mx", "mms_lab_ln_trace")      # libmmscore_lab.so only
 
@@ -109,6 +109,7 @@ def load(path=None):
     lib.mms_dbg_gemm.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.mms_dbg_attention.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     lib.mms_dbg_layernorm.argtypes = [vp, vp, vp, i64, vp, vp]
+    lib.mms_dbg_qkv_attn.argtypes = [vp, i64, i64, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, C.POINTER(i32), vp]
     lib.mms_dbg_counter.argtypes = [vp, i32]
     lib.mms_fused_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.mms_dbg_counter.restype = i64
