@@ -198,11 +198,18 @@ int mms_finalize(mms_handle* h);
  *                            kdd_conv2 / visn_fc / featureemb over the box rows): K in 8 slices
  *   rows <  8192             the N = 768 projections that a LayerNorm follows (attention output, FFN-down): K in 4 (K = 768) / 8 (K >= 2048) slices,
  *                            summed by the LayerNorm kernel
- *   rows <  16384            register-staged / LDS-DMA 128 x 256 tiles (bit-identical to each other), one pass over K; attention = the two-kernel route
- *   rows >= 16384            persistent ping-pong engines; mms_config.fuse_layernorm: bias + residual + LayerNorm in the GEMM epilogue (one-pass variance);
- *                            mms_config.fuse_attention: projection + attention in one kernel (2: split-bf16 attention arithmetic, online softmax)
+ *   rows >= 1024             mms_config.fuse_attention: a stream's QKV projection + attention in one kernel (qkv_attn.hip).  1: the two-kernel route's arithmetic, bit-identical
+ *                            to it.  2 (the scorers' default in precision mode 2): split-bf16 attention over 16-query tiles of a packed sub-tile, online softmax -- a pair's
+ *                            logits then depend on its place in the launch by fp32 round-off (<= 1e-4 relative), so calls of >= 1024 token rows are bit-identical across batch
+ *                            compositions only with fuse_attention <= 1
+ *   rows <  16384            register-staged / LDS-DMA 128 x 256 tiles (bit-identical to each other), one pass over K
+ *   rows >= 16384            persistent ping-pong engines; mms_config.fuse_layernorm: bias + residual + LayerNorm in the GEMM epilogue (one-pass variance) -- except in
+ *                            lxmert calls of fewer than 400 000 token rows (pairs x (text_len + 10); ~12 500 pairs), which run their two streams' launch chains side by
+ *                            side on two lanes and leave every LayerNorm to its own kernel (the fused epilogue needs its whole grid resident)
  * Batch composition enters in two more places: lxmert with pack_tokens runs its language layers once per DISTINCT query when at least half of the pairs
  * share theirs (the rows of that stage = distinct queries x text_len), and label texts are encoded once per distinct 8-id tuple (rows = tuples).
+ * lxmert's two launch lanes (a side stream between fork / join events: the vision stream's sub-layers beside the language stream's between two cross attentions, the
+ * distinct-query stage beside the box stream's layers) run the same kernels on the same operands: no numerical effect beyond the LayerNorm route named above.
  * Not numerical boundaries (same arithmetic, tested bit-identical): the LDS-DMA tile variant taken when a launch has no more workgroups than CUs, the
  * read-back-free label de-duplication of calls of <= 51 pairs, packed vs. dense token layout.
  * A call is ~110 (zk, lds) to ~220 (lxmert) dependent launches: 0.6 - 1.1 ms at 1 pair, so batch thousands of pairs per call when

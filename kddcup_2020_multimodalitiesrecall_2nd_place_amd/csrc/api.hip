@@ -100,6 +100,13 @@ struct mms_handle {
 
     static constexpr int LN_SLOTS = 2048;
     float* kparts = nullptr; int64_t kparts_floats = 0;    // fp32 partials of the split-K launches (small calls): slices x launch rows x N, sized with the workspace (ensure_kparts)
+    // Second launch lane (lxmert calls below LANE_ROWS token rows): the language and the vision stream's sub-layers between two cross attentions -- and the
+    // distinct-query stage beside the box stream's layers -- are independent chains of under-filled launches; the vision chain / the query stage is enqueued on `side`
+    // between a fork and a join event.  Same kernels on the same operands: results do not change.  lane == 1 while the side chain is being enqueued: its split-K partials
+    // and its FFN intermediate live in kparts_side / behind mid_side_off elements of `mid` (everything else a chain touches is addressed by its stream's row range).
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int lane = 0; bool lanes_on = false, lanes_q = false;      // lanes_on: the whole call (stream chains of the X layers, language beside box layers); lanes_q: the distinct-query stage only
+    float* kparts_side = nullptr; int64_t kparts_side_floats = 0; int64_t mid_side_off = 0, mid_elems = 0;
     int fuse_ln = 0;       // mms_config.fuse_layernorm (lab build: env MMS_FUSE_LN overrides)
     int fuse_attn = 0;     // mms_config.fuse_attention: QKV projection + self-attention in one kernel (qkv_attn.hip; precision mode 2)
     int* qa_rec[3] = {nullptr, nullptr, nullptr};      // per-pair records of the tables (split-bf16 attention route)
@@ -121,6 +128,9 @@ struct mms_handle {
     int *lq_slots = nullptr, *lq_rep = nullptr, *lq_uid = nullptr, *lq_counter = nullptr, *lq_rows_of = nullptr, *lq_index = nullptr;
     int lq_cap = 0;
     int64_t *lq_ids = nullptr, *lq_mask = nullptr;
+    int *lq_pk_off = nullptr, *lq_pk_cnt = nullptr, *lq_pk_src = nullptr; float* lq_key_add = nullptr;      // the stage's own packed plan (it may run beside a chunk's prologue: two lanes)
+    int4* lq_qa_sub = nullptr; int *lq_qa_rec = nullptr, *lq_qa_jump = nullptr;      // ... and its own sub-tile table (plan_tiles)
+    bool lq_join_pending = false;                      // the stage was enqueued on the side lane: lx_chunk joins before it reads lq_store
     Planes lq_store;
     bool lq_active = false;
     // fused three-model entry point: feed conversions and member outputs, sized for ens_pairs
@@ -470,6 +480,28 @@ int alloc_planes(mms_handle* h, std::vector<void*>& pool, Planes* p, int64_t ele
 
 int ensure_kparts(mms_handle* h, int64_t floats);
 int64_t kparts_need(const mms_handle* h, int64_t pairs, int64_t rows);
+// the lane-private buffers of the chain that is being enqueued (mms_handle::lane)
+inline float* kp(const mms_handle* h) { return h->lane ? h->kparts_side : h->kparts; }
+inline Planes midp(const mms_handle* h) { return h->lane ? h->mid.at(h->mid_side_off) : h->mid; }
+// lxmert calls whose chunk has fewer token rows (pairs x (text_len + 10), padded) than this run their independent launch chains on two lanes
+constexpr int64_t LANE_ROWS_DEFAULT = 400000;      // measured (profiles/rd5_lanes.txt): +27 % at 256 pairs, +30 % at 1024, +28 % at 2048, +13 % at 4096, +8.6 % at 8192, +3 % at 16384 (= the query stage alone), +0.7 % at 30000 (query stage alone: +2 %)
+int64_t lane_rows() {
+#ifdef MMS_LAB
+    static const int64_t v = getenv("MMS_LANE_ROWS") ? atoll(getenv("MMS_LANE_ROWS")) : LANE_ROWS_DEFAULT;      // A/B: 0 = one lane
+    return v;
+#else
+    return LANE_ROWS_DEFAULT;
+#endif
+}
+// ... and above that only the distinct-query stage runs on the side lane (beside the chunk's prologue and box-stream layers)
+bool lane_query_stage() {
+#ifdef MMS_LAB
+    static const bool v = !getenv("MMS_LANE_QUERY") || atoi(getenv("MMS_LANE_QUERY")) != 0;
+    return v;
+#else
+    return true;
+#endif
+}
 
 int ensure_workspace(mms_handle* h, int64_t pairs) {
     if (pairs <= h->ws_pairs) return MMS_OK;
@@ -482,7 +514,10 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     int64_t rows, mid_rows;
     if (c.model == MMS_MODEL_ZK) rows = mid_rows = pairs * (T + MMS_NBOX);
     else if (c.model == MMS_MODEL_LDS) rows = mid_rows = pairs * (T + 2 * MMS_NBOX);
-    else { rows = pairs * (T + MMS_NBOX); mid_rows = pairs * (T > MMS_NBOX ? T : MMS_NBOX); }
+    else {      // (two lanes: the language and the vision stream's FFN intermediates are live at once)
+        rows = pairs * (T + MMS_NBOX);
+        mid_rows = rows < lane_rows() ? rows : pairs * (T > MMS_NBOX ? T : MMS_NBOX);
+    }
     h->x_rows = rows / pairs;
     // mid also hosts the split 2048-d box features during the embedding stage
     int64_t mid_elems = mid_rows * c.inter;
@@ -493,6 +528,7 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     if (int rc = alloc_planes(h, h->ws_allocs, &h->ctx, rows * H)) return rc;
     if (int rc = alloc_planes(h, h->ws_allocs, &h->y, rows * H)) return rc;
     if (int rc = alloc_planes(h, h->ws_allocs, &h->mid, mid_elems)) return rc;
+    h->mid_elems = mid_elems;
     if (h->f8) {   // e4m3 copies of the GEMM A operands (x / y: LayerNorm outputs, ctx: attention output, mid: FFN intermediate)
         // + 256 rows: gemm_mx8_kernel fetches whole 256-row panels (rows past the live count are multiplied and discarded, never clamped)
         if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)(rows + 256) * H)) return rc;
@@ -544,6 +580,12 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)mms_handle::LN_SLOTS * 2 * 4)) return rc;
     h->ln_ctl = (int*)p;
     if (int rc = ensure_kparts(h, kparts_need(h, pairs, rows))) return rc;
+    if (c.model == MMS_MODEL_LXMERT && rows < lane_rows()) {
+        h->lane = 1;
+        const int rc = ensure_kparts(h, kparts_need(h, pairs, rows));
+        h->lane = 0;
+        if (rc) return rc;
+    }
     h->ws_pairs = pairs;
     return MMS_OK;
 }
@@ -612,6 +654,19 @@ int64_t tiny_rows() {
 #endif
 }
 #define TINY_ROWS tiny_rows()
+// padded row bound from which a stream's QKV projection + attention run as the fused kernel (qkv_attn.hip).  Rounds 3-4: 16384 (the persistent engines' bound); measured
+// this round (profiles/rd5_fused_rows.txt): 16 row tiles x 12 heads fill 192 CUs at 256 zk pairs, one launch of ~32 us where the 128 x 256 tile grid of the QKV projection
+// takes 47 (279 workgroups on 256 CUs: two rounds) and the attention kernel 16 -- zk 2.53 -> 2.34 ms at 256 pairs, lds 3.72 -> 3.38, lxmert 3.50 -> 3.28; down to 1024 rows
+// (= TINY_ROWS, where the wide projections' split-K route takes over) never slower
+constexpr int64_t FUSED_ATTN_ROWS_DEFAULT = 1024;
+int64_t fused_attn_rows() {
+#ifdef MMS_LAB
+    static const int64_t v = getenv("MMS_FUSED_ROWS") ? atoll(getenv("MMS_FUSED_ROWS")) : FUSED_ATTN_ROWS_DEFAULT;
+    return v;
+#else
+    return FUSED_ATTN_ROWS_DEFAULT;
+#endif
+}
 
 int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf16* w, const float* bias, int64_t M,
          int N, int K, int act, const GemmOut& out, const Planes* resid = nullptr, const int* m_dev = nullptr,
@@ -651,12 +706,12 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     if (tiny) {      // K slices into fp32 partials; the reduce kernel below applies what the epilogue would have
         if (int rc = ensure_kparts(h, TINY_S * part_stride)) return rc;      // (no-op: ensure_workspace sized it for every split launch of this workspace)
         (skinny_tall ? h->skinny_launches : h->splitk_launches) += 1;
-        p.bias = nullptr; p.act = ACT_NONE; p.out_kind = OUT_F32; p.c_f32 = h->kparts; p.ldc = N; p.hm_rows = 0; p.hm_col0 = 0;
+        p.bias = nullptr; p.act = ACT_NONE; p.out_kind = OUT_F32; p.c_f32 = kp(h); p.ldc = N; p.hm_rows = 0; p.hm_col0 = 0;
         p.k_splits = TINY_S; p.c_split_stride = part_stride;
         if (skinny_tall) p.variant = 55;
     }
     auto tiny_reduce = [&]() {
-        if (tiny) launch_splitk_reduce(h->kparts, TINY_S, part_stride, (int)M, N, m_dev, bias, act, out.f32, out.ldc, out.hm_rows, out.hm_col0,
+        if (tiny) launch_splitk_reduce(kp(h), TINY_S, part_stride, (int)M, N, m_dev, bias, act, out.f32, out.ldc, out.hm_rows, out.hm_col0,
                                        out.pl.hi, out.pl.lo, out.ldp, st);
     };
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
@@ -719,6 +774,9 @@ int gemm_ln(mms_handle* h, hipStream_t st, bool f8, const Planes& a, int lda, co
     *fused = false;
     // mms_config.fuse_layernorm is a mask: bit 0 the attention-output projections (K = 768), bit 1 the FFN-down projections (K = inter)
     if (!(h->fuse_ln & (K == H ? 1 : 2)) || f8 || M < 16384 || h->nsplit != 2 || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
+    // two launch lanes: the fused epilogue needs its whole grid resident (the column tiles of a row panel exchange statistics) and falls back to the LayerNorm
+    // kernel when it is not -- beside another lane's persistent kernel that would be decided by timing.  A call on two lanes takes the two-kernel route throughout.
+    if (h->lanes_on || h->lane || h->lq_join_pending) return MMS_OK;      // (lq_join_pending: the distinct-query stage is running on the side lane)
     if (K % 64 != 0) return MMS_OK;
     (void)w8; (void)wscale;          // the fp8 mode always takes the two-kernel route (f8 returned above)
     GemmParams p{};
@@ -799,12 +857,14 @@ int splitk_for(const mms_handle* h, int64_t M, int K) {
     const int S = K >= 2048 ? 8 : 4;
     return K % (64 * S) == 0 ? S : 1;
 }
-int ensure_kparts(mms_handle* h, int64_t floats) {
-    if (floats <= h->kparts_floats) return MMS_OK;
-    if (h->kparts) { (void)hipFree(h->kparts); h->kparts = nullptr; h->kparts_floats = 0; }      // (hipFree waits for the work that may still read it)
+int ensure_kparts(mms_handle* h, int64_t floats) {      // (of the lane that is being enqueued)
+    float*& buf = h->lane ? h->kparts_side : h->kparts;
+    int64_t& have = h->lane ? h->kparts_side_floats : h->kparts_floats;
+    if (floats <= have) return MMS_OK;
+    if (buf) { (void)hipFree(buf); buf = nullptr; have = 0; }      // (hipFree waits for the work that may still read it)
     void* p = nullptr;
     HIP_TRY(h, hipMalloc(&p, (size_t)floats * 4));
-    h->kparts = (float*)p; h->kparts_floats = floats;
+    buf = (float*)p; have = floats;
     return MMS_OK;
 }
 // Partials of every split-K launch a workspace of `pairs` pairs can issue (sized here, with the workspace, so that a scoring call on a warmed-up
@@ -838,7 +898,7 @@ int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap
                 if (w >= wp.base && w < wp.base + wp.elems) { p.w_lo = w + wp.elems; break; }
             if (!p.w_lo) return h->fail(MMS_ERR_STATE, "proj_ln: weight has no lo plane");
         }
-        p.out_kind = OUT_F32; p.c_f32 = h->kparts; p.ldc = H; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
+        p.out_kind = OUT_F32; p.c_f32 = kp(h); p.ldc = H; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
         p.k_splits = S; p.c_split_stride = (long long)M * H;
         p.m_dev = m_dev;
         if (skinny) p.variant = 55;      // gemm_skinny.hip, K slices dealt to workgroups (same partials as the tile engine's: bit-identical)
@@ -856,7 +916,7 @@ int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap
         r.hi = resid.hi; r.lo = resid.lo; r.ld = H; r.rmap = rmap; r.r_index = r_index;
         r.nparts = S; r.part_stride = p.c_split_stride; r.bias = bias;
         r.o_f8 = out.f8;
-        launch_ln_to_planes(h->kparts, H, g, b, out.hi, out.lo, H, (int)M, st, m_dev, r);
+        launch_ln_to_planes(kp(h), H, g, b, out.hi, out.lo, H, (int)M, st, m_dev, r);
         return MMS_OK;
     }
     if (int rc = gemm(h, st, a, lda, amap, w, bias, M, H, K, ACT_NONE, to_f32(t, H), &resid, m_dev, a_index, rmap, r_index, cls_bit,
@@ -873,18 +933,23 @@ struct Pack { const int* off = nullptr; const int* cnt = nullptr; const int* row
               const int* rec = nullptr; };                               // per-pair records of the table
 
 // sub-tile table of one token stream (n pairs of at most S tokens; packed or dense) for qkv_attn.hip, in table slot `slot`
-void plan_tiles(mms_handle* h, hipStream_t st, Pack& pk, int64_t n, int S, int slot) {
+void plan_tiles(mms_handle* h, hipStream_t st, Pack& pk, int64_t n, int S, int slot, bool query_stage = false) {
     if (!h->fuse_attn || (h->nsplit != 2 && h->nsplit != 3) || h->f8 || S > 48) return;
-    // att_block() takes the fused kernel only for launches of >= 16384 rows (the plan is 68 us: 2.4 % of a 256-pair call); the exact-fp32 attention route
-    // (fuse_attention = 1: one work item per pair and 16-query tile) only for pairs of >= 16 tokens -- the split-bf16 route works on 16-row tiles of the sub-tile
-    // whatever the pairs' lengths (lxmert's 10-token box stream included)
-    if (n * S < 16384 || (S < 16 && h->fuse_attn != 2)) return;
+    // att_block() takes the fused kernel for launches of >= FUSED_ATTN_ROWS (1024) padded rows (below, the wide split-K route + the attention kernel are faster; the plan
+    // is ~20 us per call); the exact-fp32 attention route (fuse_attention = 1: one work item per pair and 16-query tile) only for pairs of >= 16 tokens -- the split-bf16
+    // route works on 16-row tiles of the sub-tile whatever the pairs' lengths (lxmert's 10-token box stream included)
+    if (n * S < fused_attn_rows() || (S < 16 && h->fuse_attn != 2)) return;
+    if (query_stage) {      // lxmert's distinct-query stage has its own table and scratch: it may be planned on the side lane while the chunk's tables are
+        if (!h->lq_qa_sub || !launch_qkv_tile_plan(pk.off, pk.cnt, (int)n, S, h->lq_qa_sub, h->qa_nsub + 3, h->nsplit, st, h->lq_qa_rec, h->lq_qa_jump)) return;
+        pk.sub = h->lq_qa_sub; pk.n_sub = h->qa_nsub + 3; pk.rec = h->lq_qa_rec;
+        return;
+    }
     if (!launch_qkv_tile_plan(pk.off, pk.cnt, (int)n, S, h->qa_sub[slot], h->qa_nsub + slot, h->nsplit, st, h->qa_rec[slot], h->qa_jump)) return;
     pk.sub = h->qa_sub[slot]; pk.n_sub = h->qa_nsub + slot; pk.rec = h->qa_rec[slot];
 }
 // ... of a PAIR of streams for the fused cross-attention launches of lxmert's X layers (fuse_attention = 2): a sub-tile = the rows of its pairs in both streams
 void plan_cross_tiles(mms_handle* h, hipStream_t st, Pack& px, const Pack& p1, const Pack& p2, int64_t n, int S1, int S2) {
-    if (h->fuse_attn != 2 || (h->nsplit != 2 && h->nsplit != 3) || h->f8 || !h->qa_sub[2] || n * (S1 + S2) < 16384) return;
+    if (h->fuse_attn != 2 || (h->nsplit != 2 && h->nsplit != 3) || h->f8 || !h->qa_sub[2] || n * (S1 + S2) < fused_attn_rows()) return;
     if (!launch_qkv_cross_plan(p1.off, p1.cnt, p2.off, p2.cnt, (int)n, S1, S2, h->qa_sub[2], h->qa_sub[3], h->qa_nsub + 2, h->nsplit, st, h->qa_rec[2], h->qa_jump)) return;
     px.sub = h->qa_sub[2]; px.sub2 = h->qa_sub[3]; px.n_sub = h->qa_nsub + 2; px.rec = h->qa_rec[2];
 }
@@ -918,10 +983,10 @@ int att_block(mms_handle* h, hipStream_t st, const AttW& w, Planes in, Planes ou
               const float* key_add, const Pack& pk = Pack()) {
     const int64_t M = B * S;
     const bool f8 = h->f8 && in.f8;
-    // one kernel for projection + attention (qkv_attn.hip) when the launch is big enough for a persistent grid and runs two-pass bf16
+    // one kernel for projection + attention (qkv_attn.hip) from FUSED_ATTN_ROWS padded rows on, in two- or three-pass bf16
     // (streams of very short pairs -- lxmert's 10 box tokens -- stay on the two-kernel route: a dozen attention items per sub-tile make the
     // fused epilogue cost more than the attention launch it replaces, profiles/r03q_*)
-    const bool fused_attn = pk.sub && w.wqkv_hm && !f8 && M >= 16384 && (S >= 16 || h->fuse_attn == 2) && ((h->nsplit == 2 && !(h->x1_mask & 1)) || h->nsplit == 3);
+    const bool fused_attn = pk.sub && w.wqkv_hm && !f8 && M >= fused_attn_rows() && (S >= 16 || h->fuse_attn == 2) && ((h->nsplit == 2 && !(h->x1_mask & 1)) || h->nsplit == 3);
     if (fused_attn) {
         QkvAttnParams q{};
         const Planes a_in = in.at(row0 * H), c_out = h->ctx.at(row0 * H);
@@ -1003,10 +1068,11 @@ int ffn_block(mms_handle* h, hipStream_t st, const FfnW& w, Planes in, Planes ou
         return MMS_OK;
     }
 #endif
-    if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(h->mid, I), nullptr, pk.rows, nullptr, ID, nullptr, 4)) return rc;
-    if (int rc = gemm_ln(h, st, false, h->mid, I, w.wd, w.wd8, w.wds, w.bd, M, I, resid, w.g, w.b, out.at(row0 * H), h->t + row0 * H, pk.rows, &fused)) return rc;
+    const Planes mid = midp(h);
+    if (int rc = gemm(h, st, in.at(row0 * H), H, ID, w.wi, w.bi, M, I, H, act, to_planes(mid, I), nullptr, pk.rows, nullptr, ID, nullptr, 4)) return rc;
+    if (int rc = gemm_ln(h, st, false, mid, I, w.wd, w.wd8, w.wds, w.bd, M, I, resid, w.g, w.b, out.at(row0 * H), h->t + row0 * H, pk.rows, &fused)) return rc;
     if (fused) return MMS_OK;
-    return proj_ln(h, st, h->mid, I, ID, nullptr, w.wd, w.bd, M, I, resid, ID, nullptr, w.g, w.b, out.at(row0 * H), h->t + row0 * H, pk.rows, 8);
+    return proj_ln(h, st, mid, I, ID, nullptr, w.wd, w.bd, M, I, resid, ID, nullptr, w.g, w.b, out.at(row0 * H), h->t + row0 * H, pk.rows, 8);
 }
 
 // Last self-attention + FFN block before the pooler: only the CLS row feeds the pooler (pixelbert.py:258-266,
@@ -1277,9 +1343,37 @@ int lx_label_features(mms_handle* h, hipStream_t st, const int64_t* uniq_ids, in
 // rows are found on the device (batchops.hip), embedded and run through the l_layers ONCE, stored dense by (query, token), and
 // lx_chunk copies each pair's live language rows from the store.  Per-row arithmetic is unchanged (same kernels, same weights).
 // Skipped (lq_active = false -> the per-pair path) when fewer than half of the pairs share their query with another pair.
+// two launch lanes (mms_handle::side): fork = the side stream waits for everything enqueued on st so far; join = st waits for the side chain
+int lanes_init(mms_handle* h) {
+    if (h->side) return MMS_OK;
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    return MMS_OK;
+}
+int lane_fork(mms_handle* h, hipStream_t st) {
+    HIP_TRY(h, hipEventRecord(h->ev_fork, st));
+    HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    return MMS_OK;
+}
+int lane_join(mms_handle* h, hipStream_t st) {
+    HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
+    HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    return MMS_OK;
+}
+// enqueues `chain` on the side lane with the lane-private buffers selected
+template <class F>
+int on_side_lane(mms_handle* h, F&& chain) {
+    h->lane = 1;
+    const int rc = chain(h->side);
+    h->lane = 0;
+    return rc;
+}
+
 int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t B, int cs) {
     const mms_config& c = h->cfg;
     h->lq_active = false;
+    h->lq_join_pending = false;
     if (!c.pack_tokens || c.stop_after >= 0 || c.layers <= 0 || B < 2) return MMS_OK;
     const int T = c.text_len;
     if (B > h->lq_pairs) {
@@ -1320,27 +1414,64 @@ int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int
         h->lq_ids = (int64_t*)p;
         if (int rc = dev_alloc(h, h->lq_sub_allocs, &p, (size_t)cs * T * 8)) return rc;
         h->lq_mask = (int64_t*)p;
+        if (int rc = dev_alloc(h, h->lq_sub_allocs, &p, (size_t)cs * 4)) return rc;
+        h->lq_pk_off = (int*)p;
+        if (int rc = dev_alloc(h, h->lq_sub_allocs, &p, (size_t)cs * 4)) return rc;
+        h->lq_pk_cnt = (int*)p;
+        if (int rc = dev_alloc(h, h->lq_sub_allocs, &p, (size_t)cs * T * 4)) return rc;
+        h->lq_pk_src = (int*)p;
+        if (int rc = dev_alloc(h, h->lq_sub_allocs, &p, (size_t)cs * T * 4)) return rc;
+        h->lq_key_add = (float*)p;
+        if (int rc = dev_alloc(h, h->lq_sub_allocs, &p, (size_t)(cs + 2) * sizeof(int4))) return rc;
+        h->lq_qa_sub = (int4*)p;
+        if (int rc = dev_alloc(h, h->lq_sub_allocs, &p, (size_t)(cs + 2) * 4)) return rc;
+        h->lq_qa_rec = (int*)p;
+        if (int rc = dev_alloc(h, h->lq_sub_allocs, &p, (size_t)qkv_plan_scratch_ints(cs) * 4)) return rc;
+        h->lq_qa_jump = (int*)p;
         h->lq_sub = cs;
     }
-    for (int64_t u0 = 0; u0 < Q; u0 += cs) {
+    // One chunk, one sub-batch, a small call (two lanes): the stage runs on the side lane beside the chunk's box-stream prologue and r_layers (lx_chunk joins
+    // before it copies the language rows out of lq_store).  The stage's rows [0, Q T) of x / y / ctx / qkv / t lie inside the chunk's language rows, which the
+    // chunk does not touch before the join; the plan scratch is shared, so a stage big enough for the fused attention kernel's table stays on the main lane.
+    const int64_t R = B * (T + MMS_NBOX);
+    // (mid: the main lane needs the box rows' share until the join -- split features, then the r_layers' FFN intermediate -- and the stage's rows follow it)
+    const bool side = h->lanes_q && B <= cs && Q <= cs && (B * MMS_NBOX + Q * T) * (int64_t)c.inter <= h->mid_elems;
+    hipStream_t qs = st;
+    if (side) {
+        if (int rc = lanes_init(h)) return rc;
+        h->lane = 1;
+        const int rc = ensure_kparts(h, kparts_need(h, B, R));
+        h->lane = 0;
+        if (rc) return rc;
+        h->mid_side_off = B * MMS_NBOX * (int64_t)c.inter;
+        if (int rc2 = lane_fork(h, st)) return rc2;
+        qs = h->side;
+        h->lane = 1;
+    }
+    int* const q_rows = h->pk_rows + 2;
+    int rc_stage = MMS_OK;
+    for (int64_t u0 = 0; u0 < Q && !rc_stage; u0 += cs) {
         const int64_t n = (Q - u0) < cs ? (Q - u0) : cs;
-        launch_gather_i64_rows(b->input_ids, h->lq_rows_of + u0, T, n, h->lq_ids, st);
-        launch_gather_i64_rows(b->input_mask, h->lq_rows_of + u0, T, n, h->lq_mask, st);
-        launch_lx_pack_plan(h->lq_mask, nullptr, T, (int)n, h->pk_off[0], h->pk_cnt[0], h->pk_src[0], h->key_add, h->pk_rows, nullptr, nullptr,
-                            nullptr, nullptr, nullptr, st);
+        launch_gather_i64_rows(b->input_ids, h->lq_rows_of + u0, T, n, h->lq_ids, qs);
+        launch_gather_i64_rows(b->input_mask, h->lq_rows_of + u0, T, n, h->lq_mask, qs);
+        launch_lx_pack_plan(h->lq_mask, nullptr, T, (int)n, h->lq_pk_off, h->lq_pk_cnt, h->lq_pk_src, h->lq_key_add, q_rows, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, qs);
         Pack pl;
-        pl.off = h->pk_off[0]; pl.cnt = h->pk_cnt[0]; pl.rows = h->pk_rows;
-        launch_lx_embed_lang_packed(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, h->lq_ids, T, c.vocab, h->pk_src[0], h->pk_rows,
-                                    (int)(n * T), h->x.hi, h->x.lo, st);
-        plan_tiles(h, st, pl, n, T, 0);
-        if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, n * T * H, st);
-        for (int i = 0; i < c.layers; ++i) {
-            if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, T, n, h->key_add, pl)) return rc;
-            if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, n * T, ACT_GELU_ERF, pl)) return rc;
+        pl.off = h->lq_pk_off; pl.cnt = h->lq_pk_cnt; pl.rows = q_rows;
+        launch_lx_embed_lang_packed(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, h->lq_ids, T, c.vocab, h->lq_pk_src, q_rows,
+                                    (int)(n * T), h->x.hi, h->x.lo, qs);
+        plan_tiles(h, qs, pl, n, T, 0, true);
+        if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, n * T * H, qs);
+        for (int i = 0; i < c.layers && !rc_stage; ++i) {
+            rc_stage = att_block(h, qs, h->layers[i].att, h->x, h->y, 0, T, n, h->lq_key_add, pl);
+            if (!rc_stage) rc_stage = ffn_block(h, qs, h->layers[i].ffn, h->y, h->x, 0, n * T, ACT_GELU_ERF, pl);
         }
         // packed row r holds token pk_src[r] = u_local * T + t  ->  store row (u0 + u_local) * T + t
-        launch_rows_scatter(h->x.hi, h->x.lo, h->pk_src[0], h->pk_rows, (int)(n * T), h->lq_store.at(u0 * T * H).hi, h->lq_store.at(u0 * T * H).lo, st);
+        launch_rows_scatter(h->x.hi, h->x.lo, h->lq_pk_src, q_rows, (int)(n * T), h->lq_store.at(u0 * T * H).hi, h->lq_store.at(u0 * T * H).lo, qs);
     }
+    h->lane = 0;
+    if (side) h->lq_join_pending = true;
+    if (rc_stage) return rc_stage;
     h->lq_active = true;
     return MMS_OK;
 }
@@ -1355,7 +1486,7 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
     float* visn_add = h->key_add2;
     Pack pl, pv;
     Planes featp = h->mid;
-    float* xf = h->qkv;
+    float* xf = h->lq_join_pending ? h->t + ML * H : h->qkv;      // (the distinct-query stage on the side lane owns the first rows of qkv until the join)
     // packed single-model path: the vision plan comes first and visn_fc runs on the LIVE boxes only (features split by gather, projection with the
     // device-side row count): the masked boxes -- 62 % of the rows on the bench batch -- cannot reach a logit
     bool compact = c.pack_tokens && !featp_shared;
@@ -1373,7 +1504,8 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
     else launch_split_f32(b->feats + p0 * V * MMS_FEAT, featp.hi, featp.lo, MV * MMS_FEAT, st);
     if (int rc = gemm(h, st, featp, MMS_FEAT, ID, h->w_visn, h->b_visn, MV, H, MMS_FEAT, ACT_NONE, to_f32(xf, H), nullptr, compact ? h->pk_rows + 1 : nullptr)) return rc;
     if (c.pack_tokens) {
-        if (h->lq_active)   // language rows after the l_layers, copied from the distinct-query store (pair p0 + src / T, token src % T)
+        if (h->lq_join_pending) {}      // (the distinct-query stage is still running on the side lane: the copy follows the join, behind the r_layers)
+        else if (h->lq_active)   // language rows after the l_layers, copied from the distinct-query store (pair p0 + src / T, token src % T)
             launch_rows_gather(h->lq_store.hi, h->lq_store.lo, h->pk_src[0], h->lq_index + p0, T, h->pk_rows, (int)ML, h->x.hi, h->x.lo, st);
         else
             launch_lx_embed_lang_packed(h->E, h->pos_tab, h->type_tab, h->emb_g, h->emb_b, b->input_ids + p0 * T, T, c.vocab, h->pk_src[0],
@@ -1392,13 +1524,37 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
     if (c.x_layers > 1 || (c.x_layers > 0 && c.stop_after >= 0)) plan_cross_tiles(h, st, px, pl, pv, n, T, V);      // (the last X layer of a full run is trimmed to what the pooler reads: two-kernel route)
     if (h->f8) launch_planes_to_f8(h->x.hi, h->x.lo, h->x.f8, R * H, st);
     int budget = c.stop_after >= 0 ? c.stop_after : (1 << 30);
+    // small calls: two lanes (see mms_handle::side).  Not with a layer budget (debug runs count layers in stream order) and not in precision mode 4.
+    const bool lanes = h->lanes_on && R * (int64_t)c.inter <= h->mid_elems;
+    if (lanes) {
+        if (int rc = lanes_init(h)) return rc;
+        h->lane = 1;
+        const int rc = ensure_kparts(h, kparts_need(h, n, R));      // (sized with the workspace unless a larger call sized that first)
+        h->lane = 0;
+        if (rc) return rc;
+        h->mid_side_off = ML * (int64_t)c.inter;
+    }
+    auto r_stage = [&](hipStream_t s) -> int {
+        for (int i = 0; i < c.r_layers && budget > 0; ++i, --budget) {
+            if (int rc = att_block(h, s, h->r_layers[i].att, h->x, h->y, ML, V, n, visn_add, pv)) return rc;
+            if (int rc = ffn_block(h, s, h->r_layers[i].ffn, h->y, h->x, ML, MV, ACT_GELU_ERF, pv)) return rc;
+        }
+        return MMS_OK;
+    };
+    const bool lr_lanes = lanes && !h->lq_active && c.layers > 0 && c.r_layers > 0;      // language layers beside the box stream's layers
+    if (lr_lanes) { if (int rc = lane_fork(h, st)) return rc; }
     for (int i = 0; i < c.layers && budget > 0 && !h->lq_active; ++i, --budget) {
         if (int rc = att_block(h, st, h->layers[i].att, h->x, h->y, 0, T, n, lang_add, pl)) return rc;
         if (int rc = ffn_block(h, st, h->layers[i].ffn, h->y, h->x, 0, ML, ACT_GELU_ERF, pl)) return rc;
     }
-    for (int i = 0; i < c.r_layers && budget > 0; ++i, --budget) {
-        if (int rc = att_block(h, st, h->r_layers[i].att, h->x, h->y, ML, V, n, visn_add, pv)) return rc;
-        if (int rc = ffn_block(h, st, h->r_layers[i].ffn, h->y, h->x, ML, MV, ACT_GELU_ERF, pv)) return rc;
+    if (lr_lanes) {
+        if (int rc = on_side_lane(h, r_stage)) return rc;
+        if (int rc = lane_join(h, st)) return rc;
+    } else if (int rc = r_stage(st)) return rc;
+    if (h->lq_join_pending) {      // the distinct-query stage ran beside the prologue and the r_layers above
+        if (int rc = lane_join(h, st)) return rc;
+        h->lq_join_pending = false;
+        launch_rows_gather(h->lq_store.hi, h->lq_store.lo, h->pk_src[0], h->lq_index + p0, T, h->pk_rows, (int)ML, h->x.hi, h->x.lo, st);
     }
     const bool trim_last = c.stop_after < 0 && c.x_layers > 0;   // debug runs keep the full hidden state
     for (int i = 0; i < c.x_layers && budget > 0; ++i, --budget) {
@@ -1459,6 +1615,23 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
         a.o_hi = h->ctx.at(ML * H).hi; a.o_lo = h->ctx.at(ML * H).lo;
         a.q_off = pv.off; a.q_cnt = pv.cnt; a.kv_off = pl.off; a.kv_cnt = pl.cnt;
         if (int rc = attend(h, a, st)) return rc;
+        }
+        if (lanes) {
+            // the two streams' chains up to the next cross attention (attention output + LayerNorm, self-attention block, FFN block), side by side
+            if (int rc = lane_fork(h, st)) return rc;
+            if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
+            ln_resid(h, st, h->t, w.cross.g, w.cross.b, h->y, ML, pl.rows, h->x);
+            if (int rc = att_block(h, st, w.lang_self, h->y, h->x, 0, T, n, lang_add, pl)) return rc;
+            if (int rc = ffn_block(h, st, w.lang_ffn, h->x, h->x, 0, ML, ACT_GELU_ERF, pl)) return rc;
+            if (int rc = on_side_lane(h, [&](hipStream_t s) -> int {
+                    const Planes rv = h->x.at(ML * H);
+                    if (int rc = gemm(h, s, h->ctx.at(ML * H), H, ID, w.cross.wo, w.cross.bo, MV, H, H, ACT_NONE, to_f32(h->t + ML * H, H), &rv, pv.rows)) return rc;
+                    ln_resid(h, s, h->t + ML * H, w.cross.g, w.cross.b, h->y.at(ML * H), MV, pv.rows, rv);
+                    if (int rc = att_block(h, s, w.visn_self, h->y, h->x, ML, V, n, visn_add, pv)) return rc;
+                    return ffn_block(h, s, w.visn_ffn, h->x, h->x, ML, MV, ACT_GELU_ERF, pv);
+                })) return rc;
+            if (int rc = lane_join(h, st)) return rc;
+            continue;
         }
         if (c.pack_tokens) {
             // per stream: the fused bias + residual + LayerNorm epilogue on big launches (mms_config.fuse_layernorm bit 0), else GEMM -> LayerNorm kernel
@@ -1571,6 +1744,10 @@ void mms_destroy(mms_handle* h) {
     free_pool(h->lq_sub_allocs);
     if (h->lq_store.hi) (void)hipFree(h->lq_store.hi);
     if (h->kparts) (void)hipFree(h->kparts);
+    if (h->kparts_side) (void)hipFree(h->kparts_side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     for (auto e : h->ev_fused) (void)hipEventDestroy(e);
     delete h;
@@ -1672,6 +1849,10 @@ int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, fl
         uniq = h->dd_uniq64; index = h->dd_index;
     }
     if (int rc = ln_begin_call(h, st)) return rc;
+    // two launch lanes (mms_handle::side) for calls whose launch wave has fewer than LANE_ROWS token rows; not for debug runs (they count layers in stream
+    // order), precision mode 4 or per-launch timing
+    h->lanes_q = h->cfg.pack_tokens && h->cfg.stop_after < 0 && !h->f8 && !h->timing && lane_rows() > 0 && lane_query_stage();
+    h->lanes_on = h->lanes_q && (int64_t)cs * (h->cfg.text_len + MMS_NBOX) < lane_rows();
     if (int rc = lx_label_features(h, st, uniq, U)) return rc;
     if (int rc = lx_query_stage(h, st, b, B, cs)) return rc;
     for (int64_t p0 = 0; p0 < B; p0 += cs)
@@ -1761,6 +1942,10 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
     mms_lxmert_batch xb{};
     xb.n_pairs = B; xb.input_ids = lx_ids; xb.input_mask = lx_mask; xb.feats = b->feats; xb.boxes = z->ens_boxes4;
     xb.visual_attention_mask = z->ens_vmask;
+    // two lanes inside the lxmert member's chunks as in mms_score_lxmert, but its distinct-query stage stays on the main lane: on the side lane it would run beside the
+    // other members' launches, whose fused LayerNorm epilogues need their whole grid resident (gemm_ln)
+    x->lanes_q = false;
+    x->lanes_on = x->cfg.pack_tokens && !x->f8 && !x->timing && (int64_t)cs * (TL + MMS_NBOX) < lane_rows();
     if (int rc = lx_query_stage(x, st, &xb, B, cs)) return z->fail(rc, "lxmert member: " + x->err);
     float* lg[4]; float* pr[4];
     for (int k = 0; k < 4; ++k) { lg[k] = z->ens_logits + (int64_t)k * B * 2; pr[k] = z->ens_probs + (int64_t)k * B * 2; }

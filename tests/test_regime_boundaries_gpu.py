@@ -1,6 +1,6 @@
 """GPU suite, round 4: the launch-size regimes of api.hip meet at fixed PADDED row counts (pairs x tokens per pair) -- 128 (skinny kernel), 1024 (wide projections split over K with
 k_splitk_reduce), 4096 (long-K projections in front of the encoder), 8192 (split-K N = 768 projections summed in the LayerNorm kernel), 16 384 (persistent
-ping-pong engines, fused QKV + attention, LayerNorm in the GEMM epilogue).  The same pairs scored in ONE call of a size one pair below / at each bound must give the
+ping-pong engines, LayerNorm in the GEMM epilogue; the fused QKV + attention kernel starts at 1024).  The same pairs scored in ONE call of a size one pair below / at each bound must give the
 same scores up to fp32 round-off of a different summation order, packed and dense, with a ragged last wave -- a partial-buffer, row-bound or off-by-one slip
 at a boundary shows up as garbage in some pairs, not as round-off."""
 import numpy as np
@@ -44,7 +44,8 @@ def test_calls_just_below_and_at_every_regime_bound_agree(name, pack):
         assert got.shape == (c, 2) and np.isfinite(got).all(), (name, pack, c)
         e = np.linalg.norm(got - base[:c], axis=1) / floor[:c]
         worst[c] = float(e.max())
-        assert e.max() < 5e-4 and np.median(e) < 3e-5, (name, pack, c, float(e.max()), float(np.median(e)), int(np.argmax(e)))
+        # (the baseline's 48-pair waves attend on the split-bf16 route -- >= 1024 token rows -- the smallest calls on the exact one: the median of 3 .. 7 pairs is not a median)
+        assert e.max() < 5e-4 and np.median(e) < (3e-5 if c >= 16 else 6e-5), (name, pack, c, float(e.max()), float(np.median(e)), int(np.argmax(e)))
     # ... and the whole set in equal waves with a ragged tail (1117 pairs in waves of <= 500: three of 373 / 372)
     got = run(b, 500)
     e = np.linalg.norm(got - base, axis=1) / floor
