@@ -773,7 +773,7 @@ int gemm_ln(mms_handle* h, hipStream_t st, bool f8, const Planes& a, int lda, co
             const int* m_dev, bool* fused) {
     *fused = false;
     // mms_config.fuse_layernorm is a mask: bit 0 the attention-output projections (K = 768), bit 1 the FFN-down projections (K = inter)
-    if (!(h->fuse_ln & (K == H ? 1 : 2)) || f8 || M < 16384 || h->nsplit != 2 || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
+    if (!(h->fuse_ln & (K == H ? 1 : 2)) || f8 || M < pp_rows() || h->nsplit != 2 || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
     // two launch lanes: the fused epilogue needs its whole grid resident (the column tiles of a row panel exchange statistics) and falls back to the LayerNorm
     // kernel when it is not -- beside another lane's persistent kernel that would be decided by timing.  A call on two lanes takes the two-kernel route throughout.
     if (h->lanes_on || h->lane || h->lq_join_pending) return MMS_OK;      // (lq_join_pending: the distinct-query stage is running on the side lane)

@@ -27,6 +27,15 @@ int device_cu_count() {
     return v;
 }
 
+int pp_rows() {
+#ifdef MMS_LAB
+    static const int v = getenv("MMS_PP_ROWS") ? atoi(getenv("MMS_PP_ROWS")) : 16384;
+    return v;
+#else
+    return 16384;
+#endif
+}
+
 // false: no engine took the launch (nothing was enqueued) -- the caller turns that into MMS_ERR_ARG instead of letting the next kernel read an unwritten buffer
 bool launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return true;
@@ -42,7 +51,7 @@ bool launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
         }
         if (variant == 55 && launch_gemm_skinny_parts(p, 3, st)) return true;
         if (variant == 54 || variant == 58) { GemmParams q = p; q.k_splits = variant - 50; if (launch_gemm_skinny(q, 3, st)) return true; }
-        if ((variant == 27 || (variant == 99 && p.M >= 16384)) && launch_gemm_ppw(p, st)) return true;
+        if ((variant == 27 || (variant == 99 && p.M >= pp_rows())) && launch_gemm_ppw(p, st)) return true;
         return launch_gemm_tile(p, 3, 1, st);
     }
 #ifdef MMS_LAB
@@ -59,7 +68,7 @@ bool launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     ) variant = 99;
     if (variant == 99) {  // auto (profiles/r01c_gemm_variants.txt): 256x256 ping-pong phases for large M; for the small GEMMs
                           // (CLS-only last block, poolers) 256x256 / 16 waves on wide outputs, 128x256 / 8 waves otherwise
-        if (p.N % 256 == 0 && p.M >= 16384) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)
+        if (p.N % 256 == 0 && p.M >= pp_rows()) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)
         else variant = 4;   // (rounds 1-3 sent wide outputs at M >= 8192 to the 256x256 / 16-wave tile: 82 .. 95 us per launch on lds' 256-pair calls, the 128x256 tile is faster there)
         // ... and when even the PADDED row bound gives no more workgroups than the chip has CUs (calls of up to ~50 .. 120 pairs): the same tile with LDS-DMA
         // double buffering (no VGPR round trip, one barrier per K step; 128 KiB of LDS, so one workgroup per CU -- which is all such a launch has anyway):

@@ -57,6 +57,8 @@ struct GemmParams {
 };
 // CUs of the CURRENT device rounded down to a multiple of 8 (one per XCD-slot), cached per device ordinal; thread-safe (gemm_dispatch.hip)
 int device_cu_count();
+// padded row bound from which the persistent ping-pong engines (and the fused LayerNorm epilogue) take a launch (gemm_dispatch.hip)
+int pp_rows();
 bool launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);      // false: no engine took the shape, nothing was launched
 bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
 bool launch_gemm_skinny_parts(const GemmParams& p, int nsplit, hipStream_t st);        // ... with the K slices dealt to workgroups: k_splits fp32 partials, c_split_stride apart (variant 55; the LayerNorm kernel sums them)

@@ -16,19 +16,21 @@ from kddcup_2020_multimodalitiesrecall_2nd_place_amd import scorers, synth, weig
 
 name = sys.argv[1] if len(sys.argv) > 1 else "zk"
 NS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+TOTAL = int(sys.argv[3]) if len(sys.argv) > 3 else 30000      # pairs per step over all streams (mid-size calls: e.g. 256)
 cfg = bench.CFGS[name]()
 dev = torch.device("cuda", 0)
 w = weights.make_weights(cfg)
 sc, feed, streams = [], [], []
 for i in range(NS):
     s = scorers.make_scorer(cfg, w, device=0)
-    ps = synth.make_pairs(1000 // NS, 30, tag="/ds%d" % i, with_feats=False)
+    per = TOTAL // NS
+    ps = synth.make_pairs((per + 29) // 30, 30, tag="/ds%d" % i, with_feats=False).take(slice(0, per))
     feats = bench.device_feats(ps, dev, 7 + i)
     sc.append(s); feed.append(bench.device_feed(name, {name: cfg}, ps, feats, dev)); streams.append(torch.cuda.Stream(dev))
-total = (1000 // NS) * 30 * NS
+total = (TOTAL // NS) * NS
 
 
-def run(concurrent, steps=6):
+def run(concurrent, steps=6 if TOTAL > 4000 else 100):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -42,6 +44,6 @@ def run(concurrent, steps=6):
     return steps * total / (time.perf_counter() - t0)
 
 
-run(False, 2); run(True, 2)
+run(False, 3); run(True, 3)
 for _ in range(2):
     print("%s grid %s: sequential %.0f pairs/s | %d streams %.0f pairs/s" % (name, os.environ.get("MMS_PP_GRID", "all"), run(False), NS, run(True)), flush=True)
