@@ -259,9 +259,36 @@ def batch_sweep(a, local, dev):
         out[name] = rows
         s.close()
         del feats
+    # ... and the fused three-model call (mms_score_ensemble: zk, zk on the rewritten query, lds, lxmert and the main.py:59 merge) at the same sizes
+    cfgs = {n: CFGS[n]() for n in ("zk", "lds", "lxmert")}
+    sc = {n: scorers.make_scorer(c, weights.make_weights(c), precision=a.precision, device=local) for n, c in cfgs.items()}
+    ens = scorers.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
+    whole = synth.make_pairs(1000, 30, tag="/bench0", with_feats=False)
+    feats = device_feats(whole, dev, 20200823)
+    rows = []
+    for B in (5, 256, 1024, 30000):
+        fd = device_feed("ensemble", cfgs, whole.take(slice(0, B)), feats[:B], dev)
+        for _ in range(2):
+            ens.score_prepared(ens.prepare(fd), members=False)
+        torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            ens.score_prepared(ens.prepare(fd), members=False)
+            torch.cuda.synchronize()
+            n += 1
+            dt = time.perf_counter() - t0
+            if (dt > 0.5 and n >= 3) or n >= 200:
+                break
+        rows.append({"pairs_per_call": B, "calls": n, "ms_per_call": round(dt / n * 1e3, 4), "pairs_per_s": round(B * n / dt, 1)})
+    for r in rows:
+        r["of_large_batch_rate"] = round(r["pairs_per_s"] / rows[-1]["pairs_per_s"], 4)
+    out["ensemble"] = rows
+    ens.close()
+    del feats
     print(json.dumps({"metric": "per-call latency and pairs/s of the drop-in call surfaces by batch size", "unit": "pairs/s", "n_gpus": 1,
                       "precision_mode": a.precision, "data": "synthetic", "call_surface": {"zk": "ZkScorer.__call__ (13-argument model_attention_channel_e order)",
-                      "lds": "LdsScorer.__call__(features)", "lxmert": "LxmertScorer.forward (KDDModel.forward order)"},
+                      "lds": "LdsScorer.__call__(features)", "lxmert": "LxmertScorer.forward (KDDModel.forward order)",
+                      "ensemble": "EnsembleScorer.score_prepared (mms_score_ensemble: four members + merge)"},
                       "reference_call_sizes": {"zk": 1, "lds": 5, "lxmert": 256}, "sweep": out}), flush=True)
 
 

@@ -208,6 +208,8 @@ int mms_finalize(mms_handle* h);
  *                            side on two lanes and leave every LayerNorm to its own kernel (the fused epilogue needs its whole grid resident)
  * Batch composition enters in two more places: lxmert with pack_tokens runs its language layers once per DISTINCT query when at least half of the pairs
  * share theirs (the rows of that stage = distinct queries x text_len), and label texts are encoded once per distinct 8-id tuple (rows = tuples).
+ * mms_score_ensemble runs the three members of a launch wave of fewer than 5000 pairs side by side on three streams (same rule: every LayerNorm by its own kernel; a member's
+ * scores equal the single-model call's bit for bit wherever that call would not have used the fused epilogue either, i.e. below 16384 token rows).
  * lxmert's two launch lanes (a side stream between fork / join events: the vision stream's sub-layers beside the language stream's between two cross attentions, the
  * distinct-query stage beside the box stream's layers) run the same kernels on the same operands: no numerical effect beyond the LayerNorm route named above.
  * Not numerical boundaries (same arithmetic, tested bit-identical): the LDS-DMA tile variant taken when a launch has no more workgroups than CUs, the

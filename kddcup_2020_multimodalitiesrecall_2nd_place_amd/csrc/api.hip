@@ -142,6 +142,7 @@ struct mms_handle {
     int *ens_diff = nullptr, *ens_doff = nullptr, *ens_dlist = nullptr, *ens_dcount = nullptr;
     int32_t *ens_cq = nullptr, *ens_clen = nullptr, *ens_cnb = nullptr; int64_t* ens_clab = nullptr;
     float *ens_ctok = nullptr, *ens_clog = nullptr, *ens_cprob = nullptr; int64_t ens_cpairs = 0;
+    Planes ens_featp; int64_t ens_featp_pairs = 0;      // the wave's split box features when the three members run side by side (they may not live in zk's FFN buffer then)
 
     // ---- gemm timing ----
     bool timing = false;
@@ -716,7 +717,7 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     };
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
     if (skinny && !skinny_tall) { p.variant = 5; p.k_splits = skinny_ks; h->skinny_launches += 1; }
-    if (h->timing) {
+    if (h->timing && !h->lane) {      // (per-launch events and FLOP counts cover the main lane: a side-lane launch shares the chip with the launch beside it)
         if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
         p.flop_counter = h->flop_counter;   // executed algorithmic FLOPs (2*M_live*N*K), counted on the device
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
@@ -749,7 +750,7 @@ int gemm_f8(mms_handle* h, hipStream_t st, const unsigned char* a8, int lda, con
     p.cmap = out.cmap; p.rmap = RowMap{0, 0, 0};
     p.m_dev = m_dev;
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
-    if (h->timing) {
+    if (h->timing && !h->lane) {
         if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
         p.flop_counter = h->flop_counter;
         HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
@@ -902,7 +903,7 @@ int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap
         p.k_splits = S; p.c_split_stride = (long long)M * H;
         p.m_dev = m_dev;
         if (skinny) p.variant = 55;      // gemm_skinny.hip, K slices dealt to workgroups (same partials as the tile engine's: bit-identical)
-        if (h->timing) {
+        if (h->timing && !h->lane) {
             if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
             p.flop_counter = h->flop_counter;
             HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], st));
@@ -957,7 +958,7 @@ void plan_cross_tiles(mms_handle* h, hipStream_t st, Pack& px, const Pack& p1, c
 // one fused QKV + attention launch, timed apart from the GEMM launches (its duration includes the attention of its pairs)
 int fused_attn_launch(mms_handle* h, hipStream_t st, QkvAttnParams& q) {
     if (h->alternate) { q.reverse = h->flip; h->flip ^= 1; }
-    if (h->timing) {
+    if (h->timing && !h->lane) {
         if (h->ev_fused_used + 2 > h->ev_fused.size()) { if (int rc = grow_event_pair(h, h->ev_fused)) return rc; }
         q.flop_counter = h->flop_counter + 1;
         HIP_TRY(h, hipEventRecord(h->ev_fused[h->ev_fused_used], st));
@@ -1745,6 +1746,7 @@ void mms_destroy(mms_handle* h) {
     if (h->lq_store.hi) (void)hipFree(h->lq_store.hi);
     if (h->kparts) (void)hipFree(h->kparts);
     if (h->kparts_side) (void)hipFree(h->kparts_side);
+    if (h->ens_featp.hi) (void)hipFree(h->ens_featp.hi);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -1791,6 +1793,7 @@ int mms_score_zk(mms_handle* h, const mms_zk_batch* b, float* logits, float* pro
         return h->fail(MMS_ERR_ARG, "mms_score_zk: null batch field");
     if (b->uniq_label_ids ? (!b->label_index || b->n_uniq_labels == 0) : !b->label_ids)
         return h->fail(MMS_ERR_ARG, "mms_score_zk: pass label_ids (dense) or uniq_label_ids + label_index");
+    h->lanes_on = false;
     DeviceScope dev(h->cfg.device);
     hipStream_t st = (hipStream_t)stream;
     const int cs = chunk_size(h, B);
@@ -1818,6 +1821,7 @@ int mms_score_lds(mms_handle* h, const mms_lds_batch* b, float* logits, float* p
     if (B < 0) return h->fail(MMS_ERR_ARG, "negative batch size");
     if (B == 0) return MMS_OK;
     if (!b->input_ids || !b->segment_ids || !b->features || !b->labelfeat) return h->fail(MMS_ERR_ARG, "mms_score_lds: null batch field");
+    h->lanes_on = false;
     DeviceScope dev(h->cfg.device);
     hipStream_t st = (hipStream_t)stream;
     const int cs = chunk_size(h, B);
@@ -1850,9 +1854,9 @@ int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, fl
     }
     if (int rc = ln_begin_call(h, st)) return rc;
     // two launch lanes (mms_handle::side) for calls whose launch wave has fewer than LANE_ROWS token rows; not for debug runs (they count layers in stream
-    // order), precision mode 4 or per-launch timing
-    h->lanes_q = h->cfg.pack_tokens && h->cfg.stop_after < 0 && !h->f8 && !h->timing && lane_rows() > 0 && lane_query_stage();
-    h->lanes_on = h->lanes_q && (int64_t)cs * (h->cfg.text_len + MMS_NBOX) < lane_rows();
+    // order) or precision mode 4; with per-launch timing (bench.py's roofline pass) only the distinct-query stage keeps its side lane, and its launches stay out of the per-launch sums
+    h->lanes_q = h->cfg.pack_tokens && h->cfg.stop_after < 0 && !h->f8 && lane_rows() > 0 && lane_query_stage();
+    h->lanes_on = h->lanes_q && !h->timing && (int64_t)cs * (h->cfg.text_len + MMS_NBOX) < lane_rows();
     if (int rc = lx_label_features(h, st, uniq, U)) return rc;
     if (int rc = lx_query_stage(h, st, b, B, cs)) return rc;
     for (int64_t p0 = 0; p0 < B; p0 += cs)
@@ -1942,10 +1946,32 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
     mms_lxmert_batch xb{};
     xb.n_pairs = B; xb.input_ids = lx_ids; xb.input_mask = lx_mask; xb.feats = b->feats; xb.boxes = z->ens_boxes4;
     xb.visual_attention_mask = z->ens_vmask;
-    // two lanes inside the lxmert member's chunks as in mms_score_lxmert, but its distinct-query stage stays on the main lane: on the side lane it would run beside the
-    // other members' launches, whose fused LayerNorm epilogues need their whole grid resident (gemm_ln)
-    x->lanes_q = false;
-    x->lanes_on = x->cfg.pack_tokens && !x->f8 && !x->timing && (int64_t)cs * (TL + MMS_NBOX) < lane_rows();
+    // Waves of fewer than ENS_LANE_ROWS token rows in the longest member (lds: text + 20 per pair; 5000 pairs): the three members are independent once the feeds exist, and
+    // each is a serial queue of launches that do not fill the chip.  They run side by side: zk (both passes) on the caller's stream, lds and lxmert on two more (fork after the
+    // wave's feature split, join in front of the merge); same kernels, same operands -- and, as with lxmert's own lanes, every LayerNorm by its own kernel (the fused epilogue
+    // needs its whole grid resident), which only matters above 409 pairs per wave.  Measured (profiles/rd5_lanes.txt): 3.52 -> 2.27 ms at 5 pairs, 10.3 -> 7.8 at 256,
+    // 18.1 -> 13.9 at 600, 27.6 -> 22.6 at 1024, 46.3 -> 40.7 at 2048, 80.1 -> 77.8 at 4096.
+    int64_t ens_rows = 200000;
+#ifdef MMS_LAB
+    { static const int64_t v = getenv("MMS_ENS_LANE_ROWS") ? atoll(getenv("MMS_ENS_LANE_ROWS")) : 0; if (v) ens_rows = v; }
+#endif
+    const bool ens_lanes = lane_rows() > 0 && (int64_t)cs * (T + 2 * MMS_NBOX) < ens_rows && (int64_t)cs * (TL + MMS_NBOX) < ens_rows && !z->timing && !l->timing && !x->timing;
+    z->lanes_on = l->lanes_on = ens_lanes;      // (gemm_ln: no fused LayerNorm epilogue beside another lane)
+    if (ens_lanes) {
+        if (int rc = lanes_init(z)) return rc;
+        if (int rc = lanes_init(l)) return z->fail(rc, "lds handle: " + l->err);
+        if (cs > z->ens_featp_pairs) {
+            if (z->ens_featp.hi) { (void)hipFree(z->ens_featp.hi); z->ens_featp.hi = nullptr; z->ens_featp_pairs = 0; }
+            void* q = nullptr;
+            HIP_TRY(z, hipMalloc(&q, (size_t)cs * MMS_NBOX * MMS_FEAT * 4));
+            z->ens_featp.hi = (bf16*)q; z->ens_featp.lo = z->ens_featp.hi + MMS_PLANE_LO;
+            z->ens_featp_pairs = cs;
+        }
+    }
+    // two lanes inside the lxmert member's chunks as in mms_score_lxmert; its distinct-query stage goes to the side lane only in the small-wave regime above: beside
+    // the other members' big launches with fused LayerNorm epilogues it would break those (gemm_ln)
+    x->lanes_on = x->cfg.pack_tokens && !x->f8 && !x->timing && lane_rows() > 0 && (int64_t)cs * (TL + MMS_NBOX) < lane_rows();
+    x->lanes_q = ens_lanes && x->lanes_on && lane_query_stage();
     if (int rc = lx_query_stage(x, st, &xb, B, cs)) return z->fail(rc, "lxmert member: " + x->err);
     float* lg[4]; float* pr[4];
     for (int k = 0; k < 4; ++k) { lg[k] = z->ens_logits + (int64_t)k * B * 2; pr[k] = z->ens_probs + (int64_t)k * B * 2; }
@@ -1998,10 +2024,17 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
         const int64_t n = (B - p0) < cs ? (B - p0) : cs;
         const int64_t NB = n * MMS_NBOX;
         // the 2048-d box features become operand planes ONCE per wave (zk's FFN buffer; zk itself runs last)
-        Planes featp = z->mid;
+        Planes featp = ens_lanes ? z->ens_featp : z->mid;
         launch_split_f32(b->feats + p0 * MMS_NBOX * MMS_FEAT, featp.hi, featp.lo, NB * MMS_FEAT, st);
-        if (int rc = lds_chunk(l, st, &lb, p0, n, lg[2], pr[2], &featp)) return z->fail(rc, "lds member: " + l->err);
-        if (int rc = lx_chunk(x, st, &xb, index, p0, n, lg[3], pr[3], &featp)) return z->fail(rc, "lxmert member: " + x->err);
+        hipStream_t st_l = st, st_x = st;
+        if (ens_lanes) {      // lds on its handle's side stream, lxmert on zk's (lxmert's own two lanes fork from there)
+            st_l = l->side; st_x = z->side;
+            HIP_TRY(z, hipEventRecord(z->ev_fork, st));
+            HIP_TRY(z, hipStreamWaitEvent(st_l, z->ev_fork, 0));
+            HIP_TRY(z, hipStreamWaitEvent(st_x, z->ev_fork, 0));
+        }
+        if (int rc = lds_chunk(l, st_l, &lb, p0, n, lg[2], pr[2], &featp)) return z->fail(rc, "lds member: " + l->err);
+        if (int rc = lx_chunk(x, st_x, &xb, index, p0, n, lg[3], pr[3], &featp)) return z->fail(rc, "lxmert member: " + x->err);
         if (int rc = zk_image_tokens(z, st, &zb, index, p0, n, &featp)) return rc;
         HIP_TRY(z, hipMemcpyAsync(z->ens_tok, z->qkv + NB * H, (size_t)NB * H * 4, hipMemcpyDeviceToDevice, st));
         if (int rc = zk_encode(z, st, &zb, p0, n, z->ens_tok, lg[0], pr[0])) return rc;
@@ -2020,6 +2053,12 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
         }
         launch_select_rows2(z->ens_diff + p0, z->ens_doff + p0, lg[0] + p0 * 2, z->ens_clog, (int)n, lg[1] + p0 * 2, st);
         launch_select_rows2(z->ens_diff + p0, z->ens_doff + p0, pr[0] + p0 * 2, z->ens_cprob, (int)n, pr[1] + p0 * 2, st);
+        if (ens_lanes) {      // the next wave's feature split and the merge wait for the other two members
+            HIP_TRY(z, hipEventRecord(l->ev_join, st_l));
+            HIP_TRY(z, hipStreamWaitEvent(st, l->ev_join, 0));
+            HIP_TRY(z, hipEventRecord(z->ev_join, st_x));
+            HIP_TRY(z, hipStreamWaitEvent(st, z->ev_join, 0));
+        }
     }
     const float* prc[4] = {pr[0], pr[1], pr[2], pr[3]};
     launch_merge4(prc, weights4, merged, member_scores, B, st);

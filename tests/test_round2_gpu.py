@@ -62,6 +62,24 @@ def test_fused_ensemble_full_model_size_matches_oracle_merged_scores():
     assert not np.allclose(mem[0], mem[1])                            # the rewrite changed at least one query
 
 
+def test_fused_ensemble_members_side_by_side_equal_separate_calls():
+    """Waves of up to 409 pairs run the three members on three streams (api.hip mms_score_ensemble, ens_lanes; lxmert on its own two lanes inside): ~290 pairs here, every
+    stream in the fused-attention regime (>= 1024 token rows), two identical calls bit-identical, members 0 / 2 / 3 bit-identical to the single-model calls on the same pairs."""
+    cfgs = {n: small_cfg(n) for n in ("zk", "lds", "lxmert")}
+    ws, sc = _members(cfgs)
+    ps = synth.make_pairs(10, (28, 30), vocab=cfgs["zk"].vocab, tag="/ens_lanes")
+    zb, zb2, lb, xb = _feeds(cfgs, ps)
+    sep = [scorers.score_batch(sc["zk"], zb)[1][:, 1], None, scorers.score_batch(sc["lds"], lb)[1][:, 1], scorers.score_batch(sc["lxmert"], xb)[1][:, 1]]
+    ens = scorers.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
+    feed = pipeline.ensemble_feed(zb, zb2, xb)
+    merged, mem = ens(feed)
+    merged_b, mem_b = ens(feed)
+    assert torch.equal(merged, merged_b) and torch.equal(mem, mem_b)
+    for k in (0, 2, 3):
+        assert torch.equal(mem[k], sep[k]), (k, float((mem[k] - sep[k]).abs().max()))
+    ens.close()
+
+
 def test_fused_ensemble_equals_four_separate_calls_and_chunks():
     """The fused call shares the feature split, the label de-duplication and zk's image-token stage; none of that may change a
     score: bit-identical to the four single-model calls, also when the batch is cut into ragged launch waves."""
