@@ -56,5 +56,7 @@ done
 echo "== 4 x 2 wave layout of the same route (MMS_QA_LAYOUT=42), all work" >> $O/qa_trace.txt
 QA_FUSE=2 MMS_QA_LAYOUT=42 python $R/tools/qa_trace.py 2>&1 | grep -A1 "^tile [2-5]" >> $O/qa_trace.txt
 python $R/bench.py --batch-sweep > $O/batch_sweep.json 2> $O/batch_sweep.err
+python $R/tools/soak_small.py 20 > $O/soak_small_calls.txt 2>&1
+(cd $R && bash tools/small_call_profile.sh $T/kmix "zk 256" "lds 256" "lxmert 256" "zk 1" "lds 5" > /dev/null 2>&1); cp $O/kmix_summary.txt $O/small_call_kernel_mix.txt 2>/dev/null; (cd /tmp)
 cd $R && timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest_gpu_tail.txt
 ls -la $O

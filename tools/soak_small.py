@@ -36,3 +36,26 @@ for name in ("zk", "lds", "lxmert"):
     print("%s: %d calls of %s pairs in %.1f s, every repetition bit-identical to the first: %s, free memory %.3f -> %.3f GB" % (
         name, calls, sorted(set(SIZES)), time.perf_counter() - t0, same, free0 / 1e9, torch.cuda.mem_get_info()[0] / 1e9), flush=True)
     s.close()
+
+# ... and the fused three-model call (members side by side on three streams below 5000 pairs per wave, lxmert on two lanes inside)
+cfgs = {n: bench.CFGS[n]() for n in ("zk", "lds", "lxmert")}
+sc = {n: scorers.make_scorer(c, weights.make_weights(c), precision=2) for n, c in cfgs.items()}
+ens = scorers.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
+ps = synth.make_pairs(40, 30, tag="/bench0", with_feats=False)
+feats = bench.device_feats(ps, dev, 20200823)
+ESIZES = [1, 5, 256, 17, 600, 3, 409, 410, 60, 1200]
+efeeds = {c: bench.device_feed("ensemble", cfgs, ps.take(slice(0, c)), feats[:c], dev) for c in set(ESIZES)}
+first = {}
+for c in ESIZES:
+    first.setdefault(c, ens.score_prepared(ens.prepare(efeeds[c]), members=False)[0].clone())
+torch.cuda.synchronize()
+free0 = torch.cuda.mem_get_info()[0]
+t0 = time.perf_counter(); calls = 0; same = True
+for r in range(max(1, rounds // 2)):
+    for c in ESIZES:
+        out = ens.score_prepared(ens.prepare(efeeds[c]), members=False)[0]
+        same = same and bool(torch.equal(out, first[c])); calls += 1
+torch.cuda.synchronize()
+print("ensemble: %d calls of %s pairs in %.1f s, every repetition bit-identical to the first: %s, free memory %.3f -> %.3f GB" % (
+    calls, sorted(set(ESIZES)), time.perf_counter() - t0, same, free0 / 1e9, torch.cuda.mem_get_info()[0] / 1e9), flush=True)
+ens.close()
