@@ -196,7 +196,7 @@ int mms_finalize(mms_handle* h);
  *   rows <  1024             wide projections (N >= 1536, K = 768: QKV, K | V, FFN-up): K in 4 slices, summed in fixed order (k_splitk_reduce)
  *   rows <  4096             the long-K projections in front of the encoder (K >= 2048, N = 768: zk kdd_conv1 as im2col over 8 x distinct label texts,
  *                            kdd_conv2 / visn_fc / featureemb over the box rows): K in 8 slices
- *   rows <  8192             the N = 768 projections that a LayerNorm follows (attention output, FFN-down): K in 4 (K = 768) / 8 (K >= 2048) slices,
+ *   rows <  8192             the N = 768 projections that a LayerNorm follows (attention output, FFN-down): K in 4 (K = 768) / 8 (K >= 2048; 4 from 4096 rows on) slices,
  *                            summed by the LayerNorm kernel
  *   rows >= 1024             mms_config.fuse_attention: a stream's QKV projection + attention in one kernel (qkv_attn.hip).  1: the two-kernel route's arithmetic, bit-identical
  *                            to it.  2 (the scorers' default in precision mode 2): split-bf16 attention over 16-query tiles of a packed sub-tile, online softmax -- a pair's

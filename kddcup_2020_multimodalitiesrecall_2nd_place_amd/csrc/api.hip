@@ -853,9 +853,19 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
 // alone, so launches in this regime stay bit-identical across batch sizes.
 constexpr int64_t SPLITK_ROWS = 8192;      // padded row bound of the launch (the live count is on the device): zk calls of <= 273 pairs
 constexpr int KSPLIT_MAX = 8;
+constexpr int64_t SPLITK_HALF_ROWS = 4096;
 int splitk_for(const mms_handle* h, int64_t M, int K) {
     if (M >= SPLITK_ROWS || h->nsplit == 1 || h->f8) return 1;
-    const int S = K >= 2048 ? 8 : 4;
+    // K = 3072 (FFN-down): 8 slices up to 4095 rows, 4 from there on -- at 256 zk pairs (7680 padded rows) 8 slices are 744 workgroups of 6 K steps and 95 MB of partials for the
+    // LayerNorm kernel to sum; 4 slices: zk 2.38 -> 2.19 ms per 256-pair call, lds 2.57 -> 2.38 at 150 pairs, neutral at 100 zk pairs (profiles/rd5_splitk_midsize.txt)
+    int S = K >= 2048 ? (M >= SPLITK_HALF_ROWS ? 4 : 8) : 4;
+#ifdef MMS_LAB
+    if (M >= 1024) {      // A/B: slice counts of the upper half of the regime
+        static const int s768 = getenv("MMS_SPLITK_768") ? atoi(getenv("MMS_SPLITK_768")) : 0, s3072 = getenv("MMS_SPLITK_3072") ? atoi(getenv("MMS_SPLITK_3072")) : 0;
+        if (K < 2048 && s768) S = s768;
+        if (K >= 2048 && s3072) S = s3072;
+    }
+#endif
     return K % (64 * S) == 0 ? S : 1;
 }
 int ensure_kparts(mms_handle* h, int64_t floats) {      // (of the lane that is being enqueued)

@@ -1,5 +1,5 @@
 """GPU suite, round 4: the launch-size regimes of api.hip meet at fixed PADDED row counts (pairs x tokens per pair) -- 128 (skinny kernel), 1024 (wide projections split over K with
-k_splitk_reduce), 4096 (long-K projections in front of the encoder), 8192 (split-K N = 768 projections summed in the LayerNorm kernel), 16 384 (persistent
+k_splitk_reduce; fused QKV + attention from there on), 4096 (long-K projections in front of the encoder; FFN-down in 8 / 4 K slices), 8192 (split-K N = 768 projections summed in the LayerNorm kernel), 16 384 (persistent
 ping-pong engines, LayerNorm in the GEMM epilogue; the fused QKV + attention kernel starts at 1024).  The same pairs scored in ONE call of a size one pair below / at each bound must give the
 same scores up to fp32 round-off of a different summation order, packed and dense, with a ragged last wave -- a partial-buffer, row-bound or off-by-one slip
 at a boundary shows up as garbage in some pairs, not as round-off."""
@@ -14,15 +14,15 @@ from oracle import np_models as O
 pytestmark = pytest.mark.gpu
 
 # pairs per launch wave so that wave rows = pairs x S straddle 256 / 4096 (box rows = pairs x 10) / 8192 / 16 384
-WAVES = {"zk": [4, 5, 34, 35, 273, 274, 409, 410, 546, 547],  # S = 30: 120 | 150 (skinny kernel <= 128 rows), 1020 | 1050, 8190 | 8220, box rows 4090 | 4100, 16 380 | 16 410
-         "lds": [3, 4, 25, 26, 204, 205, 409, 410],          # S = 40: 120 | 160, 1000 | 1040, 8160 | 8200, 16 360 | 16 400
-         "lxmert": [6, 7, 51, 52, 409, 410, 819, 820]}       # language rows S = 20: 120 | 140, 1020 | 1040, 8180 | 8200, 16 380 | 16 400; vision rows (10 per pair) 4090 | 4100, 8190 | 8200
+WAVES = {"zk": [4, 5, 34, 35, 136, 137, 273, 274, 409, 410, 546, 547],  # S = 30: 120 | 150 (skinny kernel <= 128 rows), 1020 | 1050, 4080 | 4110 (FFN-down in 8 | 4 K slices), 8190 | 8220, box rows 4090 | 4100, 16 380 | 16 410
+         "lds": [3, 4, 25, 26, 102, 103, 204, 205, 409, 410],          # S = 40: 120 | 160, 1000 | 1040, 4080 | 4120, 8160 | 8200, 16 360 | 16 400
+         "lxmert": [6, 7, 51, 52, 204, 205, 409, 410, 819, 820]}       # language rows S = 20: 120 | 140, 1020 | 1040, 4080 | 4100, 8180 | 8200, 16 380 | 16 400; vision rows (10 per pair) 4090 | 4100, 8190 | 8200
 
 
 @pytest.mark.parametrize("name", ["zk", "lds", "lxmert"])
 @pytest.mark.parametrize("pack", [True, False])
 def test_calls_just_below_and_at_every_regime_bound_agree(name, pack):
-    cfg = small_cfg(name)
+    cfg = small_cfg(name, inter=3072)      # the reference's FFN width: its K = 3072 projection changes its slice count at 4096 and 8192 rows
     w = weights.make_weights(cfg)
     ps = synth.make_pairs(40, (26, 30), vocab=cfg.vocab, tag="/bound")       # ~1100 pairs: one or two waves at the largest sizes, a ragged last wave at all of them
     b = synth.batch_for(cfg, ps)
