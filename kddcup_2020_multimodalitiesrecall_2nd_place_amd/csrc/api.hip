@@ -1356,10 +1356,9 @@ int lx_label_features(mms_handle* h, hipStream_t st, const int64_t* uniq_ids, in
 // Skipped (lq_active = false -> the per-pair path) when fewer than half of the pairs share their query with another pair.
 // two launch lanes (mms_handle::side): fork = the side stream waits for everything enqueued on st so far; join = st waits for the side chain
 int lanes_init(mms_handle* h) {
-    if (h->side) return MMS_OK;
-    HIP_TRY(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    if (!h->side) HIP_TRY(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));      // (non-blocking: ordered against the caller's stream -- the legacy default stream included -- by the two events alone)
+    if (!h->ev_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    if (!h->ev_join) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     return MMS_OK;
 }
 int lane_fork(mms_handle* h, hipStream_t st) {
