@@ -182,7 +182,9 @@ def run_timed(step, steps, warmup, world, dev, handles):
     gms = gn = gfl = 0.0
     fused = [0.0, 0.0, 0.0]
     cls = [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]           # GEMM launches by epilogue class: plain / fused LayerNorm
+    side_fl = 0.0
     for h in handles:
+        side_fl += h.side_lane_flops()                  # lxmert's distinct-query stage on the side lane: counted, not timed (before the reset below)
         for i, v in enumerate(h.fused_timing()):       # before the reset below
             fused[i] += v
         for c in (0, 1):
@@ -194,7 +196,7 @@ def run_timed(step, steps, warmup, world, dev, handles):
         t = torch.tensor([dt, med], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, med = float(t[0].item()), float(t[1].item())
-    return dt, med, gms, gn, gfl, fused + [cls]
+    return dt, med, gms, gn, gfl, fused + [cls, side_fl]
 
 
 def spawn_ranks(n, argv):
@@ -510,7 +512,7 @@ def main():
                     if key == "layernorm_fused" and traffic is not None:
                         res["roofline"][key]["traffic"] = json.load(open(tp)).get("ln_fused_hbm_bytes_per_launch")
         # the whole step on the same terms: every executed dense-contraction FLOP (device-counted) over the barrier-bracketed step time
-        step_fl = (gemm_fl + fused[2]) / max(a.steps, 1)
+        step_fl = (gemm_fl + fused[2] + fused[4]) / max(a.steps, 1)      # (fused[4]: launches on a side lane -- in the step's work, in no per-launch sum)
         res["roofline"]["whole_step"] = {"executed_flops": round(step_fl, 1), "ms_per_step": round(dt / a.steps * 1e3, 3),
                                          "achieved": round(step_fl / (dt / a.steps) / 1e12, 2), "frac": round(step_fl / (dt / a.steps) / 1e12 / peak, 4),
                                          "note": "all kernels of the step (GEMMs, fused QKV + attention, row kernels, bookkeeping) in the denominator"}

@@ -235,6 +235,8 @@ int mms_gemm_timing_class(mms_handle* h, int32_t cls, double* ms_out, int64_t* l
  * reported apart from the GEMM launches because their duration includes the attention of their pairs: total ms, launches, executed
  * projection FLOPs. */
 int mms_fused_timing(mms_handle* h, double* ms_out, int64_t* launches_out, double* flops_out);
+/* ... and the executed FLOPs of the launches that ran on a side lane (lxmert's distinct-query stage): counted, not timed -- a launch that shares the chip has no duration of its own */
+int mms_side_lane_flops(mms_handle* h, double* flops_out);
 
 /* ---- debug / test hooks (kernel-level parity tests call the same kernels the scorers launch) ---- */
 int mms_debug_read_x(mms_handle* h, float* dst_dev, int64_t rows, void* stream); /* current hidden state -> fp32 [rows,768] */

@@ -717,6 +717,7 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     };
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
     if (skinny && !skinny_tall) { p.variant = 5; p.k_splits = skinny_ks; h->skinny_launches += 1; }
+    if (h->timing && h->lane) p.flop_counter = h->flop_counter + 3;      // side lane: FLOPs only (slot 3, mms_side_lane_flops) -- a launch that shares the chip has no duration of its own
     if (h->timing && !h->lane) {      // (per-launch events and FLOP counts cover the main lane: a side-lane launch shares the chip with the launch beside it)
         if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
         p.flop_counter = h->flop_counter;   // executed algorithmic FLOPs (2*M_live*N*K), counted on the device
@@ -750,6 +751,7 @@ int gemm_f8(mms_handle* h, hipStream_t st, const unsigned char* a8, int lda, con
     p.cmap = out.cmap; p.rmap = RowMap{0, 0, 0};
     p.m_dev = m_dev;
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
+    if (h->timing && h->lane) p.flop_counter = h->flop_counter + 3;      // side lane: FLOPs only (slot 3, mms_side_lane_flops) -- a launch that shares the chip has no duration of its own
     if (h->timing && !h->lane) {
         if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
         p.flop_counter = h->flop_counter;
@@ -913,6 +915,7 @@ int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap
         p.k_splits = S; p.c_split_stride = (long long)M * H;
         p.m_dev = m_dev;
         if (skinny) p.variant = 55;      // gemm_skinny.hip, K slices dealt to workgroups (same partials as the tile engine's: bit-identical)
+        if (h->timing && h->lane) p.flop_counter = h->flop_counter + 3;      // side lane: FLOPs only (slot 3, mms_side_lane_flops) -- a launch that shares the chip has no duration of its own
         if (h->timing && !h->lane) {
             if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
             p.flop_counter = h->flop_counter;
@@ -968,6 +971,7 @@ void plan_cross_tiles(mms_handle* h, hipStream_t st, Pack& px, const Pack& p1, c
 // one fused QKV + attention launch, timed apart from the GEMM launches (its duration includes the attention of its pairs)
 int fused_attn_launch(mms_handle* h, hipStream_t st, QkvAttnParams& q) {
     if (h->alternate) { q.reverse = h->flip; h->flip ^= 1; }
+    if (h->timing && h->lane) q.flop_counter = h->flop_counter + 3;      // side lane: FLOPs only (slot 3, mms_side_lane_flops) -- a launch that shares the chip has no duration of its own
     if (h->timing && !h->lane) {
         if (h->ev_fused_used + 2 > h->ev_fused.size()) { if (int rc = grow_event_pair(h, h->ev_fused)) return rc; }
         q.flop_counter = h->flop_counter + 1;
@@ -2079,7 +2083,7 @@ int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out
     DeviceScope dev(h->cfg.device);
     if (!h->flop_counter) {
         void* p;
-        if (int rc = dev_alloc(h, h->w_allocs, &p, 32)) return rc;      // [0]: GEMM launches, [1]: fused QKV + attention launches, [2]: LayerNorm-fused GEMM launches
+        if (int rc = dev_alloc(h, h->w_allocs, &p, 32)) return rc;      // [0]: GEMM launches, [1]: fused QKV + attention launches, [2]: LayerNorm-fused GEMM launches, [3]: side-lane launches (untimed)
         h->flop_counter = (unsigned long long*)p;
         HIP_TRY(h, hipMemset(p, 0, 32));
     }
@@ -2141,6 +2145,17 @@ int mms_fused_timing(mms_handle* h, double* ms_out, int64_t* launches_out, doubl
     if (ms_out) *ms_out = ms;
     if (launches_out) *launches_out = h->fused_timed;
     if (flops_out) *flops_out = (double)fl;
+    return MMS_OK;
+}
+
+// executed FLOPs of the launches that ran on the side lane since the last mms_gemm_timing reset (lxmert's distinct-query stage beside the box stream's layers):
+// part of the step's work, in no per-launch sum
+int mms_side_lane_flops(mms_handle* h, double* flops_out) {
+    if (!h || !flops_out) return MMS_ERR_ARG;
+    DeviceScope dev(h->cfg.device);
+    unsigned long long fl = 0;
+    if (h->flop_counter) HIP_TRY(h, hipMemcpy(&fl, h->flop_counter + 3, 8, hipMemcpyDeviceToHost));
+    *flops_out = (double)fl;
     return MMS_OK;
 }
 

@@ -63,7 +63,7 @@ ABI_VERSION = 6     # include/mmscore.h MMS_ABI_VERSION
 EXPORTS = ("mms_version", "mms_global_error", "mms_create", "mms_destroy", "mms_last_error", "mms_load_weight",
            "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_score_ensemble", "mms_gemm_timing", "mms_gemm_timing_class",
            "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_ln", "mms_dbg_proj_ln_splitk", "mms_dbg_attention", "mms_dbg_qkv_attn", "mms_dbg_layernorm",
-           "mms_dbg_gemm_bench", "mms_dbg_counter", "mms_fused_timing")
+           "mms_dbg_gemm_bench", "mms_dbg_counter", "mms_fused_timing", "mms_side_lane_flops")
 LAB_EXPORTS = ("mms_dbg_gemm_mx", "mms_lab_ln_trace")      # libmmscore_lab.so only
 
 _lib = None
@@ -112,6 +112,7 @@ def load(path=None):
     lib.mms_dbg_qkv_attn.argtypes = [vp, i64, i64, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, C.POINTER(i32), vp]
     lib.mms_dbg_counter.argtypes = [vp, i32]
     lib.mms_fused_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
+    lib.mms_side_lane_flops.argtypes = [vp, C.POINTER(C.c_double)]
     lib.mms_dbg_counter.restype = i64
     lib.mms_dbg_gemm_bench.argtypes = [i64, i64, i64, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float)]
     _lib = lib
@@ -170,6 +171,12 @@ class Handle:
         ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
         self._check(self.lib.mms_gemm_timing_class(self._h, cls, C.byref(ms), C.byref(n), C.byref(fl)), "mms_gemm_timing_class")
         return ms.value, n.value, fl.value
+
+    def side_lane_flops(self):
+        """Executed FLOPs of the launches that ran on the side lane since the last gemm_timing reset (counted, not timed)."""
+        fl = C.c_double(0)
+        self._check(self.lib.mms_side_lane_flops(self._h, C.byref(fl)), "mms_side_lane_flops")
+        return fl.value
 
     def fused_timing(self):
         """(ms, launches, projection flops) of the fused QKV + attention launches timed since the last gemm_timing reset."""

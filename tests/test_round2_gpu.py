@@ -222,18 +222,19 @@ def test_testB_like_set_single_gpu_matches_shardwise_scoring():
         a, e = sharding.pair_slice_for_queries(qop, lo, hi)
         parts.append(scorers.score_batch(s, {k: v[a:e] for k, v in b.items()})[0])
     assert (torch.cat(parts) - whole).abs().max() < 2e-4
-    # same engine regime on both sides: a launch against its own quarters stays bitwise (all below api.hip's SPLITK_ROWS = 8192 padded
-    # token rows: register-staged tiles, the N = 768 projections split over K by a factor that depends on K alone)
+    # same engine regime on both sides: a launch against its own parts stays bitwise (register-staged tiles, the N = 768 projections split over K by a factor that
+    # depends on K and the regime alone)
     # -- on the position-independent attention arithmetic (fuse_attention = 1); the default route (2) attends 16-query tiles of a packed sub-tile from 1024 token rows
     # on, and a pair's round-off depends on its place in the launch: <= 1e-4
     half = scorers.score_batch(s, {k: v[:200] for k, v in b.items()})[0]
     q = torch.cat([scorers.score_batch(s, {k: v[i:i + 50] for k, v in b.items()})[0] for i in range(0, 200, 50)])
     assert (half - q).abs().max() < 1e-4
     s.close()
+    # one regime on both sides: 135 pairs = 4050 padded token rows against three calls of 45 = 1350 (all in [1024, 4096): FFN-down in 8 K slices, wide projections unsplit)
     s1 = scorers.ZkScorer(cfg, w, fuse_attention=1)
-    half = scorers.score_batch(s1, {k: v[:200] for k, v in b.items()})[0]
-    q = torch.cat([scorers.score_batch(s1, {k: v[i:i + 50] for k, v in b.items()})[0] for i in range(0, 200, 50)])
-    assert torch.equal(half, q)
+    whole1 = scorers.score_batch(s1, {k: v[:135] for k, v in b.items()})[0]
+    q = torch.cat([scorers.score_batch(s1, {k: v[i:i + 45] for k, v in b.items()})[0] for i in range(0, 135, 45)])
+    assert torch.equal(whole1, q)
     s1.close()
 
 
