@@ -172,7 +172,7 @@ typedef struct mms_ensemble_batch {
 /* ABI revision of the structs and entry points declared in this header.  It changes whenever a struct gains a field or an entry
  * point changes its signature (r1: 1; r2 added mms_config.fuse_layernorm, mms_zk_batch.label_ids, mms_lxmert_batch.label_ids / x_norm
  * without bumping it; r3: 3, then 4 with mms_config.fuse_attention; r4: 5 -- mms_dbg_gemm takes the tile engine per call,
- * the process-global mms_set_gemm_variant and the lab engines' hooks left the product library, fuse_layernorm became a mask; r5: 6 -- mms_dbg_qkv_attn added).  A caller built against another revision would make the library read past its structs, so compare
+ * the process-global mms_set_gemm_variant and the lab engines' hooks left the product library, fuse_layernorm became a mask; r5: 6 -- mms_dbg_qkv_attn and mms_side_lane_flops added).  A caller built against another revision would make the library read past its structs, so compare
  * BEFORE the first mms_create:  if (mms_version() != MMS_ABI_VERSION) abort();   (lib.py's load() does) */
 #define MMS_ABI_VERSION 6
 int mms_version(void);
@@ -275,7 +275,8 @@ int mms_dbg_qkv_attn(const float* x, int64_t rows1, int64_t rows2, const int32_t
                      int32_t mode, float* ctx_f32, int32_t* n_sub_out, void* stream);
 /* launch counters since mms_create: which = 0 -> fused QKV + attention launches (mms_config.fuse_attention took effect), 1 -> GEMM launches
  * with the fused LayerNorm epilogue (mms_config.fuse_layernorm), 2 -> split-K launches of the small-call routes, 3 -> skinny-GEMM launches (launches of <= 128
- * padded rows, precision modes 2 and 3); anything else: -1 */
+ * padded rows, precision modes 2 and 3), 4 -> fork / join pairs of the second launch lane (lxmert handles; on a zk handle: the member lanes of mms_score_ensemble);
+ * anything else: -1 */
 int64_t mms_dbg_counter(mms_handle* h, int32_t which);
 int mms_dbg_layernorm(const float* x, const float* gamma, const float* beta, int64_t M, float* out_f32, void* stream);
 

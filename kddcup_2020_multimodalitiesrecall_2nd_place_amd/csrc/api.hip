@@ -153,6 +153,7 @@ struct mms_handle {
     int64_t fused_attn_launches = 0;     // qkv_attn.hip launches since mms_create (mms_dbg_counter)
     bool zk_plans_merged = false;        // zk_image_tokens() already built this launch wave's token plan (small waves: launch_zk_plans_small)
     int64_t skinny_launches = 0;         // gemm_skinny.hip launches (launches of <= 128 padded rows) since mms_create
+    int64_t lane_forks = 0;              // fork / join pairs of the second launch lane since mms_create (mms_dbg_counter 4)
     int64_t ln_fused_launches = 0, splitk_launches = 0;      // LayerNorm-fused GEMM launches / split-K launches (small-call routes) since mms_create
     std::vector<hipEvent_t> ev_fused; size_t ev_fused_used = 0; int64_t fused_timed = 0;     // timing of the fused launches, apart from the GEMMs' (mms_fused_timing)
 
@@ -1366,6 +1367,7 @@ int lanes_init(mms_handle* h) {
     return MMS_OK;
 }
 int lane_fork(mms_handle* h, hipStream_t st) {
+    h->lane_forks += 1;
     HIP_TRY(h, hipEventRecord(h->ev_fork, st));
     HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
     return MMS_OK;
@@ -2042,6 +2044,7 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
         hipStream_t st_l = st, st_x = st;
         if (ens_lanes) {      // lds on its handle's side stream, lxmert on zk's (lxmert's own two lanes fork from there)
             st_l = l->side; st_x = z->side;
+            z->lane_forks += 1;
             HIP_TRY(z, hipEventRecord(z->ev_fork, st));
             HIP_TRY(z, hipStreamWaitEvent(st_l, z->ev_fork, 0));
             HIP_TRY(z, hipStreamWaitEvent(st_x, z->ev_fork, 0));
@@ -2362,7 +2365,7 @@ __global__ void k_fill_random(float* p, long long n, unsigned seed) {
 
 int64_t mms_dbg_counter(mms_handle* h, int32_t which) {
     if (!h) return -1;
-    return which == 0 ? h->fused_attn_launches : which == 1 ? h->ln_fused_launches : which == 2 ? h->splitk_launches : which == 3 ? h->skinny_launches : -1;
+    return which == 0 ? h->fused_attn_launches : which == 1 ? h->ln_fused_launches : which == 2 ? h->splitk_launches : which == 3 ? h->skinny_launches : which == 4 ? h->lane_forks : -1;
 }
 
 // GEMM micro-benchmark on random operands: returns the average kernel time (ms) over `iters` launches.

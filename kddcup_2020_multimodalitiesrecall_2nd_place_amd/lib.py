@@ -185,7 +185,7 @@ class Handle:
         return ms.value, n.value, fl.value
 
     def counter(self, which: int) -> int:
-        """mms_dbg_counter: 0 = fused QKV + attention launches, 1 = LayerNorm-fused GEMM launches, 2 = split-K launches (small calls), 3 = skinny-GEMM launches (launches of <= 128 padded rows) since creation."""
+        """mms_dbg_counter: 0 = fused QKV + attention launches, 1 = LayerNorm-fused GEMM launches, 2 = split-K launches (small calls), 3 = skinny-GEMM launches (launches of <= 128 padded rows), 4 = fork / join pairs of the second launch lane (lxmert; zk handle: member lanes of the fused three-model call) since creation."""
         return int(self.lib.mms_dbg_counter(self._h, which))
 
     def debug_read_x(self, dst_ptr, rows, stream_ptr):

@@ -29,3 +29,36 @@ def test_two_lanes_give_the_bits_of_one_lane(tmp_path):
             assert np.array_equal(a, b) and np.array_equal(a, q), (k, float(np.abs(a - b).max()), float(np.abs(a - q).max()))
         else:                 # one lane: LayerNorm in the GEMM epilogue; two lanes: the LayerNorm kernel
             assert np.abs(a - b).max() < 2e-4 and np.abs(a - q).max() < 2e-4, (k, float(np.abs(a - b).max()))
+
+
+def test_product_build_takes_the_lanes_where_documented():
+    """mms_dbg_counter 4 = fork / join pairs: a 256-pair lxmert call (the reference's batch size, param.py:46) forks for its distinct-query stage and once per full X layer;
+    a call above LANE_ROWS (400 000 token rows) only for the query stage; zk never; the fused three-model call forks its members once per wave below 5000 pairs."""
+    import torch
+    from helpers import small_cfg
+    from kddcup_2020_multimodalitiesrecall_2nd_place_amd import pipeline, scorers, synth, weights
+    cfg = small_cfg("lxmert", x_layers=3)
+    s = scorers.make_scorer(cfg, weights.make_weights(cfg))
+    ps = synth.make_pairs(9, (28, 30), vocab=cfg.vocab, tag="/lanes_ctr")
+    b = synth.batch_for(cfg, ps)
+    scorers.score_batch(s, b)
+    n1 = s.handle.counter(4)
+    assert n1 == 1 + (cfg.x_layers - 1), n1          # query stage + the X layers in front of the trimmed last one
+    big = synth.make_pairs(450, 30, vocab=cfg.vocab, tag="/lanes_ctr_big")      # 13 500 pairs x 33 rows > 400 000
+    scorers.score_batch(s, synth.batch_for(cfg, big))
+    assert s.handle.counter(4) == n1 + 1
+    lone = synth.make_pairs(40, 1, vocab=cfg.vocab, tag="/lanes_ctr_lone")      # no query shared: language layers beside the box stream's layers inside the chunk
+    scorers.score_batch(s, synth.batch_for(cfg, lone))
+    assert s.handle.counter(4) == n1 + 1 + 1 + (cfg.x_layers - 1)
+    s.close()
+    cfgs = {n: small_cfg(n) for n in ("zk", "lds", "lxmert")}
+    sc = {n: scorers.make_scorer(c, weights.make_weights(c)) for n, c in cfgs.items()}
+    ens = scorers.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
+    zb = synth.zk_batch(ps, cfgs["zk"].text_len)
+    zb2 = synth.zk_batch(synth.sen2forest_variant(ps), cfgs["zk"].text_len)
+    xb = synth.lxmert_batch(ps, cfgs["lxmert"].text_len)
+    ens(pipeline.ensemble_feed(zb, zb2, xb))
+    assert sc["zk"].handle.counter(4) == 1 and sc["lds"].handle.counter(4) == 0 and sc["lxmert"].handle.counter(4) >= 1
+    scorers.score_batch(sc["zk"], zb)
+    assert sc["zk"].handle.counter(4) == 1
+    ens.close()
