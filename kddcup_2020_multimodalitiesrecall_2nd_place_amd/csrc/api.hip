@@ -1589,8 +1589,14 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
             a.o_hi = h->ctx.hi; a.o_lo = h->ctx.lo;
             a.q_off = pl.off; a.q_cnt = pl.cnt; a.kv_off = pv.off; a.kv_cnt = pv.cnt;
             if (int rc = attend(h, a, st)) return rc;
-            if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
-            ln_resid(h, st, h->t, w.cross.g, w.cross.b, h->y, ML, pl.rows, h->x);
+            bool fl = false;      // (big launches: bias + residual + LayerNorm in the projection's epilogue, as in the layers before)
+            if (!(h->f8 && h->x.f8)) {
+                if (int rc = gemm_ln(h, st, false, h->ctx, H, w.cross.wo, nullptr, nullptr, w.cross.bo, ML, H, h->x, w.cross.g, w.cross.b, h->y, h->t, pl.rows, &fl)) return rc;
+            }
+            if (!fl) {
+                if (int rc = gemm(h, st, h->ctx, H, ID, w.cross.wo, w.cross.bo, ML, H, H, ACT_NONE, to_f32(h->t, H), &h->x, pl.rows)) return rc;
+                ln_resid(h, st, h->t, w.cross.g, w.cross.b, h->y, ML, pl.rows, h->x);
+            }
             if (int rc = last_block_cls(h, st, w.lang_self, w.lang_ffn, ACT_GELU_ERF, h->y, h->x, T, n, lang_add, pl)) return rc;
             break;
         }
