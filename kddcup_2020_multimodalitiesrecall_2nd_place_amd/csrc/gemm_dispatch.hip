@@ -36,6 +36,15 @@ int pp_rows() {
 #endif
 }
 
+int pp_wide_rows() {
+#ifdef MMS_LAB
+    static const int v = getenv("MMS_PP_WIDE_ROWS") ? atoi(getenv("MMS_PP_WIDE_ROWS")) : 5120;
+    return v;
+#else
+    return 5120;
+#endif
+}
+
 // false: no engine took the launch (nothing was enqueued) -- the caller turns that into MMS_ERR_ARG instead of letting the next kernel read an unwritten buffer
 bool launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return true;
@@ -69,6 +78,11 @@ bool launch_gemm(const GemmParams& p, int nsplit, hipStream_t st) {
     if (variant == 99) {  // auto (profiles/r01c_gemm_variants.txt): 256x256 ping-pong phases for large M; for the small GEMMs
                           // (CLS-only last block, poolers) 256x256 / 16 waves on wide outputs, 128x256 / 8 waves otherwise
         if (p.N % 256 == 0 && p.M >= pp_rows()) variant = 26;   // ping-pong phases, persistent workgroups (20 = one tile per workgroup)
+        // ... and for the WIDE projections (N >= 1536: FFN-up, an unfused QKV / K | V) already from 5120 padded rows on: the engines contract K in the same order per element
+        // (bit-identical, tests/test_kernels_gpu.py), so this is a speed choice alone.  At 256 zk pairs FFN-up is 372 live 128 x 256 workgroups on 256 CUs (two rounds, 47 us)
+        // against 192 ping-pong tiles in one round (41 us): zk 2.33 -> 2.10 ms per 256-pair call, lds 2.47 -> 2.26 at 150 pairs, 4.90 -> 4.40 at 350, lxmert 3.63 -> 3.46 at 512;
+        // below ~5000 rows the tiles win (zk 140 / 170 pairs +4 % with a bound of 4096), and the N = 768 projections lose at every size below 16 384 (profiles/rd5_pp_plain.txt)
+        else if (p.N % 256 == 0 && p.N >= 1536 && p.k_splits <= 1 && p.M >= pp_wide_rows()) variant = 26;
         else variant = 4;   // (rounds 1-3 sent wide outputs at M >= 8192 to the 256x256 / 16-wave tile: 82 .. 95 us per launch on lds' 256-pair calls, the 128x256 tile is faster there)
         // ... and when even the PADDED row bound gives no more workgroups than the chip has CUs (calls of up to ~50 .. 120 pairs): the same tile with LDS-DMA
         // double buffering (no VGPR round trip, one barrier per K step; 128 KiB of LDS, so one workgroup per CU -- which is all such a launch has anyway):

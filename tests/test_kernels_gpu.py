@@ -148,6 +148,27 @@ def test_lds_dma_tile_equals_the_register_staged_tile_bit_for_bit(case):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[2], outs[1]), case
 
 
+@pytest.mark.parametrize("case", [(3000, 768, 3072, lib.ACT_GELU_TANH, True), (3000, 3072, 768, lib.ACT_NONE, False), (5000, 768, 2304, lib.ACT_NONE, False), (20000, 768, 768, lib.ACT_NONE, False)])
+def test_ping_pong_engine_equals_the_tile_engine_bit_for_bit(case):
+    """The 256 x 256 ping-pong engine (one tile per workgroup: 20, persistent: 26 -- the forward's choice from 16 384 padded rows on) and the 16-wave 256 x 256 tile (16) contract K in the
+    same order per output element as the 128 x 256 tile (4): hi then lo plane per 32-column block, blocks in order.  The engine choice is a speed decision; what changes results at
+    16 384 rows is the fused LayerNorm epilogue alone."""
+    M, K, N, act, planes = case
+    l = lib.load()
+    a = weights.normal("vpp/a/%d/%d" % (M, K), (M, K), 1)
+    w = weights.round_to_bf16(weights.normal("vpp/w/%d/%d" % (N, K), (N, K), 1, 1.0 / np.sqrt(K)))
+    bias = weights.normal("vpp/b/%d" % N, (N,), 1, 0.1)
+    da, dw, db = _dev(a), _dev(w), _dev(bias)
+    outs = {}
+    for v in (4, 20, 26, 16):
+        out = torch.empty((M, N), device="cuda", dtype=torch.float32)
+        rc = l.mms_dbg_gemm(da.data_ptr(), M, K, K, dw.data_ptr(), N, db.data_ptr(), None, act, 2, int(planes), v, out.data_ptr(), None)
+        assert rc == 0, l.mms_global_error()
+        outs[v] = out.cpu().numpy()
+    for v in (20, 26, 16):
+        assert np.array_equal(outs[v], outs[4]), (case, v, float(np.abs(outs[v] - outs[4]).max()))
+
+
 ATT_CASES = [(7, 30, 30, True), (5, 40, 40, False), (6, 23, 23, True), (9, 10, 10, True), (4, 23, 10, True),
              (4, 10, 23, True), (3, 1, 1, False), (2, 17, 33, True)]
 

@@ -196,9 +196,9 @@ def test_full_size_workload_properties(name):
 def test_testB_like_set_single_gpu_matches_shardwise_scoring():
     """994 queries x 8..30 candidates (run_pretraining_predict_score.py:566): scoring the whole job equals scoring each of 8
     contiguous query blocks on its own (what 8 ranks do) -- pairs are independent, shard boundaries are inert.  Not bit for bit at
-    THIS size: the GEMM engine is chosen per launch by its row count (M >= 16384 rows: persistent ping-pong tiles, below: register-
-    staged tiles; gemm_dispatch.hip), and the two engines sum K in different orders, so a 29 k-pair launch and a 3.6 k-pair launch
-    differ in fp32 round-off (~1e-5 relative on the logits).  Launches in the same regime ARE bit-identical
+    THIS size: the launch plan is chosen per launch by its row count (M >= 16384 rows: LayerNorm in the GEMM epilogue with a one-pass
+    variance, below: split-K partials summed by the LayerNorm kernel; the split-bf16 attention route depends on a pair's place in its launch),
+    so a 29 k-pair launch and a 3.6 k-pair launch differ in fp32 round-off (~1e-5 relative on the logits).  Launches in the same regime ARE bit-identical
     (test_multirank_gpu.py compares ranks against a single rank that way)."""
     from kddcup_2020_multimodalitiesrecall_2nd_place_amd import sharding
     cfg = ZkConfig(layers=2)
