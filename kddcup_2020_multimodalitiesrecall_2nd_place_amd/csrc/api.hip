@@ -1448,7 +1448,7 @@ int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int
     }
     // One chunk, one sub-batch, a small call (two lanes): the stage runs on the side lane beside the chunk's box-stream prologue and r_layers (lx_chunk joins
     // before it copies the language rows out of lq_store).  The stage's rows [0, Q T) of x / y / ctx / qkv / t lie inside the chunk's language rows, which the
-    // chunk does not touch before the join; the plan scratch is shared, so a stage big enough for the fused attention kernel's table stays on the main lane.
+    // chunk does not touch before the join; its packed plan, its sub-tile table and the plan scratch are its own.
     const int64_t R = B * (T + MMS_NBOX);
     // (mid: the main lane needs the box rows' share until the join -- split features, then the r_layers' FFN intermediate -- and the stage's rows follow it)
     const bool side = h->lanes_q && B <= cs && Q <= cs && (B * MMS_NBOX + Q * T) * (int64_t)c.inter <= h->mid_elems;
