@@ -203,14 +203,14 @@ int mms_finalize(mms_handle* h);
  *                            logits then depend on its place in the launch by fp32 round-off (<= 1e-4 relative), so calls of >= 1024 token rows are bit-identical across batch
  *                            compositions only with fuse_attention <= 1
  *   rows <  16384            register-staged / LDS-DMA 128 x 256 tiles (bit-identical to each other), one pass over K
- *   rows >= 16384            persistent ping-pong engines (same contraction order per element as the tiles: bit-identical, tested); what changes results here is
- *                            mms_config.fuse_layernorm: bias + residual + LayerNorm in the GEMM epilogue (one-pass variance) -- except in
+ *   rows >= 16384            persistent ping-pong engines for every projection (same contraction order per element as the tiles: bit-identical, tested)
+ *   rows >= 98304            mms_config.fuse_layernorm: bias + residual + LayerNorm in the GEMM epilogue (one-pass variance; below, the LayerNorm kernel is faster) -- except in
  *                            lxmert calls of fewer than 400 000 token rows (pairs x (text_len + 10); ~12 500 pairs), which run their two streams' launch chains side by
  *                            side on two lanes and leave every LayerNorm to its own kernel (the fused epilogue needs its whole grid resident)
  * Batch composition enters in two more places: lxmert with pack_tokens runs its language layers once per DISTINCT query when at least half of the pairs
  * share theirs (the rows of that stage = distinct queries x text_len), and label texts are encoded once per distinct 8-id tuple (rows = tuples).
  * mms_score_ensemble runs the three members of a launch wave of fewer than 5000 pairs side by side on three streams (same rule: every LayerNorm by its own kernel; a member's
- * scores equal the single-model call's bit for bit wherever that call would not have used the fused epilogue either, i.e. below 16384 token rows).
+ * scores equal the single-model call's bit for bit wherever that call would not have used the fused epilogue either, i.e. below 98304 token rows).
  * lxmert's two launch lanes (a side stream between fork / join events: the vision stream's sub-layers beside the language stream's between two cross attentions, the
  * distinct-query stage beside the box stream's layers) run the same kernels on the same operands: no numerical effect beyond the LayerNorm route named above.
  * Not numerical boundaries (same arithmetic, tested bit-identical): the ping-pong engine taken for the wide projections (N >= 1536) from 5120 rows on and for every

@@ -772,12 +772,25 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
 // out = LayerNorm(A W^T + bias + resid) for the N = 768 projections, the LayerNorm fused into the GEMM epilogue when the launch is big
 // enough for the persistent ping-pong engine (gemm_pp_ln.h).  Returns MMS_OK with *fused = false when the caller has to take the
 // two-kernel route itself (small M, precision modes 1 / 3, no control slot left).
+// Padded row bound of the fused bias + residual + LayerNorm epilogue.  Rounds 2-4: 16 384 (with the persistent engines).  Its tile carries eight residual K stages and a statistics exchange across the
+// three column tiles of a row panel; on a launch of a round or two that is latency the LayerNorm kernel does not add: with the two-kernel route zk takes 4.15 instead of 4.75 ms at 600 pairs, 6.33 / 6.99 at
+// 1024, 11.4 / 12.0 at 2048 and 19.7 / 19.5 at 4096 (122 880 rows: the epilogue wins from here on); lds 5.69 / 6.39 at 512, 10.6 / 11.8 at 1024, a tie at 2048 (81 920 rows) -- profiles/rd5_fuse_ln_midsize.txt
+constexpr int64_t LNF_ROWS_DEFAULT = 98304;
+int64_t lnf_rows() {
+#ifdef MMS_LAB
+    static const int64_t v = getenv("MMS_LNF_ROWS") ? atoll(getenv("MMS_LNF_ROWS")) : LNF_ROWS_DEFAULT;
+    return v > pp_rows() ? v : pp_rows();
+#else
+    return LNF_ROWS_DEFAULT;
+#endif
+}
+
 int gemm_ln(mms_handle* h, hipStream_t st, bool f8, const Planes& a, int lda, const bf16* w, const unsigned char* w8, const unsigned* wscale,
             const float* bias, int64_t M, int K, const Planes& resid, const float* g, const float* b, const Planes& out, float* t,
             const int* m_dev, bool* fused) {
     *fused = false;
     // mms_config.fuse_layernorm is a mask: bit 0 the attention-output projections (K = 768), bit 1 the FFN-down projections (K = inter)
-    if (!(h->fuse_ln & (K == H ? 1 : 2)) || f8 || M < pp_rows() || h->nsplit != 2 || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
+    if (!(h->fuse_ln & (K == H ? 1 : 2)) || f8 || M < lnf_rows() || h->nsplit != 2 || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
     // two launch lanes: the fused epilogue needs its whole grid resident (the column tiles of a row panel exchange statistics) and falls back to the LayerNorm
     // kernel when it is not -- beside another lane's persistent kernel that would be decided by timing.  A call on two lanes takes the two-kernel route throughout.
     if (h->lanes_on || h->lane || h->lq_join_pending) return MMS_OK;      // (lq_join_pending: the distinct-query stage is running on the side lane)

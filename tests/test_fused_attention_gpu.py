@@ -107,7 +107,8 @@ def test_default_is_the_fused_route_for_all_three_models():
         cfg = CFGS[name]()
         w = weights.make_weights(cfg)
         # (lxmert: 13 500 pairs = 432 000 token rows -- below 400 000 its calls run on two launch lanes and leave the LayerNorm to its own kernel, api.hip LANE_ROWS)
-        ps, b = _feed(cfg, 450 if name == "lxmert" else 100, 30, "/fuseattn4")
+        # (zk / lds: 3600 pairs = 108 000 / 144 000 token rows -- the fused LayerNorm epilogue starts at 98 304, api.hip LNF_ROWS)
+        ps, b = _feed(cfg, 450 if name == "lxmert" else 120, 30, "/fuseattn4")
         s = scorers.make_scorer(cfg, w, precision=2)
         assert s.fuse_attention == 2
         scorers.score_batch(s, b)
