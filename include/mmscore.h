@@ -202,7 +202,7 @@ int mms_finalize(mms_handle* h);
  *                            to it.  2 (the scorers' default in precision mode 2): split-bf16 attention over 16-query tiles of a packed sub-tile, online softmax -- a pair's
  *                            logits then depend on its place in the launch by fp32 round-off (<= 1e-4 relative), so calls of >= 1024 token rows are bit-identical across batch
  *                            compositions only with fuse_attention <= 1
- *   rows <  16384            register-staged / LDS-DMA 128 x 256 tiles (bit-identical to each other), one pass over K
+ *   rows <  16384            register-staged / LDS-DMA 128 x 256 tiles (bit-identical to each other), one pass over K (FFN-down, K = 3072: 2 slices from 11264 rows on)
  *   rows >= 16384            persistent ping-pong engines for every projection (same contraction order per element as the tiles: bit-identical, tested)
  *   rows >= 98304            mms_config.fuse_layernorm: bias + residual + LayerNorm in the GEMM epilogue (one-pass variance; below, the LayerNorm kernel is faster) -- except in
  *                            lxmert calls of fewer than 400 000 token rows (pairs x (text_len + 10); ~12 500 pairs), which run their two streams' launch chains side by

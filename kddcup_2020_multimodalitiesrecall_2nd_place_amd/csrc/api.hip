@@ -870,8 +870,19 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
 constexpr int64_t SPLITK_ROWS = 8192;      // padded row bound of the launch (the live count is on the device): zk calls of <= 273 pairs
 constexpr int KSPLIT_MAX = 8;
 constexpr int64_t SPLITK_HALF_ROWS = 4096;
+constexpr int64_t SPLITK2_LO_ROWS = 11264;
 int splitk_for(const mms_handle* h, int64_t M, int K) {
-    if (M >= SPLITK_ROWS || h->nsplit == 1 || h->f8) return 1;
+    if (h->nsplit == 1 || h->f8) return 1;
+    // 8192 .. 16383 rows: one pass over K -- except K = 3072 (FFN-down) from 11 264 rows on, in 2 slices: unsplit it is 130 .. 190 live workgroups walking 48 K steps on 256 CUs
+    // (zk 400 / 520 pairs 3.63 -> 3.41 / 3.85 -> 3.71 ms, lxmert 600 pairs 3.85 -> 3.67; below 11 264 rows lds' fuller launches lose 3 %: profiles/rd5_splitk_midsize.txt)
+    if (M >= SPLITK_ROWS) {
+        int64_t lo = SPLITK2_LO_ROWS;
+        int s2 = 2;
+#ifdef MMS_LAB
+        { static const int64_t e = getenv("MMS_SPLITK2_LO_ROWS") ? atoll(getenv("MMS_SPLITK2_LO_ROWS")) : 0; if (e) lo = e; }
+#endif
+        return (K >= 2048 && M >= lo && M < pp_rows() && K % (64 * s2) == 0) ? s2 : 1;
+    }
     // K = 3072 (FFN-down): 8 slices up to 4095 rows, 4 from there on -- at 256 zk pairs (7680 padded rows) 8 slices are 744 workgroups of 6 K steps and 95 MB of partials for the
     // LayerNorm kernel to sum; 4 slices: zk 2.38 -> 2.19 ms per 256-pair call, lds 2.57 -> 2.38 at 150 pairs, neutral at 100 zk pairs (profiles/rd5_splitk_midsize.txt)
     int S = K >= 2048 ? (M >= SPLITK_HALF_ROWS ? 4 : 8) : 4;

@@ -14,9 +14,9 @@ from oracle import np_models as O
 pytestmark = pytest.mark.gpu
 
 # pairs per launch wave so that wave rows = pairs x S straddle 256 / 4096 (box rows = pairs x 10) / 8192 / 16 384
-WAVES = {"zk": [4, 5, 34, 35, 136, 137, 273, 274, 409, 410, 546, 547],  # S = 30: 120 | 150 (skinny kernel <= 128 rows), 1020 | 1050, 4080 | 4110 (FFN-down in 8 | 4 K slices), 8190 | 8220, box rows 4090 | 4100, 16 380 | 16 410
-         "lds": [3, 4, 25, 26, 102, 103, 204, 205, 409, 410],          # S = 40: 120 | 160, 1000 | 1040, 4080 | 4120, 8160 | 8200, 16 360 | 16 400
-         "lxmert": [6, 7, 51, 52, 204, 205, 409, 410, 819, 820]}       # language rows S = 20: 120 | 140, 1020 | 1040, 4080 | 4100, 8180 | 8200, 16 380 | 16 400; vision rows (10 per pair) 4090 | 4100, 8190 | 8200
+WAVES = {"zk": [4, 5, 34, 35, 136, 137, 273, 274, 375, 376, 409, 410, 546, 547],     # (375 | 376: 11 250 | 11 280 rows, FFN-down unsplit | in 2 K slices)  # S = 30: 120 | 150 (skinny kernel <= 128 rows), 1020 | 1050, 4080 | 4110 (FFN-down in 8 | 4 K slices), 8190 | 8220, box rows 4090 | 4100, 16 380 | 16 410
+         "lds": [3, 4, 25, 26, 102, 103, 204, 205, 281, 282, 409, 410],          # S = 40: 120 | 160, 1000 | 1040, 4080 | 4120, 8160 | 8200, 16 360 | 16 400
+         "lxmert": [6, 7, 51, 52, 204, 205, 409, 410, 489, 490, 819, 820]}       # language rows (text_len per pair) around 128, 1024, 4096, 8192, 11 264 (FFN-down in 1 | 2 K slices), 16 384; vision rows (10 per pair) 4090 | 4100, 8190 | 8200
 
 
 @pytest.mark.parametrize("name", ["zk", "lds", "lxmert"])
