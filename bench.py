@@ -166,7 +166,7 @@ def run_timed(step, steps, warmup, world, dev, handles):
         h.gemm_timing(True, True)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -174,7 +174,7 @@ def run_timed(step, steps, warmup, world, dev, handles):
         step()
         ev[i][1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     dt = time.perf_counter() - t0
     per = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
@@ -192,7 +192,7 @@ def run_timed(step, steps, warmup, world, dev, handles):
                 cls[c][i] += v
         ms, n, fl = h.gemm_timing(False, True, read=True)
         gms += ms; gn += n; gfl += fl
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt, med], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, med = float(t[0].item()), float(t[1].item())
@@ -334,7 +334,10 @@ def main():
         # that failed to give each rank its own GPU -- the device check below must refuse it
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    # under a launcher (RANK / MASTER_PORT set) the process group comes up even for ONE rank and the step's score gather goes through the
+    # collective: `torchrun --nproc-per-node 1 bench.py --gpus 1` runs the RCCL calls of an N-GPU job on a single-GPU box
+    use_pg = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # backend "nccl" == RCCL over xGMI; MMS_BENCH_BACKEND=gloo (+ MMS_BENCH_SHARE_GPU=1) only exists for single-GPU test boxes
         # the process-group backends announce themselves on stdout ("[Gloo] Rank 0 is connected to ..."): the contract is ONE line
@@ -354,7 +357,7 @@ def main():
     # N > 1: the line proves where its ranks ran -- every rank reports the device it holds; two "nccl" ranks on one device is an error
     # (only the single-GPU test mode, MMS_BENCH_SHARE_GPU + gloo, may share), not a silently meaningless scaling number
     rank_devices = None
-    if world > 1:
+    if use_pg:
         pr = torch.cuda.get_device_properties(local)
         me = {"rank": rank, "hip_device": local, "name": pr.name,
               "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0xff), getattr(pr, "pci_device_id", 0xff)),
@@ -412,9 +415,9 @@ def main():
 
         def step(first=False):
             sc = score()
-            if world > 1:
+            if use_pg:
                 sc = sc.to(gather_dev)
-                return sharding.gather_scores(sc, qid if first else None, pid if first else None, counts=counts_)
+                return sharding.gather_scores(sc, qid if first else None, pid if first else None, counts=counts_, force_collective=True)
             return sc, None, None
         return step, feats_, feed_
 
@@ -518,7 +521,7 @@ def main():
                                          "note": "all kernels of the step (GEMMs, fused QKV + attention, row kernels, bookkeeping) in the denominator"}
         if strong is not None:
             res["strong"] = strong
-        if world > 1:
+        if use_pg:
             try:
                 ccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
             except Exception:        # noqa: BLE001 -- a version string is not worth a failed bench
@@ -544,7 +547,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(cfg0, w0, hip_logits, budget_s=a.cpu_budget)
         print(json.dumps(res), flush=True)
     scorer.close()
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

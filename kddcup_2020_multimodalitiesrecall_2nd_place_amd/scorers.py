@@ -8,6 +8,8 @@ replaces, so the reference's predict drivers can call it unchanged:
 * ``LdsScorer.__call__``     <- ``bertmodel(..., features, ...)`` (code/imagebert_lds/src/run_pretraining_predict_score.py:288-336)
                                -> ``next_sentence_prob[B,2]``
 * ``LxmertScorer.forward``   <- ``KDDModel.forward`` (code/lxmert/src/tasks/kdd_model.py:183-214) -> ``(x_norm[B,768], None, logit[B,2])``
+* ``KDDModel``               <- the same class as ``KDD`` drives it (kdd_model.py:28-43,54,131-152): no-argument constructor, ``.cuda()``,
+                               ``.eval()``, ``state_dict()``, ``load_state_dict(sd, strict=False)``, ``model(...)``
 * ``EnsembleScorer``         <- what ``code/main.py:41-59`` merges: the four members on the same pairs, one C call
 
 All arithmetic of the forward runs in libmmscore (HIP, gfx950), including the de-duplication of the label-text tuples
@@ -194,6 +196,136 @@ class LxmertScorer(_Base):
         return (x_norm.cpu().numpy() if as_np else x_norm, None, logits.cpu().numpy() if as_np else logits)
 
     __call__ = forward
+
+
+class KDDModel(torch.nn.Module):
+    """``tasks.kdd_model.KDDModel`` as its callers use it (code/lxmert/src/tasks/kdd_model.py:25-60,86-103,131-152): built with no
+    arguments, ``.cuda()`` / ``.to()`` / ``.eval()`` return the module, ``state_dict()`` lists the reference's tensors (470 at full size:
+    ``weights.kdd_state_dict_shapes``), ``load_state_dict(sd, strict=False)`` takes a ``torch.load('BEST.pth')`` (``module.`` prefixes of a
+    DataParallel save accepted) and ``model(...)`` is the 9-argument ``KDDModel.forward`` -> ``(x_norm, None, logit)``.
+
+    An ``nn.Module`` without parameters: the tensors live on the host as the checkpoint holds them (fp32) and, once a forward needs them,
+    inside one ``mms_handle`` (``LxmertScorer``); a ``load_state_dict`` after that re-creates the handle at the next forward.  A fresh
+    instance holds this repo's seeded synthetic weights (the reference: ``init_bert_weights`` noise, kdd_model.py:172) -- every real use
+    loads a checkpoint next (``KDD.__init__`` -> ``self.load(args.load)``, :36-37).  ``logit_W`` and the MLM heads ``cls.*`` are carried
+    for the round trip and never reach the device: the predict path reads ``logit_fc`` (``task_amsloss`` off, :207-212), and
+    ``lang_prediction_scores`` is discarded by every caller.  Inference only: ``train(True)`` raises; there is no CPU forward."""
+
+    def __init__(self, cfg=None, weights=None, device=None, **scorer_kw):
+        super().__init__()
+        from .config import LxmertConfig
+        self.cfg = cfg if cfg is not None else LxmertConfig()        # args.llayers / xlayers / rlayers = 9 / 5 / 5 (param.py:72-74)
+        self.config = self.cfg                                       # kdd_model.py:164
+        self.training = False
+        self._scorer_kw = scorer_kw
+        self._device = device                                        # None until .cuda() / .to() or the first forward picks one
+        self._host = None                                            # {name: np.float32 array}: the checkpoint as loaded
+        self._scorer = None
+        self._stale = True
+        if weights is not None:
+            self.load_state_dict(weights, strict=False)
+
+    # -- host-side tensors -----------------------------------------------------------------------
+    def _tensors(self):
+        if self._host is None:
+            from . import weights as W
+            shapes = W.kdd_state_dict_shapes(self.cfg)
+            host = {k: np.array(v) for k, v in W.make_weights(self.cfg).items()}      # private, writeable copies of the memoised arrays
+            for k, shp in shapes.items():
+                if k not in host:
+                    host[k] = W.normal("kdd/" + k, shp, 20200823, std=0.02) if k == "logit_W" else np.zeros(shp, np.float32)
+            host["cls.predictions.decoder.weight"] = host["lxrt_encoder.model.bert.embeddings.word_embeddings.weight"]   # tied
+            self._host = {k: host[k] for k in shapes}
+        return self._host
+
+    def state_dict(self, destination=None, prefix="", keep_vars=False):
+        import collections
+        out = collections.OrderedDict() if destination is None else destination
+        for k, v in self._tensors().items():
+            out[prefix + k] = torch.from_numpy(v)                    # shares the host copy, like Module.state_dict(); the DEVICE copy follows
+        return out                                                   # load_state_dict only -- in-place edits of these tensors do not reach it
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        from . import weights as W
+        from torch.nn.modules.module import _IncompatibleKeys
+        shapes = W.kdd_state_dict_shapes(self.cfg)
+        got, unexpected, errors = {}, [], []
+        for k, v in state_dict.items():
+            name = k[7:] if k.startswith("module.") else k
+            if name not in shapes:
+                unexpected.append(k)
+                continue
+            a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            if tuple(a.shape) != tuple(shapes[name]):
+                errors.append("size mismatch for %s: copying a param with shape %s from checkpoint, the shape in current model is %s."
+                              % (name, tuple(a.shape), tuple(shapes[name])))
+                continue
+            got[name] = np.array(a, dtype=np.float32, order="C")     # a private copy, like Module.load_state_dict's copy_
+        missing = [k for k in shapes if k not in got]
+        if strict and (missing or unexpected):
+            errors.insert(0, "Missing key(s) in state_dict: %s. Unexpected key(s) in state_dict: %s." % (missing[:8], unexpected[:8]))
+        if errors:
+            raise RuntimeError("Error(s) in loading state_dict for KDDModel:\n\t" + "\n\t".join(errors))
+        if got:
+            host = dict(self._tensors())
+            host.update(got)
+            self._host = host
+            self._stale = True
+        return _IncompatibleKeys(missing, unexpected)
+
+    # -- nn.Module protocol the reference's driver touches ---------------------------------------
+    def train(self, mode: bool = True):
+        if mode:
+            raise _lib.MmsError("KDDModel drop-in is inference only (kdd_model.py:54 calls .eval())")
+        self.training = False
+        return self
+
+    def cuda(self, device=None):
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        return self._place(torch.device("cuda", device) if isinstance(device, int) else torch.device(device))
+
+    def to(self, *args, **kwargs):
+        dev = kwargs.get("device", next((a for a in args if isinstance(a, (str, torch.device, int))), None))
+        if dev is None:
+            return self                                              # dtype-only moves: the arithmetic is the library's, nothing to cast
+        return self._place(torch.device(dev) if not isinstance(dev, int) else torch.device("cuda", dev))
+
+    def cpu(self):
+        raise _lib.MmsError("KDDModel drop-in has no CPU forward (the reference's CPU path is what oracle/ restates)")
+
+    def _place(self, dev):
+        if dev.type != "cuda":
+            return self.cpu()
+        idx = dev.index if dev.index is not None else 0
+        if self._device != idx:
+            self._device, self._stale = idx, True
+        return self
+
+    def _live(self):
+        if self._scorer is None or self._stale:
+            from . import weights as W
+            if self._scorer is not None:
+                self._scorer.close()
+            used = W.expected_shapes(self.cfg)
+            t = self._tensors()
+            self._scorer = LxmertScorer(self.cfg, {k: t[k] for k in used}, device=self._device or 0, **self._scorer_kw)
+            self._stale = False
+        return self._scorer
+
+    def forward(self, input_ids, boxes_label_input_ids, segment_ids, input_mask, boxes_label_segment_ids,
+                boxes_label_input_mask, feats, boxes, visual_attention_mask):
+        return self._live().forward(input_ids, boxes_label_input_ids, segment_ids, input_mask, boxes_label_segment_ids,
+                                    boxes_label_input_mask, feats, boxes, visual_attention_mask)
+
+    def close(self):
+        if self._scorer is not None:
+            self._scorer.close()
+            self._scorer = None
+            self._stale = True
+
+
+KDDModelDropIn = KDDModel
 
 
 class EnsembleScorer:

@@ -38,14 +38,20 @@ def shard_sizes(query_of_pair: np.ndarray, n_queries: int, world: int):
     return out
 
 
-def gather_scores(scores: torch.Tensor, query_id: torch.Tensor = None, product_id: torch.Tensor = None, group=None, counts=None):
+def gather_scores(scores: torch.Tensor, query_id: torch.Tensor = None, product_id: torch.Tensor = None, group=None, counts=None,
+                  force_collective: bool = False):
     """All-gather ragged per-rank score vectors.  Returns (scores, query_id, product_id) concatenated in
     rank order on every rank.  One collective for the scores (padded to the max shard) and, when ids
     are given, one more for the packed int64 ids.
 
     ``counts``: the per-rank shard sizes (``shard_sizes``), static for a job.  With them a step is ONE collective and no
-    host synchronisation; without them the sizes are exchanged first (an extra small all-gather and a host read)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    host synchronisation; without them the sizes are exchanged first (an extra small all-gather and a host read).
+
+    ``force_collective``: run the collective even in a world of one rank (where the result is the input) -- the same RCCL calls an 8-GPU job
+    issues, on the one GPU a test box has (tests/test_rccl_world1_gpu.py; ``bench.py`` under a launcher with WORLD_SIZE=1)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return scores, query_id, product_id
+    if dist.get_world_size(group) == 1 and not force_collective:
         return scores, query_id, product_id
     world = dist.get_world_size(group)
     if counts is None:

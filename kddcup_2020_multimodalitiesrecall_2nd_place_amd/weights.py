@@ -272,6 +272,35 @@ def _shapes_from_generator(cfg):
     return dict(g.out)
 
 
+def kdd_state_dict_shapes(cfg) -> dict:
+    """{name: shape} of ``KDDModel().state_dict()`` in the reference's own order (code/lxmert/src/tasks/kdd_model.py:154-181: ``logit_W`` is
+    registered before any sub-module output shows up, then ``lxrt_encoder`` -- embeddings, ``visn_fc``, ``layer``, ``x_layers``, ``r_layers``,
+    pooler (lxrt/modeling.py:540-571,856-861) --, ``logit_fc``, and the MLM / relationship heads ``cls.*`` (modeling.py:648-676; the decoder
+    matrix is the word-embedding table, tied).  The scorer reads ``expected_shapes(cfg)`` of these; ``logit_W`` and ``cls.*`` are carried so that a
+    checkpoint round-trips.  Pinned to the reference's key list by tests/test_kdd_dropin.py (fixture meta of lxmert_fp32ckpt.npz)."""
+    used = _shapes_from_generator(cfg)
+    b = "lxrt_encoder.model.bert."
+    out = {"logit_W": (HIDDEN, 2)}
+    groups = ("embeddings.", "encoder.visn_fc.", "encoder.layer.", "encoder.x_layers.", "encoder.r_layers.", "pooler.")
+    for g in groups:                      # the generator emits r_layers before x_layers; the module registers x_layers first
+        for k, shp in used.items():
+            if k.startswith(b + g):
+                out[k] = shp
+    for k, shp in used.items():
+        if k.startswith("logit_fc."):
+            out[k] = shp
+    assert len(out) == len(used) + 1, "a scorer tensor is outside the KDDModel key groups"
+    out["cls.predictions.bias"] = (cfg.vocab,)
+    out["cls.predictions.transform.dense.weight"] = (HIDDEN, HIDDEN)
+    out["cls.predictions.transform.dense.bias"] = (HIDDEN,)
+    out["cls.predictions.transform.LayerNorm.weight"] = (HIDDEN,)
+    out["cls.predictions.transform.LayerNorm.bias"] = (HIDDEN,)
+    out["cls.predictions.decoder.weight"] = (cfg.vocab, HIDDEN)
+    out["cls.seq_relationship.weight"] = (2, HIDDEN)
+    out["cls.seq_relationship.bias"] = (2,)
+    return out
+
+
 def from_torch_state_dict(cfg, state_dict) -> dict:
     """lxmert: ``torch.load('BEST.pth')`` / ``KDDModel.state_dict()`` (code/lxmert/src/tasks/kdd_model.py:131-152) ->
     container.  Unused heads (``cls.*``, ``logit_W``) and DataParallel ``module.`` prefixes are dropped."""
