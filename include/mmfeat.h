@@ -30,6 +30,10 @@ typedef struct mmf_context mmf_context;
 
 /* vocab: one token per line (id = line number).  max_chars: 200 (zk/lds tokenization.py:299) or 100 (lxmert).
  * never_split_specials: 1 = keep "[CLS]" "[SEP]" "[PAD]" "[UNK]" "[MASK]" whole (lxmert's HF tokenizer), 0 = stock BERT. */
+/* base64 decoder tier: 0 scalar tables, 1 AVX2, 2 AVX-512 VBMI; the best one the CPU has is chosen at load.  set_to >= 0 selects one
+ * (process-wide; tests run every tier against the scalar one), < 0 only reports.  Returns the tier in use, or -1. */
+int mmf_b64_tier(int32_t set_to);
+
 int mmf_create(const char* vocab_path, int32_t max_chars, int32_t never_split_specials, mmf_context** out);
 void mmf_destroy(mmf_context* c);
 const char* mmf_last_error(void);
@@ -52,11 +56,15 @@ typedef struct mmf_batch_out {
     int32_t* query_len;         /* [B]  untruncated length incl. [CLS] [SEP] */
     uint8_t* needs_host_tokenizer; /* [B] 1 = query has non-ASCII bytes, query_ids/query_len not filled */
     int64_t* query_span;        /* [B,2] byte range of the query field inside `data` (for the host tokenizer) */
+    int32_t* feat_rows_live;    /* [B] or NULL.  In: how many leading box rows of feats[i] may be non-zero (a fresh buffer: 10); out: the
+                                 * record's box count.  With it the zero padding of a REUSED buffer is written only where the row's
+                                 * previous record left data (60 % of the bytes of a row at 3.8 boxes per record); NULL: always. */
 } mmf_batch_out;
 
 /* lines: `n` records in one buffer, record i = data[offsets[i] .. offsets[i+1]) (no trailing newline needed).
- * Work is split over `threads` std::threads (<= 0: hardware concurrency).  Every output row is fully written
- * (padding zeroed).  Returns 0, or -1000 - index of the first malformed record (message in mmf_last_error). */
+ * Work is split over `threads` threads (<= 0: hardware concurrency): the caller plus helper threads the context keeps
+ * between calls.  Every output row is fully written (padding zeroed; see feat_rows_live).  Calls on one context run one
+ * at a time.  Returns 0, or -1000 - index of the first malformed record (message in mmf_last_error). */
 int mmf_featurize(const mmf_context* c, const char* data, const int64_t* offsets, int64_t n, int32_t text_len,
                   int32_t box_dim, int32_t sen2forest, int32_t threads, const mmf_batch_out* out);
 
@@ -68,6 +76,18 @@ int mmf_featurize_spans(const mmf_context* c, const char* data, const int64_t* s
  * lines and lines containing "product_id" (the header test of code/lxmert/src/tasks/kdd_data.py:70-71).  *consumed = bytes of
  * `data` covered (resume the next call there).  Returns the number of records found, or -1. */
 int64_t mmf_split_lines(const char* data, int64_t len, int64_t* starts, int64_t* ends, int64_t max_lines, int64_t* consumed);
+
+/* Map the pages of [addr, addr + len) -- a read-only file mapping about to be split and decoded -- on `threads` threads
+ * (MADV_POPULATE_READ per 2 MB piece).  A 50 KB record is ~12 pages; left to demand faulting, the ONE thread that splits
+ * lines takes the faults of the whole file (fault-around maps the rest of each record with its head), which bounded the
+ * 256-thread decode at ~450 k records/s (profiles/rd6_feat_sweep.txt).  Returns 0. */
+int mmf_prefault(const mmf_context* c, const void* addr, int64_t len, int32_t threads);
+
+/* [addr, addr + len) of a read-only FILE mapping has been decoded and will not be read again: the next mmf_featurize* call on
+ * this context drops those pages from the page table (madvise MADV_DONTNEED, whole pages inside the range) on one of its threads
+ * while the others decode.  Unmapping a 2.5 GB file at the end instead is 30 ms of serial kernel work -- a third of the pass
+ * (profiles/rd6_feat_sweep.txt).  The data stays in the page cache; touching the range again simply faults it back in. */
+int mmf_release_later(const mmf_context* c, const void* addr, int64_t len);
 
 #ifdef __cplusplus
 }

@@ -17,23 +17,25 @@ from .config import FEAT_DIM, LABEL_LEN, N_BOX
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmmfeat.so")
 EXPORTS = ("mmf_create", "mmf_destroy", "mmf_last_error", "mmf_set_label", "mmf_tokenize_ascii", "mmf_featurize",
-           "mmf_featurize_spans", "mmf_split_lines")
+           "mmf_featurize_spans", "mmf_split_lines", "mmf_b64_tier", "mmf_prefault", "mmf_release_later")
 
 
 class BatchOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("product_id", "query_id", "num_boxes", "boxes", "feats", "label_ids", "label_len",
-                                          "query_ids", "query_len", "needs_host_tokenizer", "query_span")]
+                                          "query_ids", "query_len", "needs_host_tokenizer", "query_span", "feat_rows_live")]
 
 
 _lib = None
 
 
-def load():
+def load(path=None):
+    """dlopen libmmfeat.so (``path``: another build of it -- tools/feat_bench.py's A/B against an older revision)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("native featurizer missing: %s (run __graft_entry__.build())" % LIB_PATH)
-        l = C.CDLL(LIB_PATH)
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise RuntimeError("native featurizer missing: %s (run __graft_entry__.build())" % path)
+        l = C.CDLL(path)
         l.mmf_last_error.restype = C.c_char_p
         l.mmf_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         l.mmf_destroy.argtypes = [C.c_void_p]
@@ -46,6 +48,10 @@ def load():
                                           C.c_int32, C.POINTER(BatchOut)]
         l.mmf_split_lines.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         l.mmf_split_lines.restype = C.c_int64
+        if path == LIB_PATH or hasattr(l, "mmf_b64_tier"):      # (a round-5 build handed to load() for an A/B has neither)
+            l.mmf_b64_tier.argtypes = [C.c_int32]
+            l.mmf_prefault.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+            l.mmf_release_later.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         _lib = l
     return _lib
 
@@ -77,6 +83,8 @@ class NativeFeaturizer:
         self.py_tok = F.WordPieceTokenizer(vocab_path, max_input_chars_per_word=100 if hf else 200,
                                            never_split=F.SPECIALS if hf else ())
         self.threads, self.pinned = threads, pinned
+        self.stats = {}                                   # seconds per stage, accumulated by iter_spans / _run
+        self.prefault = True                              # iter_spans maps a batch's pages in parallel before splitting it (mmf_prefault)
         self._h = C.c_void_p()
         if self.lib.mmf_create(vocab_path.encode(), 100 if hf else 200, int(hf), C.byref(self._h)) != 0:
             raise RuntimeError("mmf_create: " + self.lib.mmf_last_error().decode())
@@ -108,6 +116,10 @@ class NativeFeaturizer:
         if n > self._caps[t]:
             self._caps[t] = max(n, 2 * self._caps[t])
             self._pools[t] = {k: _host(shape, dt, self.pinned) for k, (shape, dt) in self._spec(self._caps[t]).items()}
+            # mmf_batch_out.feat_rows_live: a fresh buffer holds anything -> every box row counts as dirty; from then on the library keeps
+            # the count per row, and only the part of the zero padding that a previous record wrote over is written again
+            live = np.full(self._caps[t], N_BOX, np.int32)
+            self._pools[t]["feat_rows_live"] = (live, live)
         return {k: v[0][:n] for k, v in self._pools[t].items()}, {k: v[1] for k, v in self._pools[t].items()}
 
     def featurize(self, lines, sen2forest: bool = False) -> dict:
@@ -128,11 +140,16 @@ class NativeFeaturizer:
         starts, ends = np.ascontiguousarray(starts, np.int64), np.ascontiguousarray(ends, np.int64)
         n, T = len(starts), self.text_len
         arr, keep = self._buffers(n)
-        out = BatchOut(*[arr[k].ctypes.data for k in ("product_id", "query_id", "num_boxes", "boxes", "feats", "label_ids",
-                                                      "label_len", "query_ids", "query_len", "needs_host_tokenizer", "query_span")])
+        live = arr.pop("feat_rows_live", None)                    # reused buffer sets only
+        out = BatchOut(*([arr[k].ctypes.data for k in ("product_id", "query_id", "num_boxes", "boxes", "feats", "label_ids",
+                                                       "label_len", "query_ids", "query_len", "needs_host_tokenizer", "query_span")]
+                         + [live.ctypes.data if live is not None and n else None]))
         if n:
+            import time
+            t0 = time.perf_counter()
             rc = self.lib.mmf_featurize_spans(self._h, base, starts.ctypes.data, ends.ctypes.data, n, T, self.box_dim, int(sen2forest),
                                               self.threads, C.byref(out))
+            self.stats["decode"] = self.stats.get("decode", 0.0) + time.perf_counter() - t0
             if rc != 0:
                 raise ValueError("mmf_featurize failed (%d): %s" % (rc, self.lib.mmf_last_error().decode()))
         for i in np.nonzero(arr["needs_host_tokenizer"])[0]:      # non-ASCII queries: full Unicode tokenizer
@@ -149,27 +166,50 @@ class NativeFeaturizer:
     def iter_spans(self, path: str, batch_lines: int = 8192):
         """Stream a TSV file as record spans: yields (base address, getbytes, starts, ends) per ``batch_lines`` records
         (blank lines and header lines containing 'product_id' skipped, kdd_data.py:70-71).  The file is mmapped and the line
-        splitting is native; the spans stay valid until the generator is advanced."""
+        splitting is native; the spans stay valid until the generator is advanced.  ``self.stats`` accumulates the seconds spent
+        mapping / unmapping, prefaulting and splitting (tools/feat_bench.py prints them)."""
         import mmap
+        import time
+        st = self.stats
+        clock = time.perf_counter
         with open(path, "rb") as f:
             size = os.fstat(f.fileno()).st_size
             if size == 0:
                 return
-            with mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
-                view = np.frombuffer(mm, np.uint8)
-                try:
-                    base, pos = view.ctypes.data, 0
-                    starts, ends = np.empty(batch_lines, np.int64), np.empty(batch_lines, np.int64)
-                    used = C.c_int64()
-                    while pos < size:
-                        n = self.lib.mmf_split_lines(base + pos, size - pos, starts.ctypes.data, ends.ctypes.data, batch_lines, C.byref(used))
-                        if n < 0:
-                            raise ValueError(self.lib.mmf_last_error().decode())
-                        if n:
-                            yield base + pos, (lambda a, b, p0=pos: mm[p0 + a:p0 + b]), starts[:n], ends[:n]
-                        pos += used.value
-                finally:
-                    del view                                     # release the exported buffer before the mmap closes
+            t0 = clock()
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            view = np.frombuffer(mm, np.uint8)
+            st["mmap"] = st.get("mmap", 0.0) + clock() - t0
+            try:
+                base, pos = view.ctypes.data, 0
+                starts, ends = np.empty(batch_lines, np.int64), np.empty(batch_lines, np.int64)
+                used = C.c_int64()
+                mapped, per_rec = 0, 64 << 10                # bytes of the mapping whose pages are in, estimate of a record's size
+                prefault = self.prefault and hasattr(self.lib, "mmf_prefault")
+                while pos < size:
+                    want = min(size, pos + int(batch_lines * per_rec * 1.25) + (4 << 20))
+                    t0 = clock()
+                    if prefault and want > mapped:            # the next batch's pages, mapped by several threads instead of by the splitter's faults
+                        self.lib.mmf_prefault(self._h, base + mapped, want - mapped, self.threads)
+                        mapped = want
+                    t1 = clock()
+                    n = self.lib.mmf_split_lines(base + pos, size - pos, starts.ctypes.data, ends.ctypes.data, batch_lines, C.byref(used))
+                    t2 = clock()
+                    st["prefault"] = st.get("prefault", 0.0) + t1 - t0
+                    st["split"] = st.get("split", 0.0) + t2 - t1
+                    if n < 0:
+                        raise ValueError(self.lib.mmf_last_error().decode())
+                    if n:
+                        yield base + pos, (lambda a, b, p0=pos: mm[p0 + a:p0 + b]), starts[:n], ends[:n]
+                        per_rec = max(per_rec // 2, used.value // n)
+                        if prefault:                          # the consumer is done with this batch's bytes: the NEXT decode unmaps them on the side
+                            self.lib.mmf_release_later(self._h, base + pos, used.value)
+                    pos += used.value
+            finally:
+                t0 = clock()
+                del view                                     # release the exported buffer before the mmap closes
+                mm.close()
+                st["munmap"] = st.get("munmap", 0.0) + clock() - t0
 
     def iter_file(self, path: str, batch_lines: int = 8192, sen2forest: bool = False, layout: bool = True):
         """Stream a TSV file: yields one batch dict per ``batch_lines`` records (see ``iter_spans``)."""

@@ -37,7 +37,7 @@ def _same(a: dict, b: dict, keys=None):
 
 def test_header_and_exports():
     src = open(os.path.join(ROOT, "include", "mmfeat.h")).read()
-    declared = sorted(set(re.findall(r"\b(mmf_[a-z_]+)\s*\(", src)))
+    declared = sorted(set(re.findall(r"\b(mmf_[a-z0-9_]+)\s*\(", src)))
     assert declared == sorted(N.EXPORTS)
     lib = ctypes.CDLL(N.LIB_PATH)
     for s in declared:
@@ -145,3 +145,61 @@ def test_file_streaming_matches_in_memory(tmp_path, model):
     assert list(nf.iter_file(str(tmp_path / "empty.tsv"))) == []
     (tmp_path / "hdr.tsv").write_bytes(b"product_id\tx\n\n")
     assert list(nf.iter_file(str(tmp_path / "hdr.tsv"))) == []
+
+
+def test_every_base64_tier_matches_the_scalar_decoder():
+    """AVX2 / AVX-512 VBMI bulk decoders (whatever this CPU has) against the table decoder: same arrays bit for bit, same errors."""
+    lib = N.load()
+    best = lib.mmf_b64_tier(-1)
+    assert best >= 0 and lib.mmf_b64_tier(best + 1) == -1 and lib.mmf_b64_tier(-1) == best
+    lines = _random_lines(60, 21)
+    bad = []
+    for k, pos in enumerate((0, 31, 32, 63, 64, 65, 200, 4095, 4096, 10000)):       # a bad character at block seams of both vector widths
+        f = _random_lines(1, 100 + k)[0].split("\t")
+        while int(f[3]) < 2:
+            f = _random_lines(1, 300 + k)[0].split("\t"); k += 50
+        f[5] = f[5][:pos] + "\x80!*="[k % 4] + f[5][pos + 1:]
+        bad.append("\t".join(f))
+    try:
+        ref = None
+        for tier in range(best + 1):
+            assert lib.mmf_b64_tier(tier) == tier
+            nf = N.NativeFeaturizer(VOCAB, TABLE, "zk", threads=2)
+            got = nf.featurize(lines)
+            if ref is None:
+                ref = {k: np.array(v) for k, v in got.items() if k != "keep"}
+            else:
+                for k in ref:
+                    assert np.array_equal(got[k], ref[k]), (tier, k)
+            for b in bad:
+                with pytest.raises(ValueError, match="base64"):
+                    nf.featurize([b])
+    finally:
+        lib.mmf_b64_tier(best)
+    print("\n[base64 tiers tested: 0..%d]" % best)
+
+
+def test_reused_buffers_rewrite_only_stale_padding_and_threads_may_change():
+    """feat_rows_live: a buffer set that is reused keeps rows [nb, 10) zero without rewriting them -- whatever the previous records'
+    box counts were, the batch equals one decoded into fresh buffers; the context's helper threads serve calls of any width."""
+    a, b, c = _random_lines(50, 31), _random_lines(64, 32), _random_lines(37, 33)
+    fresh = N.NativeFeaturizer(VOCAB, TABLE, "zk", threads=1)
+    nf = N.NativeFeaturizer(VOCAB, TABLE, "zk", threads=3, reuse_buffers=True, pools=1)
+    for rnd, lines in enumerate((a, b, c, a[::-1], b[:5], c + a)):
+        nf.threads = (3, 1, 8, 2, 5, 4)[rnd]
+        got = nf.featurize(lines)
+        want = fresh.featurize(lines)
+        for k in want:
+            if k != "keep":
+                assert np.array_equal(got[k], want[k]), (rnd, k)
+        live = nf._pools[0]["feat_rows_live"][0]
+        assert np.array_equal(live[:len(lines)], np.minimum(want["num_boxes"], 10))
+    # a failed call leaves the rows it touched marked dirty, and the next good call is still right
+    f = b[3].split("\t")
+    while int(f[3]) < 1:
+        f = b[4].split("\t")
+    f[5] = "!" + f[5][1:]
+    with pytest.raises(ValueError):
+        nf.featurize(a[:3] + ["\t".join(f)])
+    got, want = nf.featurize(c), fresh.featurize(c)
+    assert all(np.array_equal(got[k], want[k]) for k in want if k != "keep")

@@ -1,6 +1,6 @@
 """End-to-end TSV -> scores throughput (SURVEY.md section 8(f) row 2 + the hot path): synthetic valid/testB-like TSV file,
 native featurizer threads -> pinned buffers -> H2D on a copy stream -> scorer, all overlapped (pipeline.stream_scores_tsv).
-usage (GPU box): python tools/e2e_tsv_bench.py [records] [model]"""
+usage (GPU box): python tools/e2e_tsv_bench.py [records] [model] [decode threads, comma list (0 = library default)]"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ from kddcup_2020_multimodalitiesrecall_2nd_place_amd.featurizer_native import Na
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
 name = sys.argv[2] if len(sys.argv) > 2 else "zk"
+threads_list = [int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
 D = os.path.join(R, "tests", "golden", "featurizer")
 VOCAB, TABLE = os.path.join(D, "vocab_small.txt"), F.load_label_table(os.path.join(D, "labels.txt"))
 path = "/tmp/e2e_%d.tsv" % n
@@ -54,14 +55,32 @@ if name == "ensemble":      # BASELINE.json config 5: TSV -> four score tables -
     sys.exit(0)
 cfg = {"zk": ZkConfig(), "lds": LdsConfig(), "lxmert": LxmertConfig()}[name]
 sc = scorers.make_scorer(cfg, weights.make_weights(cfg), device=0)
-nf = NativeFeaturizer(VOCAB, TABLE, name, pinned=True, reuse_buffers=True)
+for th in threads_list:
+    nf = NativeFeaturizer(VOCAB, TABLE, name, threads=th, pinned=True, reuse_buffers=True, pools=3)
+    for _ in range(3):
+        nf.stats.clear()
+        t0 = time.time(); k = sum(len(b["query_id"]) for b in nf.iter_file(path, 8192)); dt = time.time() - t0
+    print("featurizer alone (%s of %d host threads): %.0f records/s, %.2f GB/s of TSV  [ms: %s]" % (
+        th or "default", os.cpu_count(), k / dt, os.path.getsize(path) / dt / 1e9, ", ".join("%s %.0f" % (a_, b_ * 1e3) for a_, b_ in nf.stats.items())), flush=True)
+    nf.close()
+    for bp in (8192, 16384):
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.time()
+            qid, pid, score = pipeline.stream_scores_tsv(sc, path, VOCAB, TABLE, batch_pairs=bp, threads=th)
+            torch.cuda.synchronize(); dt = time.time() - t0
+        print("TSV -> scores, batch %d, threads %s: %.0f pairs/s (%d pairs, %.2f s)" % (bp, th or "default", len(score) / dt, len(score), dt), flush=True)
+# device-resident rate of the same records (the ceiling of the lines above): the batches of the file, already on the device
+nf = NativeFeaturizer(VOCAB, TABLE, name, pinned=False)
+dev_batches = []
+for b in nf.iter_file(path, 8192):
+    dev_batches.append({k: (torch.from_numpy(np.array(v)).cuda() if isinstance(v, np.ndarray) and v.dtype.kind in "fiu" else v) for k, v in b.items() if k not in ("query_id", "product_id", "keep")})
+    if len(dev_batches) == 4:
+        break
 for _ in range(2):
-    t0 = time.time(); k = sum(len(b["query_id"]) for b in nf.iter_file(path, 8192)); dt = time.time() - t0
-print("featurizer alone (%d host threads): %.0f records/s, %.2f GB/s of TSV" % (os.cpu_count(), k / dt, os.path.getsize(path) / dt / 1e9), flush=True)
-for bp in (8192, 16384):
-    for _ in range(2):
-        torch.cuda.synchronize(); t0 = time.time()
-        qid, pid, score = pipeline.stream_scores_tsv(sc, path, VOCAB, TABLE, batch_pairs=bp)
-        torch.cuda.synchronize(); dt = time.time() - t0
-    print("TSV -> scores, batch %d: %.0f pairs/s (%d pairs, %.2f s)" % (bp, len(score) / dt, len(score), dt), flush=True)
+    torch.cuda.synchronize(); t0 = time.time()
+    for r in range(4):
+        for d in dev_batches:
+            scorers.score_batch(sc, d)
+    torch.cuda.synchronize(); dt = time.time() - t0
+print("device-resident, same records, batches of 8192: %.0f pairs/s" % (16 * 8192 / dt), flush=True)
 os.remove(path)
