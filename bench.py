@@ -111,29 +111,99 @@ def live_fraction(name, cfgs, ps, dense):
     return round(float((cfgs["lds"].text_len + nb + (nb < N_BOX) + distinct).sum()) / (ps.n * cfgs["lds"].seq), 4)
 
 
+def _host_topology():
+    """(logical CPUs this process may use, physical cores among them, CPUs of NUMA node 0 among them)."""
+    cpus = sorted(os.sched_getaffinity(0))
+    phys, node0 = set(), []
+    for c in cpus:
+        try:
+            phys.add(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip())
+        except OSError:
+            phys.add(str(c))
+    try:
+        txt = open("/sys/devices/system/node/node0/cpulist").read().strip()
+        for part in txt.split(","):
+            lo, _, hi = part.partition("-")
+            node0 += [c for c in range(int(lo), int(hi or lo) + 1) if c in cpus]
+    except (OSError, ValueError):
+        node0 = list(cpus)
+    return cpus, len(phys), node0 or list(cpus)
+
+
+def _pin_all_threads(cpus):
+    """CPU affinity of every thread of this process (OpenMP / BLAS workers exist already and keep theirs otherwise)."""
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(tid), cpus)
+        except OSError:
+            pass
+
+
 def cpu_baseline(cfg, w, hip_logits_fn=None, budget_s=20.0):
-    """the oracle's torch-fp32 port of the same forward on this box's host cores, on BASELINE.json config 1's
-    shape (100 queries x 30 candidates, batch 256), bounded to ~budget_s of CPU work: whole batches of 256 pairs are timed until the
-    budget is spent.  The same sample's logits also serve as a CHECK of the HIP path (hip_logits_fn), never as its output."""
+    """the oracle's fp32 port of the same forward on this box's host cores, on BASELINE.json config 1's shape (100
+    queries x 30 candidates, batch 256), bounded to ~budget_s of CPU work.  Round 5 ran it on torch's default thread count (= every physical
+    core of a two-socket host) and got HALF the rate of an 8-vCPU container: the port's batch-256 GEMMs do not feed 128 cores across two NUMA
+    nodes.  Now: one batch per thread count in {8, 16, 32, 64 on one NUMA node; all physical cores}, then whole batches on the fastest
+    setting until the budget is spent.  ``value`` / ``cores`` = that setting (the threads actually used); ``all_physical_cores`` = the
+    protocol's "N = all physical cores" figure beside it.  The weights are converted once, outside the timed calls.  The sample's logits
+    also serve as a CHECK of the HIP path (hip_logits_fn), never as its output."""
     from oracle import np_models, torch_models  # checker / baseline only
-    cores = torch.get_num_threads()
     ps = synth.make_pairs(100, 30, tag="/cpu")     # config 1: 3000 pairs
     b = synth.batch_for(cfg, ps)
-    run = (lambda bb: torch_models.forward(cfg, w, bb)) if cfg.name != "lxmert" else \
-        (lambda bb: np_models.forward(cfg, w, bb, np.float32))
+    if cfg.name != "lxmert":
+        tw = torch_models.prepare(w)
+        run = lambda bb: torch_models.forward(cfg, tw, bb)
+        blas = None
+    else:
+        run = lambda bb: np_models.forward(cfg, w, bb, np.float32)
+        from threadpoolctl import threadpool_limits as blas
     cut = lambda lo, hi: {k: (v[lo:hi] if hasattr(v, "__len__") and len(v) == ps.n else v) for k, v in b.items()}
-    run(cut(0, 16))                                 # thread-pool / allocator warm-up, untimed
-    done, dt, ref = 0, 0.0, []
-    while done < ps.n and dt < budget_s:
+    cpus, n_phys, node0 = _host_topology()
+    torch_default = torch.get_num_threads()
+
+    def timed(threads, on_cpus, lo, hi):
+        _pin_all_threads(on_cpus)
+        torch.set_num_threads(threads)
+        try:
+            if blas is not None:
+                with blas(limits=threads):
+                    t0 = time.time(); out = run(cut(lo, hi)); dt = time.time() - t0
+            else:
+                t0 = time.time(); out = run(cut(lo, hi)); dt = time.time() - t0
+        finally:
+            _pin_all_threads(cpus)
+            torch.set_num_threads(torch_default)
+        return dt, np.asarray(out[0], np.float64)
+
+    timed(min(8, len(cpus)), cpus, 0, 16)           # thread-pool / allocator warm-up, untimed
+    settings = [(t, node0, "%d threads on NUMA node 0" % t) for t in (16, 8, 32, 64) if t <= len(node0) and t < n_phys]      # 16 first: the usual winner, measured even on a tight budget
+    settings.append((n_phys, cpus, "%d threads = all physical cores" % n_phys))
+    spent, sweep, probe = 0.0, [], min(256, ps.n)
+    for k, (t, on, label) in enumerate(settings):
+        if k and spent > 0.6 * budget_s:            # a slow host: keep what has been measured
+            break
+        dt, ref0 = timed(t, on, 0, probe)
+        spent += dt
+        sweep.append({"threads": t, "placement": label, "value": round(probe / dt, 2)})
+    best = max(range(len(sweep)), key=lambda i: sweep[i]["value"])
+    bt, bon, blabel = settings[best]
+    done, dt_best, ref = probe, probe / sweep[best]["value"], [ref0 if best == len(sweep) - 1 else None]
+    if ref[0] is None:                               # the best setting's own logits of the first batch (any setting's agree to fp32 round-off)
+        ref = [timed(bt, bon, 0, probe)[1]]
+    while done < ps.n and spent < budget_s:
         hi = min(done + 256, ps.n)
-        t0 = time.time()
-        out = run(cut(done, hi))
-        dt += time.time() - t0
-        ref.append(np.asarray(out[0], np.float64))
+        dt, out = timed(bt, bon, done, hi)
+        spent += dt; dt_best += dt
+        ref.append(out)
         done = hi
-    res = {"value": round(done / dt, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
-           "sample": "%d of config 1's 3000 pairs (100 queries x 30 candidates) in batches of 256, %s fp32 restatement of %s on %d "
-                     "threads, %.1f s" % (done, "numpy (BLAS)" if cfg.name == "lxmert" else "torch", cfg.name, cores, dt)}
+    allp = [s_ for s_ in sweep if s_["threads"] == n_phys]
+    res = {"value": round(done / dt_best, 2), "unit": "pairs/s", "cores": bt, "kind": "port",
+           "best_threads": bt, "best_value": round(done / dt_best, 2), "placement": blabel,
+           "all_physical_cores": ({"value": allp[0]["value"], "cores": n_phys} if allp else None), "thread_sweep": sweep,
+           "host": {"logical_cpus": len(cpus), "physical_cores": n_phys, "numa_node0_cpus": len(node0)},
+           "sample": "%d of config 1's 3000 pairs (100 queries x 30 candidates) in batches of 256, %s fp32 restatement of %s, %s (the fastest of "
+                     "a one-batch sweep over %s threads), weights converted once outside the timed calls, %.1f s of CPU work in all"
+                     % (done, "numpy (BLAS)" if cfg.name == "lxmert" else "torch", cfg.name, blabel, [s_["threads"] for s_ in sweep], spent)}
     if hip_logits_fn is not None:
         got = hip_logits_fn(cut(0, done))
         ref = np.concatenate(ref)
@@ -551,7 +621,7 @@ def main():
         dist.destroy_process_group()
 
 
-def tsv_pipeline_rate(scorer, records=60000):
+def tsv_pipeline_rate(scorer, records=120000):
     """The caller-side pipeline with every stage overlapped (pipeline.stream_scores_tsv): a synthetic valid/testB-like TSV file
     (the reference's wire format, load_data_v4.py:133-163; mean 3.8 boxes per record) -> libmmfeat decode threads -> rotating
     pinned buffers -> H2D on a copy stream -> the scorer.  This is the PCIe-inclusive rate a file-fed caller sees; never `value`."""
@@ -575,17 +645,47 @@ def tsv_pipeline_rate(scorer, records=60000):
                                         " ".join(rng.choice(words, int(rng.integers(2, 9)))), i // 30) + "\n")
         size = os.path.getsize(path)
         best = 0.0
-        for _ in range(2):
+        for _ in range(3):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             _q, _p, sc = pipeline.stream_scores_tsv(scorer, path, vocab, table, batch_pairs=8192)
             torch.cuda.synchronize()
             best = max(best, len(sc) / (time.perf_counter() - t0))
+        # the host side alone: the same file through libmmfeat into reused pinned buffers, nothing consuming them
+        from kddcup_2020_multimodalitiesrecall_2nd_place_amd.featurizer_native import NativeFeaturizer
+        nf = NativeFeaturizer(vocab, table, scorer.cfg.name, pinned=True, reuse_buffers=True, pools=3)
+        feat = 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            k = sum(len(b_["query_id"]) for b_ in nf.iter_file(path, 8192))
+            feat = max(feat, k / (time.perf_counter() - t0))
+        nf.close()
+        # ... and the device side alone on the same records (what the file-fed rate is to be compared with: these records carry 3.8 boxes each)
+        nf = NativeFeaturizer(vocab, table, scorer.cfg.name)
+        devb = []
+        for b_ in nf.iter_file(path, 8192):
+            devb.append({k: (torch.from_numpy(np.array(v)).to(scorer.device) if isinstance(v, np.ndarray) and v.dtype.kind in "fiu" else v)
+                         for k, v in b_.items() if k not in ("query_id", "product_id", "keep")})
+            if len(devb) == 3:
+                break
+        nf.close()
+        resident = 0.0
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _r in range(3):
+                for d_ in devb:
+                    scorers.score_batch(scorer, d_)
+            torch.cuda.synchronize()
+            resident = max(resident, 9 * 8192 / (time.perf_counter() - t0))
+        del devb
     finally:
         os.remove(path)
-    return {"value": round(best, 1), "unit": "pairs/s",
+    return {"value": round(best, 1), "unit": "pairs/s", "featurizer_alone_records_per_s": round(feat, 1),
+            "device_resident_same_records": round(resident, 1), "fraction_of_device_resident": round(best / resident, 4),
             "note": "TSV file (%d records, %.2f GB) -> native featurizer threads -> pinned buffers -> H2D on a copy stream -> scorer, all "
-                    "overlapped (pipeline.stream_scores_tsv, batches of 8192); %d host threads" % (records, size / 1e9, os.cpu_count())}
+                    "overlapped (pipeline.stream_scores_tsv, batches of 8192 after a 1024 / 2048 / 4096 ramp); %d host threads, the decode on "
+                    "up to 64 of them" % (records, size / 1e9, os.cpu_count())}
 
 
 def secondary(a, local, dev, ps, feats, members, scorer, feed, value):

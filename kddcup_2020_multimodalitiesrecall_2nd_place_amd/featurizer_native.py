@@ -163,9 +163,11 @@ class NativeFeaturizer:
         arr["keep"] = keep
         return arr
 
-    def iter_spans(self, path: str, batch_lines: int = 8192):
+    def iter_spans(self, path: str, batch_lines: int = 8192, ramp: int = 0):
         """Stream a TSV file as record spans: yields (base address, getbytes, starts, ends) per ``batch_lines`` records
-        (blank lines and header lines containing 'product_id' skipped, kdd_data.py:70-71).  The file is mmapped and the line
+        (blank lines and header lines containing 'product_id' skipped, kdd_data.py:70-71).  ``ramp`` > 0: the first batches hold
+        ramp, 2 ramp, 4 ramp ... records until ``batch_lines`` is reached -- a consumer that overlaps decode, copy and scoring starts
+        after the decode of ``ramp`` records instead of a whole batch (pipeline.stream_scores_tsv).  The file is mmapped and the line
         splitting is native; the spans stay valid until the generator is advanced.  ``self.stats`` accumulates the seconds spent
         mapping / unmapping, prefaulting and splitting (tools/feat_bench.py prints them)."""
         import mmap
@@ -184,23 +186,25 @@ class NativeFeaturizer:
                 base, pos = view.ctypes.data, 0
                 starts, ends = np.empty(batch_lines, np.int64), np.empty(batch_lines, np.int64)
                 used = C.c_int64()
+                cur = min(batch_lines, ramp) if ramp > 0 else batch_lines
                 mapped, per_rec = 0, 64 << 10                # bytes of the mapping whose pages are in, estimate of a record's size
                 prefault = self.prefault and hasattr(self.lib, "mmf_prefault")
                 while pos < size:
-                    want = min(size, pos + int(batch_lines * per_rec * 1.25) + (4 << 20))
+                    want = min(size, pos + int(cur * per_rec * 1.25) + (4 << 20))
                     t0 = clock()
                     if prefault and want > mapped:            # the next batch's pages, mapped by several threads instead of by the splitter's faults
                         self.lib.mmf_prefault(self._h, base + mapped, want - mapped, self.threads)
                         mapped = want
                     t1 = clock()
-                    n = self.lib.mmf_split_lines(base + pos, size - pos, starts.ctypes.data, ends.ctypes.data, batch_lines, C.byref(used))
+                    n = self.lib.mmf_split_lines(base + pos, size - pos, starts.ctypes.data, ends.ctypes.data, cur, C.byref(used))
+                    cur = min(batch_lines, 2 * cur)
                     t2 = clock()
                     st["prefault"] = st.get("prefault", 0.0) + t1 - t0
                     st["split"] = st.get("split", 0.0) + t2 - t1
                     if n < 0:
                         raise ValueError(self.lib.mmf_last_error().decode())
                     if n:
-                        yield base + pos, (lambda a, b, p0=pos: mm[p0 + a:p0 + b]), starts[:n], ends[:n]
+                        yield base + pos, (lambda a, b, p0=pos: mm[p0 + a:p0 + b]), starts[:n].copy(), ends[:n].copy()
                         per_rec = max(per_rec // 2, used.value // n)
                         if prefault:                          # the consumer is done with this batch's bytes: the NEXT decode unmaps them on the side
                             self.lib.mmf_release_later(self._h, base + pos, used.value)
@@ -211,9 +215,9 @@ class NativeFeaturizer:
                 mm.close()
                 st["munmap"] = st.get("munmap", 0.0) + clock() - t0
 
-    def iter_file(self, path: str, batch_lines: int = 8192, sen2forest: bool = False, layout: bool = True):
+    def iter_file(self, path: str, batch_lines: int = 8192, sen2forest: bool = False, layout: bool = True, ramp: int = 0):
         """Stream a TSV file: yields one batch dict per ``batch_lines`` records (see ``iter_spans``)."""
-        for base, getbytes, starts, ends in self.iter_spans(path, batch_lines):
+        for base, getbytes, starts, ends in self.iter_spans(path, batch_lines, ramp):
             a = self._run(base, getbytes, starts, ends, sen2forest)
             yield self._layout(a) if layout else a
 

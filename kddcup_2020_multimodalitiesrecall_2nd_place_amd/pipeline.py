@@ -5,6 +5,8 @@ The written files are what ``ensemble.ensemble`` (main.py's merge) consumes.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import featurizer as F
@@ -57,12 +59,32 @@ def kdd_predict(scorer, tsv_lines, label_table, tokenizer, save_path=None, batch
     return match_pred, match_label, rank_score_pred
 
 
-def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: bool = False, batch_pairs: int = 32768, threads: int = 0):
+_FEATURIZERS: dict = {}
+
+
+def _cached_featurizer(vocab_path, label_table, model, threads):
+    """One NativeFeaturizer (helper threads + three pinned buffer sets, ~2 GB at 8192-record batches) per (vocabulary, label table, model,
+    threads): creating them costs about as much as decoding 30 000 records."""
+    from .featurizer_native import NativeFeaturizer
+    key = (os.path.abspath(vocab_path), os.path.getmtime(vocab_path), model, threads, tuple(sorted((int(k), v) for k, v in label_table.items())))
+    if key not in _FEATURIZERS:
+        if len(_FEATURIZERS) >= 4:
+            _FEATURIZERS.pop(next(iter(_FEATURIZERS))).close()
+        _FEATURIZERS[key] = NativeFeaturizer(vocab_path, label_table, model, threads=threads, pinned=True, reuse_buffers=True, pools=3)
+    return _FEATURIZERS[key]
+
+
+def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: bool = False, batch_pairs: int = 32768, threads: int = 0,
+                      ramp: int = 1024):
     """TSV file -> (query_id, product_id, score) with the three stages overlapped:
 
       producer thread   libmmfeat decodes batch i+2 into one of three pinned buffer sets (ctypes releases the GIL)
       copy stream       H2D of batch i+1 (pinned -> device, waited for on the host, which then frees that buffer set)
       main stream       the scorer's kernels for batch i (asynchronous; nothing on the host waits for them until the end)
+
+    ``ramp``: the first batches hold ramp, 2 ramp, 4 ramp ... records (0: every batch ``batch_pairs``): the GPU starts after ~4 ms of
+    host work instead of the ~27 ms a 8192-record batch takes to decode and copy -- 4 % of a 150 000-record file, a fifth of testB.
+    The featurizer (its helper threads and pinned buffer sets) is kept per (vocabulary, model, threads) between calls.
     """
     import queue
     import threading
@@ -70,13 +92,13 @@ def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: boo
     import torch
 
     from .featurizer_native import NativeFeaturizer
-    nf = NativeFeaturizer(vocab_path, label_table, scorer.cfg.name, threads=threads, pinned=True, reuse_buffers=True, pools=3)
+    nf = _cached_featurizer(vocab_path, label_table, scorer.cfg.name, threads)
     dev = scorer.device
     q = queue.Queue(maxsize=1)           # one decoded batch waiting + one being decoded + one being copied = 3 pools
 
     def produce():
         try:
-            for b in nf.iter_file(tsv_path, batch_pairs, sen2forest):
+            for b in nf.iter_file(tsv_path, batch_pairs, sen2forest, ramp=ramp):
                 q.put(b)
             q.put(None)
         except BaseException as e:       # surfaced in the consumer

@@ -203,3 +203,16 @@ def test_reused_buffers_rewrite_only_stale_padding_and_threads_may_change():
         nf.featurize(a[:3] + ["\t".join(f)])
     got, want = nf.featurize(c), fresh.featurize(c)
     assert all(np.array_equal(got[k], want[k]) for k in want if k != "keep")
+
+
+def test_ramp_batches_double_up_to_the_batch_size(tmp_path):
+    lines = _random_lines(45, 3)
+    p = tmp_path / "v.tsv"
+    p.write_bytes(("\n".join(lines) + "\n").encode("utf-8"))
+    nf = N.NativeFeaturizer(VOCAB, TABLE, "zk", threads=2, reuse_buffers=True, pools=2)
+    want = N.NativeFeaturizer(VOCAB, TABLE, "zk").batch(lines)
+    got = [{k: np.array(v) for k, v in b.items() if k != "keep"} for b in nf.iter_file(str(p), 16, ramp=3)]
+    assert [len(b["query_id"]) for b in got] == [3, 6, 12, 16, 8]
+    for k in want:
+        if k != "keep":
+            assert np.array_equal(np.concatenate([b[k] for b in got]), want[k]), k
