@@ -105,6 +105,7 @@ struct mms_handle {
     // between a fork and a join event.  Same kernels on the same operands: results do not change.  lane == 1 while the side chain is being enqueued: its split-K partials
     // and its FFN intermediate live in kparts_side / behind mid_side_off elements of `mid` (everything else a chain touches is addressed by its stream's row range).
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool no_fused_ln = false;      // this call takes the two-kernel LayerNorm route throughout: it runs on lanes -- or WOULD without per-launch timing (the route must not depend on instrumentation)
     int lane = 0; bool lanes_on = false, lanes_q = false;      // lanes_on: the whole call (stream chains of the X layers, language beside box layers); lanes_q: the distinct-query stage only
     float* kparts_side = nullptr; int64_t kparts_side_floats = 0; int64_t mid_side_off = 0, mid_elems = 0;
     int fuse_ln = 0;       // mms_config.fuse_layernorm (lab build: env MMS_FUSE_LN overrides)
@@ -482,6 +483,7 @@ int alloc_planes(mms_handle* h, std::vector<void*>& pool, Planes* p, int64_t ele
 
 int ensure_kparts(mms_handle* h, int64_t floats);
 int64_t kparts_need(const mms_handle* h, int64_t pairs, int64_t rows);
+int64_t kparts_side_need(const mms_handle* h, int64_t pairs);
 // the lane-private buffers of the chain that is being enqueued (mms_handle::lane)
 inline float* kp(const mms_handle* h) { return h->lane ? h->kparts_side : h->kparts; }
 inline Planes midp(const mms_handle* h) { return h->lane ? h->mid.at(h->mid_side_off) : h->mid; }
@@ -582,9 +584,9 @@ int ensure_workspace(mms_handle* h, int64_t pairs) {
     if (int rc = dev_alloc(h, h->ws_allocs, &p, (size_t)mms_handle::LN_SLOTS * 2 * 4)) return rc;
     h->ln_ctl = (int*)p;
     if (int rc = ensure_kparts(h, kparts_need(h, pairs, rows))) return rc;
-    if (c.model == MMS_MODEL_LXMERT && rows < lane_rows()) {
+    if (c.model == MMS_MODEL_LXMERT && lane_rows() > 0) {      // whichever call sizes the workspace: the side lane's partials come with it, never inside a scoring call
         h->lane = 1;
-        const int rc = ensure_kparts(h, kparts_need(h, pairs, rows));
+        const int rc = ensure_kparts(h, kparts_side_need(h, pairs));
         h->lane = 0;
         if (rc) return rc;
     }
@@ -793,7 +795,7 @@ int gemm_ln(mms_handle* h, hipStream_t st, bool f8, const Planes& a, int lda, co
     if (!(h->fuse_ln & (K == H ? 1 : 2)) || f8 || M < lnf_rows() || h->nsplit != 2 || !h->resid_in_ln || h->ln_slot >= mms_handle::LN_SLOTS) return MMS_OK;
     // two launch lanes: the fused epilogue needs its whole grid resident (the column tiles of a row panel exchange statistics) and falls back to the LayerNorm
     // kernel when it is not -- beside another lane's persistent kernel that would be decided by timing.  A call on two lanes takes the two-kernel route throughout.
-    if (h->lanes_on || h->lane || h->lq_join_pending) return MMS_OK;      // (lq_join_pending: the distinct-query stage is running on the side lane)
+    if (h->no_fused_ln || h->lanes_on || h->lane || h->lq_join_pending) return MMS_OK;      // (lq_join_pending: the distinct-query stage is running on the side lane)
     if (K % 64 != 0) return MMS_OK;
     (void)w8; (void)wscale;          // the fp8 mode always takes the two-kernel route (f8 returned above)
     GemmParams p{};
@@ -916,6 +918,12 @@ int64_t kparts_need(const mms_handle* h, int64_t pairs, int64_t rows) {
     if (4 * r_wide * nmax > need) need = 4 * r_wide * nmax;
     if ((int64_t)KSPLIT_MAX * r_tall * H > need) need = (int64_t)KSPLIT_MAX * r_tall * H;
     return need;
+}
+
+// ... of the side lane (lxmert): it runs the box stream's chains (10 rows per pair) or the distinct-query stage (<= text_len rows per pair), never both streams' rows
+int64_t kparts_side_need(const mms_handle* h, int64_t pairs) {
+    const int64_t per = h->cfg.text_len > MMS_NBOX ? h->cfg.text_len : MMS_NBOX;
+    return kparts_need(h, pairs, pairs * per);
 }
 
 // out = LayerNorm(A W^T + bias + resid) for a bf16 N = 768 projection on the two-kernel route: split-K partials (small M) or the plain fp32
@@ -1410,6 +1418,25 @@ int on_side_lane(mms_handle* h, F&& chain) {
     return rc;
 }
 
+// A scoring call that may fork a side lane owns one of these: an error return between a fork and its join would leave the side stream running unordered against the
+// caller's stream while it still touches x / y / ctx / mid / kparts_side, and lq_join_pending set until the next call (which would silently disable the fused LayerNorm
+// epilogue).  Every exit that is not the successful one drains the side stream(s) and clears the lane state.
+struct LaneGuard {
+    mms_handle* hs[3] = {nullptr, nullptr, nullptr};
+    int n = 0;
+    bool ok = false;
+    explicit LaneGuard(mms_handle* a, mms_handle* b = nullptr, mms_handle* c = nullptr) { hs[n++] = a; if (b) hs[n++] = b; if (c) hs[n++] = c; }
+    int done(int rc) { ok = rc == MMS_OK; return rc; }
+    ~LaneGuard() {
+        if (ok) return;
+        for (int i = 0; i < n; ++i) {
+            mms_handle* h = hs[i];
+            if (h->side) (void)hipStreamSynchronize(h->side);
+            h->lane = 0; h->lq_join_pending = false; h->lanes_on = false; h->lanes_q = false;
+        }
+    }
+};
+
 int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int64_t B, int cs) {
     const mms_config& c = h->cfg;
     h->lq_active = false;
@@ -1473,14 +1500,13 @@ int lx_query_stage(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, int
     // One chunk, one sub-batch, a small call (two lanes): the stage runs on the side lane beside the chunk's box-stream prologue and r_layers (lx_chunk joins
     // before it copies the language rows out of lq_store).  The stage's rows [0, Q T) of x / y / ctx / qkv / t lie inside the chunk's language rows, which the
     // chunk does not touch before the join; its packed plan, its sub-tile table and the plan scratch are its own.
-    const int64_t R = B * (T + MMS_NBOX);
     // (mid: the main lane needs the box rows' share until the join -- split features, then the r_layers' FFN intermediate -- and the stage's rows follow it)
     const bool side = h->lanes_q && B <= cs && Q <= cs && (B * MMS_NBOX + Q * T) * (int64_t)c.inter <= h->mid_elems;
     hipStream_t qs = st;
     if (side) {
         if (int rc = lanes_init(h)) return rc;
         h->lane = 1;
-        const int rc = ensure_kparts(h, kparts_need(h, B, R));
+        const int rc = ensure_kparts(h, kparts_side_need(h, B));      // (a no-op: sized with the workspace)
         h->lane = 0;
         if (rc) return rc;
         h->mid_side_off = B * MMS_NBOX * (int64_t)c.inter;
@@ -1569,7 +1595,7 @@ int lx_chunk(mms_handle* h, hipStream_t st, const mms_lxmert_batch* b, const int
     if (lanes) {
         if (int rc = lanes_init(h)) return rc;
         h->lane = 1;
-        const int rc = ensure_kparts(h, kparts_need(h, n, R));      // (sized with the workspace unless a larger call sized that first)
+        const int rc = ensure_kparts(h, kparts_side_need(h, n));      // (a no-op: sized with the workspace)
         h->lane = 0;
         if (rc) return rc;
         h->mid_side_off = ML * (int64_t)c.inter;
@@ -1838,7 +1864,7 @@ int mms_score_zk(mms_handle* h, const mms_zk_batch* b, float* logits, float* pro
         return h->fail(MMS_ERR_ARG, "mms_score_zk: null batch field");
     if (b->uniq_label_ids ? (!b->label_index || b->n_uniq_labels == 0) : !b->label_ids)
         return h->fail(MMS_ERR_ARG, "mms_score_zk: pass label_ids (dense) or uniq_label_ids + label_index");
-    h->lanes_on = false;
+    h->lanes_on = false; h->no_fused_ln = false;
     DeviceScope dev(h->cfg.device);
     hipStream_t st = (hipStream_t)stream;
     const int cs = chunk_size(h, B);
@@ -1866,7 +1892,7 @@ int mms_score_lds(mms_handle* h, const mms_lds_batch* b, float* logits, float* p
     if (B < 0) return h->fail(MMS_ERR_ARG, "negative batch size");
     if (B == 0) return MMS_OK;
     if (!b->input_ids || !b->segment_ids || !b->features || !b->labelfeat) return h->fail(MMS_ERR_ARG, "mms_score_lds: null batch field");
-    h->lanes_on = false;
+    h->lanes_on = false; h->no_fused_ln = false;
     DeviceScope dev(h->cfg.device);
     hipStream_t st = (hipStream_t)stream;
     const int cs = chunk_size(h, B);
@@ -1901,12 +1927,15 @@ int mms_score_lxmert(mms_handle* h, const mms_lxmert_batch* b, float* logits, fl
     // two launch lanes (mms_handle::side) for calls whose launch wave has fewer than LANE_ROWS token rows; not for debug runs (they count layers in stream
     // order) or precision mode 4; with per-launch timing (bench.py's roofline pass) only the distinct-query stage keeps its side lane, and its launches stay out of the per-launch sums
     h->lanes_q = h->cfg.pack_tokens && h->cfg.stop_after < 0 && !h->f8 && lane_rows() > 0 && lane_query_stage();
-    h->lanes_on = h->lanes_q && !h->timing && (int64_t)cs * (h->cfg.text_len + MMS_NBOX) < lane_rows();
+    const bool small_wave = h->lanes_q && (int64_t)cs * (h->cfg.text_len + MMS_NBOX) < lane_rows();
+    h->lanes_on = small_wave && !h->timing;
+    h->no_fused_ln = small_wave;      // with or without timing: instrumentation must not change the LayerNorm route, i.e. the logits
+    LaneGuard guard(h);
     if (int rc = lx_label_features(h, st, uniq, U)) return rc;
     if (int rc = lx_query_stage(h, st, b, B, cs)) return rc;
     for (int64_t p0 = 0; p0 < B; p0 += cs)
         if (int rc = lx_chunk(h, st, b, index, p0, (B - p0) < cs ? (B - p0) : cs, logits, probs)) return rc;
-    return post_launch(h);
+    return guard.done(post_launch(h));
 }
 
 // ---- the three models on the same pairs in one call (BASELINE.json config 5; merge of code/main.py:59) ----
@@ -2000,8 +2029,13 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
 #ifdef MMS_LAB
     { static const int64_t v = getenv("MMS_ENS_LANE_ROWS") ? atoll(getenv("MMS_ENS_LANE_ROWS")) : 0; if (v) ens_rows = v; }
 #endif
-    const bool ens_lanes = lane_rows() > 0 && (int64_t)cs * (T + 2 * MMS_NBOX) < ens_rows && (int64_t)cs * (TL + MMS_NBOX) < ens_rows && !z->timing && !l->timing && !x->timing;
-    z->lanes_on = l->lanes_on = ens_lanes;      // (gemm_ln: no fused LayerNorm epilogue beside another lane)
+    const bool ens_small = lane_rows() > 0 && (int64_t)cs * (T + 2 * MMS_NBOX) < ens_rows && (int64_t)cs * (TL + MMS_NBOX) < ens_rows;
+    const bool ens_lanes = ens_small && !z->timing && !l->timing && !x->timing;
+    z->lanes_on = l->lanes_on = ens_lanes;
+    // no fused LayerNorm epilogue in ANY member beside another member's lane (its grid-residency check would be decided by timing) -- the lxmert member included, whose own
+    // lanes_on is off with pack_tokens = 0 --, and not in the timed run of such a wave either
+    z->no_fused_ln = l->no_fused_ln = ens_small;
+    LaneGuard guard(z, l, x);
     if (ens_lanes) {
         if (int rc = lanes_init(z)) return rc;
         if (int rc = lanes_init(l)) return z->fail(rc, "lds handle: " + l->err);
@@ -2015,7 +2049,9 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
     }
     // two lanes inside the lxmert member's chunks as in mms_score_lxmert; its distinct-query stage goes to the side lane only in the small-wave regime above: beside
     // the other members' big launches with fused LayerNorm epilogues it would break those (gemm_ln)
-    x->lanes_on = x->cfg.pack_tokens && !x->f8 && !x->timing && lane_rows() > 0 && (int64_t)cs * (TL + MMS_NBOX) < lane_rows();
+    const bool x_small = x->cfg.pack_tokens && !x->f8 && lane_rows() > 0 && (int64_t)cs * (TL + MMS_NBOX) < lane_rows();
+    x->lanes_on = x_small && !x->timing;
+    x->no_fused_ln = ens_small || x_small;
     x->lanes_q = ens_lanes && x->lanes_on && lane_query_stage();
     if (int rc = lx_query_stage(x, st, &xb, B, cs)) return z->fail(rc, "lxmert member: " + x->err);
     float* lg[4]; float* pr[4];
@@ -2108,7 +2144,7 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
     }
     const float* prc[4] = {pr[0], pr[1], pr[2], pr[3]};
     launch_merge4(prc, weights4, merged, member_scores, B, st);
-    return post_launch(z);
+    return guard.done(post_launch(z));
 }
 
 int mms_gemm_timing(mms_handle* h, int32_t enable, int32_t reset, double* ms_out, int64_t* launches_out, double* flops_out) {

@@ -62,3 +62,44 @@ def test_product_build_takes_the_lanes_where_documented():
     scorers.score_batch(sc["zk"], zb)
     assert sc["zk"].handle.counter(4) == 1
     ens.close()
+
+
+def test_per_launch_timing_does_not_change_the_logits():
+    """with mms_gemm_timing on, a call that would run on two lanes runs on one -- and must still take the LayerNorm-kernel route of the
+    untimed call (no fused epilogue), so that instrumentation never changes the bits.  3 500 pairs: 115 500 token rows, above the fused-LayerNorm
+    bound (98 304) and below LANE_ROWS; the fused three-model call likewise (its members' lanes are off under timing)."""
+    import torch
+    from helpers import small_cfg
+    from kddcup_2020_multimodalitiesrecall_2nd_place_amd import pipeline, scorers, synth, weights
+    cfg = small_cfg("lxmert")
+    ps = synth.make_pairs(120, (28, 30), vocab=cfg.vocab, tag="/lanes_timing")
+    b = synth.batch_for(cfg, ps)
+    assert ps.n * 33 >= 98304
+    s = scorers.make_scorer(cfg, weights.make_weights(cfg))
+    plain, _ = scorers.score_batch(s, b)
+    forks = s.handle.counter(4)
+    assert forks > 0 and s.handle.counter(1) == 0                # two lanes, no LayerNorm-fused GEMM launch
+    s.handle.gemm_timing(True, True)
+    timed, _ = scorers.score_batch(s, b)
+    s.handle.gemm_timing(False, True)
+    assert s.handle.counter(1) == 0                              # still none: the route of the untimed call
+    assert torch.equal(plain, timed)
+    again, _ = scorers.score_batch(s, b)
+    assert torch.equal(plain, again)
+    s.close()
+    cfgs = {n: small_cfg(n) for n in ("zk", "lds", "lxmert")}
+    sc = {n: scorers.make_scorer(c, weights.make_weights(c)) for n, c in cfgs.items()}
+    ens = scorers.EnsembleScorer(sc["zk"], sc["lds"], sc["lxmert"])
+    zb = synth.zk_batch(ps, cfgs["zk"].text_len)
+    zb2 = synth.zk_batch(synth.sen2forest_variant(ps), cfgs["zk"].text_len)
+    xb = synth.lxmert_batch(ps, cfgs["lxmert"].text_len)
+    feed = pipeline.ensemble_feed(zb, zb2, xb)
+    m0, mem0 = ens(feed)
+    for h in (sc["zk"].handle, sc["lds"].handle, sc["lxmert"].handle):
+        h.gemm_timing(True, True)
+    m1, mem1 = ens(feed)
+    for h in (sc["zk"].handle, sc["lds"].handle, sc["lxmert"].handle):
+        h.gemm_timing(False, True)
+    assert torch.equal(m0, m1) and torch.equal(mem0, mem1)
+    assert all(sc[n].handle.counter(1) == 0 for n in sc)         # no member took the fused epilogue beside the others' lanes, timed or not
+    ens.close()
