@@ -171,7 +171,7 @@ typedef struct mms_ensemble_batch {
 
 /* ABI revision of the structs and entry points declared in this header.  It changes whenever a struct gains a field or an entry
  * point changes its signature (r1: 1; r2 added mms_config.fuse_layernorm, mms_zk_batch.label_ids, mms_lxmert_batch.label_ids / x_norm
- * without bumping it; r3: 3, then 4 with mms_config.fuse_attention; r4: 5 -- mms_dbg_gemm takes the tile engine per call,
+ * without bumping it; r3: 3, then 4 with mms_config.fuse_attention; r4: 5 -- mms_dbg_gemm takes the engine per call,
  * the process-global mms_set_gemm_variant and the lab engines' hooks left the product library, fuse_layernorm became a mask; r5: 6 -- mms_dbg_qkv_attn and mms_side_lane_flops added).  A caller built against another revision would make the library read past its structs, so compare
  * BEFORE the first mms_create:  if (mms_version() != MMS_ABI_VERSION) abort();   (lib.py's load() does) */
 #define MMS_ABI_VERSION 6
@@ -191,22 +191,32 @@ int mms_finalize(mms_handle* h);
  * Pairs are independent: how a caller groups them into calls (or mms_config.chunk_pairs into launch waves) changes a logit by fp32 summation
  * order at most (~1e-5 relative), and not at all between launches of the same SIZE REGIME.  A launch's regime is decided by its PADDED row bound
  * (pairs x sequence length of the stream; the live count stays on the device), per projection class -- every boundary that changes a summation order:
- *   rows <= 128              every projection on the skinny kernel (gemm_skinny.hip), K sliced exactly as the tile route of the same projection would
- *                            slice it: bit-identical to the next regime (128 is a speed boundary only)
- *   rows <  1024             wide projections (N >= 1536, K = 768: QKV, K | V, FFN-up): K in 4 slices, summed in fixed order (k_splitk_reduce)
- *   rows <  4096             the long-K projections in front of the encoder (K >= 2048, N = 768: zk kdd_conv1 as im2col over 8 x distinct label texts,
- *                            kdd_conv2 / visn_fc / featureemb over the box rows): K in 8 slices
- *   rows <  8192             the N = 768 projections that a LayerNorm follows (attention output, FFN-down): K in 4 (K = 768) / 8 (K >= 2048; 4 from 4096 rows on) slices,
- *                            summed by the LayerNorm kernel
- *   rows >= 1024             mms_config.fuse_attention: a stream's QKV projection + attention in one kernel (qkv_attn.hip).  1: the two-kernel route's arithmetic, bit-identical
- *                            to it.  2 (the scorers' default in precision mode 2): split-bf16 attention over 16-query tiles of a packed sub-tile, online softmax -- a pair's
- *                            logits then depend on its place in the launch by fp32 round-off (<= 1e-4 relative), so calls of >= 1024 token rows are bit-identical across batch
- *                            compositions only with fuse_attention <= 1
- *   rows <  16384            register-staged / LDS-DMA 128 x 256 tiles (bit-identical to each other), one pass over K (FFN-down, K = 3072: 2 slices from 11264 rows on)
- *   rows >= 16384            persistent ping-pong engines for every projection (same contraction order per element as the tiles: bit-identical, tested)
- *   rows >= 98304            mms_config.fuse_layernorm: bias + residual + LayerNorm in the GEMM epilogue (one-pass variance; below, the LayerNorm kernel is faster) -- except in
- *                            lxmert calls of fewer than 400 000 token rows (pairs x (text_len + 10); ~12 500 pairs), which run their two streams' launch chains side by
- *                            side on two lanes and leave every LayerNorm to its own kernel (the fused epilogue needs its whole grid resident)
+ * GENERATED REGIMES BEGIN (tools/gen_regime_doc.py from csrc/regimes.h -- do not edit)
+ *   rows <= 128     SKINNY_ROWS      [speed choice only: bit-identical across it]  every projection on the skinny kernel (gemm_skinny.hip), K sliced
+ *                                    exactly as the tile route of the same projection slices it
+ *   rows <  1024    TINY_ROWS        wide projections (N >= 1536, K = 768: QKV, K | V, FFN-up): K in 4 slices, summed in fixed order
+ *                                    (k_splitk_reduce)
+ *   rows >= 1024    FUSED_ATTN_ROWS  mms_config.fuse_attention: a stream's QKV projection + attention in one kernel (qkv_attn.hip); 1 = the
+ *                                    two-kernel route's arithmetic (bit-identical to it), 2 = split-bf16 attention over 16-query tiles of a packed
+ *                                    sub-tile: a pair's logits depend on its place in the launch by fp32 round-off (<= 1e-4 relative)
+ *   rows <  4096    TALL_ROWS        the long-K projections in front of the encoder (K >= 2048, N = 768: zk kdd_conv1 as im2col, kdd_conv2 / visn_fc
+ *                                    / featureemb over the box rows): K in 8 slices
+ *   rows >= 4096    SPLITK_HALF_ROWS the LayerNorm-followed K >= 2048 projections (FFN-down) of the split-K regime: 4 K slices instead of 8
+ *   rows >= 5120    PP_WIDE_ROWS     [speed choice only: bit-identical across it]  wide projections (N >= 1536) on the persistent ping-pong engine
+ *                                    instead of the 128 x 256 tiles (same contraction order per element)
+ *   rows <  8192    SPLITK_ROWS      the N = 768 projections that a LayerNorm follows (attention output, FFN-down): K in 4 (K = 768) / 8 or 4 (K >=
+ *                                    2048) slices, summed by the LayerNorm kernel
+ *   rows >= 11264   SPLITK2_LO_ROWS  FFN-down (K = 3072) of launches below PP_ROWS: 2 K slices (one pass between SPLITK_ROWS and here)
+ *   rows >= 16384   PP_ROWS          [speed choice only: bit-identical across it]  persistent ping-pong engines for every projection (same
+ *                                    contraction order per element as the tiles: bit-identical, tested)
+ *   rows >= 98304   LNF_ROWS         mms_config.fuse_layernorm: bias + residual + LayerNorm in the GEMM epilogue (one-pass variance) -- not in a call
+ *                                    that runs on launch lanes, see LANE_ROWS / ENS_LANE_ROWS
+ *   rows <  200000  ENS_LANE_ROWS    mms_score_ensemble: the three members of a launch wave (rows of its longest member; ~5000 pairs) side by side on
+ *                                    three streams, every LayerNorm by its own kernel
+ *   rows <  400000  LANE_ROWS        lxmert calls (pairs x (text_len + 10) rows; ~12 500 pairs): the two streams' launch chains on two lanes, every
+ *                                    LayerNorm by its own kernel (with or without per-launch timing)
+ * GENERATED REGIMES END
+ * (below TINY_ROWS / SPLITK_ROWS / PP_ROWS a projection runs on the register-staged / LDS-DMA 128 x 256 tiles, one pass over K unless a line above says otherwise.)
  * Batch composition enters in two more places: lxmert with pack_tokens runs its language layers once per DISTINCT query when at least half of the pairs
  * share theirs (the rows of that stage = distinct queries x text_len), and label texts are encoded once per distinct 8-id tuple (rows = tuples).
  * mms_score_ensemble runs the three members of a launch wave of fewer than 5000 pairs side by side on three streams (same rule: every LayerNorm by its own kernel; a member's
@@ -240,12 +250,32 @@ int mms_fused_timing(mms_handle* h, double* ms_out, int64_t* launches_out, doubl
 /* ... and the executed FLOPs of the launches that ran on a side lane (lxmert's distinct-query stage): counted, not timed -- a launch that shares the chip has no duration of its own */
 int mms_side_lane_flops(mms_handle* h, double* flops_out);
 
-/* ---- debug / test hooks (kernel-level parity tests call the same kernels the scorers launch) ---- */
+/* ---- debug / test hooks: NOT part of the product ABI --------------------------------------------------------------------------------
+ * The kernel-level parity tests and tools/ call the same kernels the scorers launch through these; they are built into libmmscore.so (the
+ * tests must exercise the shipped binary) but may change with any revision and take no part in MMS_ABI_VERSION.  A host that scores pairs
+ * does not define MMS_TEST_HOOKS and does not see them. */
+#ifdef MMS_TEST_HOOKS
 int mms_debug_read_x(mms_handle* h, float* dst_dev, int64_t rows, void* stream); /* current hidden state -> fp32 [rows,768] */
 int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const float* w_f32_nk, int64_t N,
                  const float* bias, const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes,
-                 int32_t variant /* 0: the forward's per-shape engine choice; 1, 4, 16: register-staged tiles; 20 / 26: ping-pong
-                                    (one tile per workgroup / persistent); 27: three-pass ping-pong -- per CALL, no global state */,
+                 int32_t engine /* enum Engine of csrc/regimes.h, per CALL, no global state:
+ * GENERATED ENGINES BEGIN (tools/gen_regime_doc.py from csrc/regimes.h -- do not edit)
+ *     0 ENG_AUTO          the per-shape choice of a forward (gemm_dispatch.hip pick_engine)
+ *     1 ENG_TILE_128      gemm_tile.hip: register-staged 128 x 128 tile (the only tile for N % 256 != 0, and the three-pass tile of precision mode 3)
+ *     3 ENG_TILE_DMA      gemm_tile.hip: 128 x 256 tile, LDS-DMA double buffered, one workgroup per CU (launches of no more workgroups than CUs)
+ *     4 ENG_TILE          gemm_tile.hip: register-staged 128 x 256 tile, the default below PP_ROWS
+ *     5 ENG_SKINNY        gemm_skinny.hip: <= 128 rows, one workgroup per 16 output columns, K sliced over its waves (GemmParams::wave_k_slices)
+ *    16 ENG_TILE_256      gemm_tile.hip: 256 x 256 / 16 waves (kept for the kernel tests; no forward selects it since round 4)
+ *    20 ENG_PP            gemm_pp.hip: 256 x 256 ping-pong phases, one tile per workgroup
+ *    26 ENG_PP_PERSIST    gemm_pp.hip: the same, persistent workgroups (XCD-aware tile walk): launches of >= PP_ROWS rows
+ *    27 ENG_PPW           gemm_ppw.hip: 256 x 128 three-pass ping-pong (precision mode 3, >= PP_ROWS rows)
+ *    28 ENG_DW            lab build: gemm_dw.hip (128 x 256, two 4-wave workgroups per CU) -- measured and shelved
+ *    54 ENG_SKINNY_K4     kernel tests: the skinny kernel with 4 wave-level K slices
+ *    55 ENG_SKINNY_PARTS  gemm_skinny.hip with the K slices dealt to single-wave WORKGROUPS: GemmParams::k_splits fp32 partials (the split-K contract
+ *                         of the tiles)
+ *    58 ENG_SKINNY_K8     kernel tests: 8 wave-level K slices
+ * GENERATED ENGINES END
+ */,
                  float* c_f32, void* stream);
 /* fp8 GEMM (precision 4, MX-scaled fp8 MFMA) on fp32 operands: A and W are quantised exactly as the forward does it (A: e4m3 RNE of the
  * value; W: per output channel the smallest POWER OF TWO scale with max|w| / scale <= 448, e4m3 RNE of w / scale; the scale is applied
@@ -261,10 +291,10 @@ int mms_dbg_gemm_ln(const float* a_f32, int64_t M, int64_t K, const float* w_f32
  * partials from the skinny kernel instead (K slices dealt to workgroups, M <= 512): bit-identical to the tile engine's */
 int mms_dbg_proj_ln_splitk(const float* a_f32, int64_t M, int64_t K, const float* w_f32_nk, const float* bias, const float* resid_f32,
                            const float* gamma, const float* beta, int32_t splits, float* c_f32, void* stream);
-/* time one GEMM shape on random data (variant as in mms_dbg_gemm; 52: the MX-fp8 engine; 60 / 61: the LayerNorm kernel with / without
- * residual; 62 / 63: N = 768 projection + residual + LayerNorm as two kernels / as one launch with the fused epilogue) */
+/* time one GEMM shape on random data (`what`: an engine as in mms_dbg_gemm, or 52: the MX-fp8 engine; 60 / 61: the LayerNorm kernel with / without
+ * residual; 62 / 63: N = 768 projection + residual + LayerNorm as two kernels / as one launch with the fused epilogue -- api.hip enum BenchMode) */
 int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t act, int32_t out_planes, int32_t resid,
-                       int32_t variant, int32_t iters, float* ms_out);
+                       int32_t what, int32_t iters, float* ms_out);
 int mms_dbg_attention(const float* q, const float* k, const float* v, int64_t B, int32_t Sq, int32_t Sk,
                       const float* key_add, float* out_f32, void* stream);
 /* ONE fused QKV-projection + attention launch (qkv_attn.hip) on fp32 operands (all device pointers but n_sub_out): x [rows1 + rows2][768], the rows of stream 1
@@ -281,6 +311,7 @@ int mms_dbg_qkv_attn(const float* x, int64_t rows1, int64_t rows2, const int32_t
  * anything else: -1 */
 int64_t mms_dbg_counter(mms_handle* h, int32_t which);
 int mms_dbg_layernorm(const float* x, const float* gamma, const float* beta, int64_t M, float* out_f32, void* stream);
+#endif /* MMS_TEST_HOOKS */
 
 #ifdef __cplusplus
 }

@@ -488,7 +488,7 @@ int64_t kparts_side_need(const mms_handle* h, int64_t pairs);
 inline float* kp(const mms_handle* h) { return h->lane ? h->kparts_side : h->kparts; }
 inline Planes midp(const mms_handle* h) { return h->lane ? h->mid.at(h->mid_side_off) : h->mid; }
 // lxmert calls whose chunk has fewer token rows (pairs x (text_len + 10), padded) than this run their independent launch chains on two lanes
-constexpr int64_t LANE_ROWS_DEFAULT = 400000;      // measured (profiles/rd5_lanes.txt): +27 % at 256 pairs, +30 % at 1024, +28 % at 2048, +13 % at 4096, +8.6 % at 8192, +3 % at 16384 (= the query stage alone), +0.7 % at 30000 (query stage alone: +2 %)
+// LANE_ROWS_DEFAULT (regimes.h) = 400 000: measured (profiles/rd5_lanes.txt): +27 % at 256 pairs, +30 % at 1024, +28 % at 2048, +13 % at 4096, +8.6 % at 8192, +3 % at 16384 (= the query stage alone), +0.7 % at 30000 (query stage alone: +2 %)
 int64_t lane_rows() {
 #ifdef MMS_LAB
     static const int64_t v = getenv("MMS_LANE_ROWS") ? atoll(getenv("MMS_LANE_ROWS")) : LANE_ROWS_DEFAULT;      // A/B: 0 = one lane
@@ -631,7 +631,6 @@ int ensure_kparts(mms_handle* h, int64_t floats);
 // (wide projections: ONE launch where the split-K tile route needs two) or, where a LayerNorm / reduce launch follows anyway, over single-wave workgroups
 // that leave the tile engine's partials.  128, measured (profiles/rd4r_skinny_gemm.txt): above it the rows a workgroup pulls through one CU's fill path cost
 // more than the launch saved.
-constexpr int64_t SKINNY_ROWS_DEFAULT = 128;
 int64_t skinny_rows() {
 #ifdef MMS_LAB
     static const int64_t v = getenv("MMS_SKINNY_ROWS") ? atoll(getenv("MMS_SKINNY_ROWS")) : SKINNY_ROWS_DEFAULT;      // A/B: 0 = the split-K routes of round 4
@@ -648,7 +647,6 @@ bool skinny_shape(const mms_handle* h, int64_t M, int K) {
 // + k_splitk_reduce (sum in fixed order, bias, activation, head-major fp32 or planes) take 10 + 6.  The N = 768 projections use proj_ln() below (no reduce
 // launch at all).  1024, measured (profiles/rd4x_tile_engines_midsize.txt): zk 12 / 17 / 34 pairs -16 / -15 / -7 % against a bound of 256, lds 12 pairs -14 %;
 // from ~2000 rows on the partial traffic and the second launch cost more than the shorter K walk saves (zk 68 pairs +10 %, lds 50 pairs +20 % at a bound of 2048).
-constexpr int64_t TINY_ROWS_DEFAULT = 1024;
 int64_t tiny_rows() {
 #ifdef MMS_LAB
     static const int64_t v = getenv("MMS_TINY_ROWS") ? atoll(getenv("MMS_TINY_ROWS")) : TINY_ROWS_DEFAULT;      // A/B: row bound of the wide split-K route (<= 4096: kparts)
@@ -662,7 +660,6 @@ int64_t tiny_rows() {
 // this round (profiles/rd5_fused_rows.txt): 16 row tiles x 12 heads fill 192 CUs at 256 zk pairs, one launch of ~32 us where the 128 x 256 tile grid of the QKV projection
 // takes 47 (279 workgroups on 256 CUs: two rounds) and the attention kernel 16 -- zk 2.53 -> 2.34 ms at 256 pairs, lds 3.72 -> 3.38, lxmert 3.50 -> 3.28; down to 1024 rows
 // (= TINY_ROWS, where the wide projections' split-K route takes over) never slower
-constexpr int64_t FUSED_ATTN_ROWS_DEFAULT = 1024;
 int64_t fused_attn_rows() {
 #ifdef MMS_LAB
     static const int64_t v = getenv("MMS_FUSED_ROWS") ? atoll(getenv("MMS_FUSED_ROWS")) : FUSED_ATTN_ROWS_DEFAULT;
@@ -683,7 +680,6 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
     const bool wide = splittable && M < TINY_ROWS && N >= 1536 && K == H;
     // ... and the two long-K projections in front of the encoder at any small M: kdd_conv1 as im2col (K = 6144, M = 8 x distinct label texts: 96 serial
     // K steps, 170 us per call whatever the batch) and kdd_conv2 / visn_fc / featureemb (K = 2048) below TALL_ROWS box rows: eight K slices
-    constexpr int64_t TALL_ROWS = 4096;
     const bool tall = splittable && !wide && M < TALL_ROWS && N == H && K >= 2048 && K % 512 == 0;
     // a long-K projection of a few rows (kdd_conv1 as im2col: 80 rows x K = 6144 in a 1-pair call): its K slices go to single-wave WORKGROUPS of the skinny
     // kernel and k_splitk_reduce sums them -- in one workgroup per 16 columns every workgroup pulls all rows x all of K (2 MB) through one CU: 40 us
@@ -712,14 +708,14 @@ int gemm(mms_handle* h, hipStream_t st, Planes a, int lda, RowMap amap, const bf
         (skinny_tall ? h->skinny_launches : h->splitk_launches) += 1;
         p.bias = nullptr; p.act = ACT_NONE; p.out_kind = OUT_F32; p.c_f32 = kp(h); p.ldc = N; p.hm_rows = 0; p.hm_col0 = 0;
         p.k_splits = TINY_S; p.c_split_stride = part_stride;
-        if (skinny_tall) p.variant = 55;
+        if (skinny_tall) p.engine = ENG_SKINNY_PARTS;
     }
     auto tiny_reduce = [&]() {
         if (tiny) launch_splitk_reduce(kp(h), TINY_S, part_stride, (int)M, N, m_dev, bias, act, out.f32, out.ldc, out.hm_rows, out.hm_col0,
                                        out.pl.hi, out.pl.lo, out.ldp, st);
     };
     if (h->alternate) { p.reverse = h->flip; h->flip ^= 1; }
-    if (skinny && !skinny_tall) { p.variant = 5; p.k_splits = skinny_ks; h->skinny_launches += 1; }
+    if (skinny && !skinny_tall) { p.engine = ENG_SKINNY; p.wave_k_slices = skinny_ks; h->skinny_launches += 1; }
     if (h->timing && h->lane) p.flop_counter = h->flop_counter + 3;      // side lane: FLOPs only (slot 3, mms_side_lane_flops) -- a launch that shares the chip has no duration of its own
     if (h->timing && !h->lane) {      // (per-launch events and FLOP counts cover the main lane: a side-lane launch shares the chip with the launch beside it)
         if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
@@ -777,7 +773,6 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
 // Padded row bound of the fused bias + residual + LayerNorm epilogue.  Rounds 2-4: 16 384 (with the persistent engines).  Its tile carries eight residual K stages and a statistics exchange across the
 // three column tiles of a row panel; on a launch of a round or two that is latency the LayerNorm kernel does not add: with the two-kernel route zk takes 4.15 instead of 4.75 ms at 600 pairs, 6.33 / 6.99 at
 // 1024, 11.4 / 12.0 at 2048 and 19.7 / 19.5 at 4096 (122 880 rows: the epilogue wins from here on); lds 5.69 / 6.39 at 512, 10.6 / 11.8 at 1024, a tie at 2048 (81 920 rows) -- profiles/rd5_fuse_ln_midsize.txt
-constexpr int64_t LNF_ROWS_DEFAULT = 98304;
 int64_t lnf_rows() {
 #ifdef MMS_LAB
     static const int64_t v = getenv("MMS_LNF_ROWS") ? atoll(getenv("MMS_LNF_ROWS")) : LNF_ROWS_DEFAULT;
@@ -869,10 +864,7 @@ void ln_resid(mms_handle* h, hipStream_t st, const float* t, const float* g, con
 // profiles/rd4g_small_batch_kernels.txt).  Split-K: S copies of the tile grid contract K / S columns each into fp32 partials, and the
 // LayerNorm kernel that follows anyway sums them (fixed order: deterministic) and adds bias + residual -- no extra launch.  S depends on K
 // alone, so launches in this regime stay bit-identical across batch sizes.
-constexpr int64_t SPLITK_ROWS = 8192;      // padded row bound of the launch (the live count is on the device): zk calls of <= 273 pairs
-constexpr int KSPLIT_MAX = 8;
-constexpr int64_t SPLITK_HALF_ROWS = 4096;
-constexpr int64_t SPLITK2_LO_ROWS = 11264;
+// SPLITK_ROWS (regimes.h): padded row bound of the launch (the live count is on the device): zk calls of <= 273 pairs
 int splitk_for(const mms_handle* h, int64_t M, int K) {
     if (h->nsplit == 1 || h->f8) return 1;
     // 8192 .. 16383 rows: one pass over K -- except K = 3072 (FFN-down) from 11 264 rows on, in 2 slices: unsplit it is 130 .. 190 live workgroups walking 48 K steps on 256 CUs
@@ -947,7 +939,7 @@ int proj_ln(mms_handle* h, hipStream_t st, const Planes& a, int lda, RowMap amap
         p.out_kind = OUT_F32; p.c_f32 = kp(h); p.ldc = H; p.cmap = RowMap{0, 0, 0}; p.rmap = RowMap{0, 0, 0};
         p.k_splits = S; p.c_split_stride = (long long)M * H;
         p.m_dev = m_dev;
-        if (skinny) p.variant = 55;      // gemm_skinny.hip, K slices dealt to workgroups (same partials as the tile engine's: bit-identical)
+        if (skinny) p.engine = ENG_SKINNY_PARTS;      // gemm_skinny.hip, K slices dealt to workgroups (same partials as the tile engine's: bit-identical)
         if (h->timing && h->lane) p.flop_counter = h->flop_counter + 3;      // side lane: FLOPs only (slot 3, mms_side_lane_flops) -- a launch that shares the chip has no duration of its own
         if (h->timing && !h->lane) {
             if (h->ev_used + 2 > h->ev.size()) { if (int rc = grow_event_pair(h, h->ev)) return rc; }
@@ -2025,7 +2017,7 @@ int mms_score_ensemble(mms_handle* z, mms_handle* l, mms_handle* x, const mms_en
     // wave's feature split, join in front of the merge); same kernels, same operands -- and, as with lxmert's own lanes, every LayerNorm by its own kernel (the fused epilogue
     // needs its whole grid resident), which only matters above 409 pairs per wave.  Measured (profiles/rd5_lanes.txt): 3.52 -> 2.27 ms at 5 pairs, 10.3 -> 7.8 at 256,
     // 18.1 -> 13.9 at 600, 27.6 -> 22.6 at 1024, 46.3 -> 40.7 at 2048, 80.1 -> 77.8 at 4096.
-    int64_t ens_rows = 200000;
+    int64_t ens_rows = ENS_LANE_ROWS_DEFAULT;
 #ifdef MMS_LAB
     { static const int64_t v = getenv("MMS_ENS_LANE_ROWS") ? atoll(getenv("MMS_ENS_LANE_ROWS")) : 0; if (v) ens_rows = v; }
 #endif
@@ -2241,8 +2233,8 @@ static int dbg_fail(const char* m) { g_err = m; return MMS_ERR_HIP; }
 #define DBG_TRY(expr) do { if ((expr) != hipSuccess) return dbg_fail(#expr); } while (0)
 
 int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const float* w_f32_nk, int64_t N, const float* bias,
-                 const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes, int32_t variant, float* c_f32, void* stream) {
-    if (!a_f32 || !w_f32_nk || !c_f32 || M <= 0 || N % 128 || K % 64 || lda < K || lda % 32 || variant < 0) { g_err = "mms_dbg_gemm: bad argument"; return MMS_ERR_ARG; }
+                 const float* resid_f32, int32_t act, int32_t nsplit, int32_t out_planes, int32_t engine, float* c_f32, void* stream) {
+    if (!a_f32 || !w_f32_nk || !c_f32 || M <= 0 || N % 128 || K % 64 || lda < K || lda % 32 || engine < 0) { g_err = "mms_dbg_gemm: bad argument"; return MMS_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     bf16 *ap = nullptr, *wp = nullptr, *rp = nullptr, *cp = nullptr;
     float* wtmp = nullptr;
@@ -2253,7 +2245,7 @@ int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const fl
     GemmParams p{};
     p.a_hi = ap; p.a_lo = ap + MMS_PLANE_LO; p.lda = (int)lda; p.amap = RowMap{0, 0, 0}; p.cmap = RowMap{0, 0, 0};
     p.w = wp; p.w_lo = wp + N * K; p.bias = bias; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
-    p.variant = variant;      // 0: the per-shape choice of the forward; else ONE named tile engine (gemm_dispatch.hip)
+    p.engine = engine;      // enum Engine (regimes.h): ENG_AUTO = the per-shape choice of the forward; else ONE named engine
     if (resid_f32) {
         DBG_TRY(hipMalloc((void**)&rp, (size_t)M * N * 4));
         launch_split_f32(resid_f32, rp, rp + MMS_PLANE_LO, M * N, st);
@@ -2270,7 +2262,7 @@ int mms_dbg_gemm(const float* a_f32, int64_t M, int64_t K, int64_t lda, const fl
     DBG_TRY(hipStreamSynchronize(st));
     DBG_TRY(hipGetLastError());
     (void)hipFree(ap); (void)hipFree(wp); (void)hipFree(rp); (void)hipFree(cp); (void)wtmp;
-    if (!taken) { g_err = "mms_dbg_gemm: no engine takes this shape / variant"; return MMS_ERR_ARG; }
+    if (!taken) { g_err = "mms_dbg_gemm: no engine takes this shape"; return MMS_ERR_ARG; }
     return MMS_OK;
 }
 
@@ -2407,7 +2399,7 @@ int mms_dbg_proj_ln_splitk(const float* a_f32, int64_t M, int64_t K, const float
     p.w = wp; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = ACT_NONE;
     p.out_kind = OUT_F32; p.c_f32 = parts; p.ldc = (int)N;
     p.k_splits = splits; p.c_split_stride = (long long)M * N;
-    p.variant = skinny_parts && splits > 1 ? 55 : 4;
+    p.engine = skinny_parts && splits > 1 ? ENG_SKINNY_PARTS : ENG_TILE;
     if (splits == 1) p.bias = bias;
     launch_gemm(p, 2, st);
     LnResid r;
@@ -2435,8 +2427,18 @@ int64_t mms_dbg_counter(mms_handle* h, int32_t which) {
 }
 
 // GEMM micro-benchmark on random operands: returns the average kernel time (ms) over `iters` launches.
+// mms_dbg_gemm_bench's `what` beyond the engines of regimes.h: other kernels timed on the same random operands (tools/gemm_bench.py)
+enum BenchMode : int {
+    BENCH_MX = 50,               // lab: the fp16 + MX-fp8 "1.5 pass" engine (gemm_mx.hip)
+    BENCH_MX_HI = 51,            // lab: its high pass alone
+    BENCH_MX8 = 52,              // precision mode 4: gemm_mx8_kernel (e4m3 x e4m3)
+    BENCH_LN_RESID = 60,         // the LayerNorm kernel with the residual planes on M rows
+    BENCH_LN = 61,               // ... without
+    BENCH_PROJ_LN_2K = 62,       // N = 768 projection + residual + LayerNorm as two kernels (fp32 tensor in between)
+    BENCH_PROJ_LN_FUSED = 63,    // ... as ONE launch with the fused epilogue
+};
 int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t act, int32_t out_planes, int32_t resid,
-                       int32_t variant, int32_t iters, float* ms_out) {
+                       int32_t what, int32_t iters, float* ms_out) {      // what: an Engine (regimes.h) or a BenchMode below
     if (M <= 0 || N % 128 || K % 64 || iters <= 0 || !ms_out) { g_err = "mms_dbg_gemm_bench: bad argument"; return MMS_ERR_ARG; }
     float *af = nullptr, *wf = nullptr, *rf = nullptr, *bias = nullptr, *cf = nullptr;
     bf16 *ap = nullptr, *wp = nullptr, *rp = nullptr, *cp = nullptr;
@@ -2465,17 +2467,17 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
     if (resid) { p.r_hi = rp; p.r_lo = rp + MMS_PLANE_LO; p.ldr = (int)N; }
     if (out_planes) { p.out_kind = OUT_PLANES; p.c_hi = cp; p.c_lo = cp + MMS_PLANE_LO; p.ldp = (int)N; }
     else { p.out_kind = OUT_F32; p.c_f32 = cf; p.ldc = (int)N; }
-    p.variant = (variant < 50 || variant == 54 || variant == 58) ? variant : 0;      // (54 / 58: the skinny kernel with 4 / 8 K slices)
+    p.engine = engine_is_named(what) ? what : ENG_AUTO;
     hipEvent_t e0, e1;
     DBG_TRY(hipEventCreate(&e0)); DBG_TRY(hipEventCreate(&e1));
-    // variants 50 / 51: the precision-5 engine (gemm_mx.hip) / its high pass alone (lab) on the same random operands
+    // BENCH_MX / BENCH_MX_HI: the precision-5 engine (gemm_mx.hip) / its high pass alone (lab) on the same random operands
     f16 *a16 = nullptr, *w16 = nullptr, *c16 = nullptr;
     unsigned char *a8 = nullptr, *w8 = nullptr, *c8 = nullptr;
     unsigned* ws4 = nullptr;
     float* cs = nullptr;
     GemmParams pm{};
-    const bool mx = variant == 50 || variant == 51 || variant == 52;      // 52: precision mode 4 (gemm_mx8_kernel, e4m3 x e4m3)
-    if (variant == 52) {
+    const bool mx = what == BENCH_MX || what == BENCH_MX_HI || what == BENCH_MX8;      // 52: precision mode 4 (gemm_mx8_kernel, e4m3 x e4m3)
+    if (what == BENCH_MX8) {
         if (N % 256 || K % 128 || resid) { g_err = "mms_dbg_gemm_bench: mx8 engine needs N % 256 == 0, K % 128 == 0, no residual"; return MMS_ERR_ARG; }
         const int64_t Mp = (M + 255) / 256 * 256;
         DBG_TRY(hipMalloc((void**)&a8, (size_t)Mp * K)); DBG_TRY(hipMemset(a8, 0, (size_t)Mp * K));
@@ -2499,21 +2501,21 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
         pm.a_hi = (const bf16*)a16; pm.a8 = a8; pm.w = (const bf16*)w16; pm.w8 = w8; pm.w8_scale4 = ws4; pm.col_scale = cs; pm.w_lo = nullptr;
         if (out_planes) { pm.out_kind = OUT_H3; pm.c_h16 = c16; pm.c_l8 = c8; pm.ldh = (int)N; }
     }
-    // variants 62 / 63: the N = 768 projection + residual + LayerNorm as two kernels (fp32 tensor in between) / as ONE launch with the
+    // BENCH_PROJ_LN_2K / BENCH_PROJ_LN_FUSED: the N = 768 projection + residual + LayerNorm as two kernels (fp32 tensor in between) / as ONE launch with the
     // fused epilogue (gemm_pp_ln.h); both leave split planes
     float* ln_stats = nullptr; int* ln_ctl = nullptr; unsigned ln_tag = 0x1000u;
-    if (variant == 62 || variant == 63) {
-        if (N != H || nsplit != 2) { g_err = "mms_dbg_gemm_bench: variants 62 / 63 need N == 768, nsplit == 2"; return MMS_ERR_ARG; }
+    if (what == BENCH_PROJ_LN_2K || what == BENCH_PROJ_LN_FUSED) {
+        if (N != H || nsplit != 2) { g_err = "mms_dbg_gemm_bench: the projection + LayerNorm modes need N == 768, nsplit == 2"; return MMS_ERR_ARG; }
         DBG_TRY(hipMalloc((void**)&ln_stats, (size_t)(M + 256) * 48)); DBG_TRY(hipMemset(ln_stats, 0, (size_t)(M + 256) * 48));
         DBG_TRY(hipMalloc((void**)&ln_ctl, 8));
     }
     auto run = [&]() {
-        if (variant == 62 || variant == 63) {
+        if (what == BENCH_PROJ_LN_2K || what == BENCH_PROJ_LN_FUSED) {
             GemmParams q = p;
             q.out_kind = OUT_F32; q.c_f32 = cf; q.ldc = H; q.r_hi = nullptr; q.r_lo = nullptr;
             LnResid res;
             res.hi = rp; res.lo = rp + MMS_PLANE_LO; res.ld = H;
-            if (variant == 62) {
+            if (what == BENCH_PROJ_LN_2K) {
                 launch_gemm(q, 2, 0);
                 launch_ln_to_planes(cf, H, bias, bias, cp, cp + MMS_PLANE_LO, H, (int)M, 0, nullptr, res);
                 return true;
@@ -2526,25 +2528,25 @@ int mms_dbg_gemm_bench(int64_t M, int64_t N, int64_t K, int32_t nsplit, int32_t 
             launch_ln_to_planes(cf, H, bias, bias, cp, cp + MMS_PLANE_LO, H, (int)M, 0, nullptr, res);
             return true;
         }
-        if (variant == 60 || variant == 61) {     // the LayerNorm kernel (with / without the residual planes) on M rows: HBM-bound, 9 / 6 KB per row
+        if (what == BENCH_LN_RESID || what == BENCH_LN) {     // the LayerNorm kernel (with / without the residual planes) on M rows: HBM-bound, 9 / 6 KB per row
             if (N != H) return false;
             LnResid res;
-            if (variant == 60) { res.hi = rp; res.lo = rp + MMS_PLANE_LO; res.ld = H; }
+            if (what == BENCH_LN_RESID) { res.hi = rp; res.lo = rp + MMS_PLANE_LO; res.ld = H; }
             launch_ln_to_planes(cf, H, bias, bias, cp, cp + MMS_PLANE_LO, H, (int)M, 0, nullptr, res);
             return true;
         }
         if (!mx) { launch_gemm(p, nsplit, 0); return true; }
 #ifdef MMS_LAB
-        if (variant == 51) return launch_gemm_mx_hi_only(pm, 0);
+        if (what == BENCH_MX_HI) return launch_gemm_mx_hi_only(pm, 0);
 #endif
-        if (variant == 52) return launch_gemm_mx8(pm, 0);
+        if (what == BENCH_MX8) return launch_gemm_mx8(pm, 0);
 #ifdef MMS_LAB
         return launch_gemm_mx(pm, 0);
 #else
         return false;     // 50 / 51: lab build only
 #endif
     };
-    if (!run()) { g_err = "mms_dbg_gemm_bench: variant not available"; return MMS_ERR_ARG; }
+    if (!run()) { g_err = "mms_dbg_gemm_bench: engine / mode not available"; return MMS_ERR_ARG; }
     run();
     DBG_TRY(hipEventRecord(e0, 0));
     for (int i = 0; i < iters; ++i) run();

@@ -9,7 +9,7 @@
 // twice the bf16 rate per flop -- with its hardware block scales used as plain per-row powers of two: the weight operand's lane scale
 // is 2^(e16-e8) of its output channel, the activation operand's the constant 2^-SA, so both passes accumulate in the same units and
 // the epilogue applies 2^-e16[n] (exact).  The low term is 2^-11 of the product and carries 4 bits of each operand: the sum is good to
-// ~2^-15 relative (two bf16 planes: 2^-17), measured per model in tests/test_round3_gpu.py.
+// ~2^-15 relative (two bf16 planes: 2^-17), measured per model in tests/test_launch_size_chost_ndcg_gpu.py.
 //
 // Engine = gemm_pp.hip's: 256x256 tile, 8 waves 2(M) x 4(N), 128x64 outputs per wave, wave rows staggered by one barrier (ping-pong),
 // persistent workgroups, swapped MFMA operands + LDS-free epilogue.  LDS (all 160 KiB):

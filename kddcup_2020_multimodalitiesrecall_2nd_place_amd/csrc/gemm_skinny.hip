@@ -150,14 +150,14 @@ bool launch_wpl(const GemmParams& p, int ks, hipStream_t st) {
 }  // namespace
 
 // false: not a launch for this kernel (more than 512 rows, another precision mode or output kind, residual in the epilogue) -- the caller takes
-// the tile engine.  GemmParams::k_splits names the number of K slices (= waves per workgroup: 1, 4 or 8; 0 -> 1): api.hip passes the split factor
+// the tile engine.  GemmParams::wave_k_slices names the number of K slices (= waves per workgroup: 1, 4 or 8; 0 -> 1): api.hip passes the split factor
 // the tile-engine route of the SAME projection uses for launches of up to 255 rows (4 for the wide and the LayerNorm-followed K = 768 projections, 8 for the
 // long-K ones, 1 = one wave walking all of K for the rest).  A slice is accumulated in the tile engine's order (per 32-wide K block: hi plane, then lo plane)
 // and the slices are summed in the same fixed order as k_splitk_reduce / k_ln_to_planes sum their partials, so a launch here is BIT-IDENTICAL to the
 // split-K tile route it replaces: the 128-row bound is not a numerical regime boundary.
 bool launch_gemm_skinny(const GemmParams& p, int nsplit, hipStream_t st) {
     if (p.M <= 0) return true;
-    const int ks = p.k_splits > 1 ? p.k_splits : 1;
+    const int ks = p.wave_k_slices > 1 ? p.wave_k_slices : 1;
     if ((nsplit != 2 && nsplit != 3) || p.M > SKINNY_MAX_ROWS || p.N % 16 || p.K % (64 * ks) || p.f8 || p.r_hi || p.ln_gamma) return false;
     if (nsplit == 3 && !p.w_lo) return false;
     if (p.out_kind != OUT_F32 && p.out_kind != OUT_PLANES) return false;

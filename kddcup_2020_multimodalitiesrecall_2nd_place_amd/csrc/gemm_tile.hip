@@ -247,17 +247,17 @@ static void launch_cfg(const GemmParams& p, hipStream_t st) {
 }
 
 template <int NSPLIT>
-static bool launch_variant(const GemmParams& p, int variant, hipStream_t st) {
-    switch (variant) {
-        case 1: launch_cfg<NSPLIT, 128, 128, 2, 2, 0, 0>(p, st); return true;                               // reg-staged 128x128 (N % 256 != 0)
-        case 3: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 0>(p, st); return true;  // LDS-DMA, double buffered, 1 WG/CU: launches of no more workgroups than CUs (gemm_dispatch.hip)
-        case 4: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 0, 0>(p, st); return true;  // reg-staged 128x256 (default)
-        case 16: if (p.N % 256) return false; launch_cfg<NSPLIT, 256, 256, 4, 4, 0, 0>(p, st); return true; // 16 waves, 1 WG/CU, 25 % fewer operand bytes per flop
+static bool launch_variant(const GemmParams& p, Engine tile, hipStream_t st) {
+    switch (tile) {
+        case ENG_TILE_128: launch_cfg<NSPLIT, 128, 128, 2, 2, 0, 0>(p, st); return true;                               // reg-staged 128x128 (N % 256 != 0)
+        case ENG_TILE_DMA: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 1, 0>(p, st); return true;  // LDS-DMA, double buffered, 1 WG/CU: launches of no more workgroups than CUs (gemm_dispatch.hip)
+        case ENG_TILE: if (p.N % 256) return false; launch_cfg<NSPLIT, 128, 256, 2, 4, 0, 0>(p, st); return true;  // reg-staged 128x256 (default)
+        case ENG_TILE_256: if (p.N % 256) return false; launch_cfg<NSPLIT, 256, 256, 4, 4, 0, 0>(p, st); return true; // 16 waves, 1 WG/CU, 25 % fewer operand bytes per flop
         default: return false;
     }
 }
 
-bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st) {
+bool launch_gemm_tile(const GemmParams& p, int nsplit, Engine tile, hipStream_t st) {
     if (p.M <= 0) return true;
     if (p.k_splits > 1 && (p.K % (64 * p.k_splits) || p.out_kind != OUT_F32 || p.hm_rows || p.bias || p.r_hi || p.act != ACT_NONE)) return false;
     if (nsplit == 3) {   // A and W both split: 128x128 tile (4 operand planes x 16 KiB = 64 KiB, 2 workgroups / CU)
@@ -265,5 +265,5 @@ bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t 
         launch_cfg<3, 128, 128, 2, 2, 0, 0>(p, st);
         return true;
     }
-    return nsplit == 2 ? launch_variant<2>(p, variant, st) : launch_variant<1>(p, variant, st);
+    return nsplit == 2 ? launch_variant<2>(p, tile, st) : launch_variant<1>(p, tile, st);
 }

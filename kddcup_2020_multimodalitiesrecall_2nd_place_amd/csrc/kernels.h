@@ -1,6 +1,7 @@
 // Host-side launcher declarations for the libmmscore kernels (all launches are async on `st`).
 #pragma once
 #include "common.h"
+#include "regimes.h"
 
 // ---------------------------------------------------------------------------------------------
 // GEMM  C[M,N] = act(A[M,K] * W[N,K]^T + bias (+ residual))      (gemm.hip)
@@ -51,8 +52,9 @@ struct GemmParams {
     // contracts K columns [s * K / k_splits, (s + 1) * K / k_splits) (a multiple of 64) and writes its fp32 partial to c_f32 + s * c_split_stride;
     // bias / residual / activation are NOT applied (the LayerNorm kernel behind it sums the partials: LnResid::nparts)
     int k_splits; long long c_split_stride;
-    int variant;                 // 0: per-shape choice (gemm_dispatch.hip); tests name ONE tile engine per call (mms_dbg_gemm): 1, 4, 16 register-staged
-                                 // tiles, 20 / 26 ping-pong (one tile per workgroup / persistent), 27 three-pass ping-pong; lab build: 3, 28
+    int wave_k_slices;           // ENG_SKINNY only: K slices dealt to the WAVES of a workgroup (1, 4 or 8; 0 -> 1), summed inside it -- bias / activation still in the epilogue.
+                                 // NOT the split-K contract above: the two never share a field (ADVICE r4's fall-through bug lived in that overlap)
+    int engine;                  // enum Engine (regimes.h).  ENG_AUTO: the per-shape choice (gemm_dispatch.hip pick_engine); else ONE named engine
     unsigned long long* ln_dbg;  // lab build only: per-tile phase stamps [virtual tile][6] of wall_clock64 (tools/ln_trace.py); nullptr otherwise
 };
 // CUs of the CURRENT device rounded down to a multiple of 8 (one per XCD-slot), cached per device ordinal; thread-safe (gemm_dispatch.hip)
@@ -60,13 +62,13 @@ int device_cu_count();
 // padded row bound from which the persistent ping-pong engines (and the fused LayerNorm epilogue) take a launch (gemm_dispatch.hip)
 int pp_rows();
 bool launch_gemm(const GemmParams& p, int nsplit, hipStream_t st);      // false: no engine took the shape, nothing was launched
-bool launch_gemm_tile(const GemmParams& p, int nsplit, int variant, hipStream_t st);  // gemm_tile.hip
-bool launch_gemm_skinny_parts(const GemmParams& p, int nsplit, hipStream_t st);        // ... with the K slices dealt to workgroups: k_splits fp32 partials, c_split_stride apart (variant 55; the LayerNorm kernel sums them)
-bool launch_gemm_skinny(const GemmParams& p, int nsplit, hipStream_t st);              // gemm_skinny.hip: a handful of rows (api.hip: <= 128), precision modes 2 and 3, one workgroup per 16 output columns, K split over its waves (variant 5); false: not taken
+bool launch_gemm_tile(const GemmParams& p, int nsplit, Engine tile, hipStream_t st);  // gemm_tile.hip: ENG_TILE_128 / ENG_TILE_DMA / ENG_TILE / ENG_TILE_256
+bool launch_gemm_skinny_parts(const GemmParams& p, int nsplit, hipStream_t st);        // ... with the K slices dealt to workgroups: k_splits fp32 partials, c_split_stride apart (ENG_SKINNY_PARTS; the LayerNorm kernel sums them)
+bool launch_gemm_skinny(const GemmParams& p, int nsplit, hipStream_t st);              // gemm_skinny.hip: a handful of rows (api.hip: <= 128), precision modes 2 and 3, one workgroup per 16 output columns, K split over its waves (ENG_SKINNY, GemmParams::wave_k_slices); false: not taken
 #ifdef MMS_LAB
-bool launch_gemm_dw(const GemmParams& p, int nsplit, hipStream_t st);                                                       // lab: gemm_dw.hip (variant 28: 128x256 tiles, two 4-wave workgroups per CU)
+bool launch_gemm_dw(const GemmParams& p, int nsplit, hipStream_t st);                                                       // lab: gemm_dw.hip (ENG_DW: 128x256 tiles, two 4-wave workgroups per CU)
 #endif
-bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist = false);                     // gemm_pp.hip (variant 20: 256x256 ping-pong phases)
+bool launch_gemm_pp(const GemmParams& p, int nsplit, int diag, hipStream_t st, bool persist = false);                     // gemm_pp.hip (ENG_PP / ENG_PP_PERSIST: 256x256 ping-pong phases)
 bool launch_gemm_pp_ln(const GemmParams& p, int nsplit, hipStream_t st);                 // gemm_pp.hip + gemm_pp_ln.h: N = 768 with the fused residual + LayerNorm epilogue (nsplit 2)
 #ifdef MMS_LAB
 bool launch_gemm_mx_hi_only(const GemmParams& p, hipStream_t st);                        // lab: timing reference, the high pass alone

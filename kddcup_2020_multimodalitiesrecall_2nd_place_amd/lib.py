@@ -60,6 +60,10 @@ class EnsembleBatch(C.Structure):
 
 ABI_VERSION = 6     # include/mmscore.h MMS_ABI_VERSION
 
+# enum Engine of csrc/regimes.h (mms_dbg_gemm / mms_dbg_gemm_bench name ONE GEMM engine per call; tests/test_abi.py holds the two lists together)
+ENGINES = {"ENG_AUTO": 0, "ENG_TILE_128": 1, "ENG_TILE_DMA": 3, "ENG_TILE": 4, "ENG_SKINNY": 5, "ENG_TILE_256": 16, "ENG_PP": 20, "ENG_PP_PERSIST": 26,
+           "ENG_PPW": 27, "ENG_DW": 28, "ENG_SKINNY_K4": 54, "ENG_SKINNY_PARTS": 55, "ENG_SKINNY_K8": 58}
+
 EXPORTS = ("mms_version", "mms_global_error", "mms_create", "mms_destroy", "mms_last_error", "mms_load_weight",
            "mms_finalize", "mms_score_zk", "mms_score_lds", "mms_score_lxmert", "mms_score_ensemble", "mms_gemm_timing", "mms_gemm_timing_class",
            "mms_debug_read_x", "mms_dbg_gemm", "mms_dbg_gemm_f8", "mms_dbg_gemm_ln", "mms_dbg_proj_ln_splitk", "mms_dbg_attention", "mms_dbg_qkv_attn", "mms_dbg_layernorm",

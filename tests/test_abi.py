@@ -163,23 +163,43 @@ int main(void) {
 
 
 def test_header_lists_the_size_regime_bounds_the_library_uses():
-    """include/mmscore.h documents every launch-size bound that changes a summation order or a route; the numbers there must be the constants of the sources."""
-    import re
-    csrc = os.path.join(ROOT, "kddcup_2020_multimodalitiesrecall_2nd_place_amd", "csrc")
-    api = open(os.path.join(csrc, "api.hip")).read()
-    disp = open(os.path.join(csrc, "gemm_dispatch.hip")).read()
+    """csrc/regimes.h is the ONE table of launch-size bounds and engine numbers: include/mmscore.h carries it verbatim (generated), api.hip and
+    gemm_dispatch.hip define no bound of their own and compare engines by name, lib.py mirrors the enum."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_regime_doc", os.path.join(ROOT, "tools", "gen_regime_doc.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    consts, table, engines = gen.parse()
+    assert {t[0]: t[3] for t in table} == {"SKINNY_ROWS": 128, "TINY_ROWS": 1024, "FUSED_ATTN_ROWS": 1024, "TALL_ROWS": 4096, "SPLITK_HALF_ROWS": 4096,
+                                           "PP_WIDE_ROWS": 5120, "SPLITK_ROWS": 8192, "SPLITK2_LO_ROWS": 11264, "PP_ROWS": 16384, "LNF_ROWS": 98304,
+                                           "ENS_LANE_ROWS": 200000, "LANE_ROWS": 400000}
+    assert [t[3] for t in table] == sorted(t[3] for t in table)
     hdr = open(os.path.join(ROOT, "include", "mmscore.h")).read()
+    assert gen.render(hdr) == hdr, "include/mmscore.h is stale: run python tools/gen_regime_doc.py"
+    for t in table:                                    # every bound, by name and value, between the markers
+        assert re.search(r"rows\s+%s\s+%d\s+%s\b" % (re.escape(t[1]), t[3], t[0]), hdr), t[0]
+    csrc = os.path.join(ROOT, "kddcup_2020_multimodalitiesrecall_2nd_place_amd", "csrc")
+    api, disp = open(os.path.join(csrc, "api.hip")).read(), open(os.path.join(csrc, "gemm_dispatch.hip")).read()
+    for src in (api, disp):                            # no second definition of a bound, no engine compared by number
+        for name in consts:
+            assert not re.search(r"constexpr\s+int(?:64_t)?\s+%s\s*=" % name, src), name
+        assert not re.search(r"\b(?:variant|engine|e)\s*[!=]=\s*\d", src)
+    for name in ("PP_ROWS_DEFAULT", "PP_WIDE_ROWS_DEFAULT"):
+        assert name in disp
+    for name in ("SKINNY_ROWS_DEFAULT", "TINY_ROWS_DEFAULT", "FUSED_ATTN_ROWS_DEFAULT", "TALL_ROWS", "SPLITK_HALF_ROWS", "SPLITK_ROWS", "SPLITK2_LO_ROWS", "LNF_ROWS_DEFAULT",
+                 "ENS_LANE_ROWS_DEFAULT", "LANE_ROWS_DEFAULT"):
+        assert name in api, name
+    assert {n: v for n, v, _ in engines if n != "ENG_DIAG_BASE"} == lib.ENGINES
 
-    def const(text, name):
-        m = re.search(r"constexpr\s+int(?:64_t)?\s+%s\s*=\s*(\d+)\s*;" % name, text)
-        assert m, name
-        return int(m.group(1))
-    bounds = {"SKINNY_ROWS_DEFAULT": const(api, "SKINNY_ROWS_DEFAULT"), "TINY_ROWS_DEFAULT": const(api, "TINY_ROWS_DEFAULT"), "FUSED_ATTN_ROWS_DEFAULT": const(api, "FUSED_ATTN_ROWS_DEFAULT"),
-              "SPLITK_HALF_ROWS": const(api, "SPLITK_HALF_ROWS"), "SPLITK_ROWS": const(api, "SPLITK_ROWS"), "SPLITK2_LO_ROWS": const(api, "SPLITK2_LO_ROWS"),
-              "LNF_ROWS_DEFAULT": const(api, "LNF_ROWS_DEFAULT"), "LANE_ROWS_DEFAULT": const(api, "LANE_ROWS_DEFAULT")}
-    assert bounds == {"SKINNY_ROWS_DEFAULT": 128, "TINY_ROWS_DEFAULT": 1024, "FUSED_ATTN_ROWS_DEFAULT": 1024, "SPLITK_HALF_ROWS": 4096, "SPLITK_ROWS": 8192, "SPLITK2_LO_ROWS": 11264,
-                      "LNF_ROWS_DEFAULT": 98304, "LANE_ROWS_DEFAULT": 400000}, bounds
-    assert re.search(r"int pp_rows\(\)[^}]*return 16384;", disp, re.S) and re.search(r"int pp_wide_rows\(\)[^}]*return 5120;", disp, re.S)
-    regimes = hdr[hdr.index("A launch's regime is decided by its PADDED row bound"):hdr.index("int mms_score_zk(")]
-    for n in ("128", "1024", "4096", "8192", "11264", "16384", "98304", "400 000", "5120", "5000"):
-        assert n in regimes, n
+
+def test_test_hooks_are_fenced_out_of_the_product_header(tmp_path):
+    """A C host that includes mmscore.h sees the scoring ABI only; the mms_dbg_* hooks need -DMMS_TEST_HOOKS (they are still exported by the library)."""
+    hdr = os.path.join(ROOT, "include")
+    src = tmp_path / "t.c"
+    src.write_text('#include "mmscore.h"\nint main(void) { return (int)(long)&mms_dbg_counter; }\n')
+    plain = subprocess.run(["gcc", "-I", hdr, "-fsyntax-only", "-Werror=implicit-function-declaration", str(src)], capture_output=True, text=True)
+    assert plain.returncode != 0 and "mms_dbg_counter" in plain.stderr
+    hooks = subprocess.run(["gcc", "-I", hdr, "-DMMS_TEST_HOOKS", "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert hooks.returncode == 0, hooks.stderr
+    src.write_text('#include "mmscore.h"\nint main(void) { return mms_version() == MMS_ABI_VERSION ? 0 : 1; }\n')
+    assert subprocess.run(["gcc", "-I", hdr, "-fsyntax-only", "-Wall", "-Werror", str(src)], capture_output=True, text=True).returncode == 0

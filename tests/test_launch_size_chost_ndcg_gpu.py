@@ -1,4 +1,4 @@
-"""GPU suite, round 3: launch-size independence in every precision mode (the big-M engines against the small-tile engines on
+"""GPU suite: launch-size independence in every precision mode (the big-M engines against the small-tile engines on
 the SAME pairs), head-major stores of the three-pass engine, fp8 x fused ensemble, full-depth nDCG@5 parity."""
 import numpy as np
 import pytest

@@ -16,5 +16,5 @@ for lib in libmmscore_lab.so libmmscore_lab_n4.so libmmscore_lab_n5.so; do
   done
 done
 echo "== parity of the 5-slot build (fp8 GEMM vs numpy, precision-4 deviation test, shallow logits)"
-MMS_LAB_LIB=$C/libmmscore_lab_n5.so timeout 600 python tools/pytest_lab.py tests/test_round2_gpu.py -q -x -p no:cacheprovider -k "fp8" 2>&1 | tail -3
-MMS_LAB_LIB=$C/libmmscore_lab_n4.so timeout 600 python tools/pytest_lab.py tests/test_round2_gpu.py -q -x -p no:cacheprovider -k "fp8" 2>&1 | tail -3
+MMS_LAB_LIB=$C/libmmscore_lab_n5.so timeout 600 python tools/pytest_lab.py tests/test_gemm_routes_gpu.py tests/test_model_routes_gpu.py -q -x -p no:cacheprovider -k "fp8" 2>&1 | tail -3
+MMS_LAB_LIB=$C/libmmscore_lab_n4.so timeout 600 python tools/pytest_lab.py tests/test_gemm_routes_gpu.py tests/test_model_routes_gpu.py -q -x -p no:cacheprovider -k "fp8" 2>&1 | tail -3

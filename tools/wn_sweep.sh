@@ -19,4 +19,4 @@ done
 done
 echo "== $lib lds"; MMS_LAB_LIB=$C/libmmscore_lab.so run --model lds; MMS_LAB_LIB=$C/libmmscore_lab_x.so run --model lds
 echo "== parity (WN=2 build)"
-MMS_LAB_LIB=$C/libmmscore_lab_x.so timeout 900 python tools/pytest_lab.py tests/test_parity_gpu.py tests/test_round2_gpu.py -q -x -p no:cacheprovider -k "full_size or full_depth or testB or fp8 or dense_and or stagewise" 2>&1 | tail -4
+MMS_LAB_LIB=$C/libmmscore_lab_x.so timeout 900 python tools/pytest_lab.py tests/test_parity_gpu.py tests/test_model_routes_gpu.py tests/test_gemm_routes_gpu.py -q -x -p no:cacheprovider -k "full_size or full_depth or testB or fp8 or dense_and or stagewise" 2>&1 | tail -4
