@@ -990,25 +990,33 @@ __global__ __launch_bounds__(512) void qkv_attn2_kernel(const QkvAttnParams p) {
         ++s;
         // park this tile's metadata in LDS (every wave passes a barrier between its own writes and the first read)
         if (wave >= NW / 2) {
-            const int t = tid - 256, u = t >> 7;
+            int tid_here = tid;
+            asm volatile("" : "+v"(tid_here));      // opaque: the LDS addresses below are computed HERE -- hoisted above the main loop they were spilled to scratch
+            const int t = tid_here - 256, u = t >> 7;
             const int4 sa = u ? sub1 : sub0;
             if ((t & 127) < sa.w) {      // the pair's rows learn which sub-tile rows their queries attend: its own rows, or (CROSS) its rows in the other stream
                 const int r1 = meta_a & 255, c1 = (meta_a >> 8) & 255;
+                // (plain loops of <= 48 trips: unrolled and vectorised they cost a VGPR spill whose reloads -- s_waitcnt vmcnt(0) -- drained the ring's LDS-DMA loads)
                 if (cross) {
                     const int r2 = sa.y + ((meta_a >> 16) & 255), c2 = (meta_a >> 24) & 255;
+#pragma clang loop unroll(disable) vectorize(disable)
                     for (int r = 0; r < c1; ++r) m_rowmeta[u * SUB + r1 + r] = r2 | ((r2 + c2) << 16);
+#pragma clang loop unroll(disable) vectorize(disable)
                     for (int r = 0; r < c2; ++r) m_rowmeta[u * SUB + r2 + r] = r1 | ((r1 + c1) << 16);
                 } else {
+#pragma clang loop unroll(disable) vectorize(disable)
                     for (int r = 0; r < c1; ++r) m_rowmeta[u * SUB + r1 + r] = r1 | ((r1 + c1) << 16);
                 }
             }
         }
         stage(std::false_type{}, std::integral_constant<int, -1>{}, s, slot);        // stage ns-1
         if (wave < NW / 2) {
-            m_keyadd[tid] = __int_as_float(meta_a) * LOG2E;
-            const int u = tid >= SUB, i = tid - u * SUB;
-            if (i >= (u ? sub1.y + sub1b.y : sub0.y + sub0b.y)) m_rowmeta[tid] = 0;      // rows behind the last pair attend nothing
-            if (tid < BN) m_bias[tid] = __int_as_float(meta_b);
+            int tid_here = tid;
+            asm volatile("" : "+v"(tid_here));      // (as above)
+            m_keyadd[tid_here] = __int_as_float(meta_a) * LOG2E;
+            const int u = tid_here >= SUB, i = tid_here - u * SUB;
+            if (i >= (u ? sub1.y + sub1b.y : sub0.y + sub0b.y)) m_rowmeta[tid_here] = 0;      // rows behind the last pair attend nothing
+            if (tid_here < BN) m_bias[tid_here] = __int_as_float(meta_b);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             qa_barrier();     // re-align the halves: nobody reads the ring any more
         }
