@@ -77,6 +77,11 @@ int mmf_featurize_spans(const mmf_context* c, const char* data, const int64_t* s
  * `data` covered (resume the next call there).  Returns the number of records found, or -1. */
 int64_t mmf_split_lines(const char* data, int64_t len, int64_t* starts, int64_t* ends, int64_t max_lines, int64_t* consumed);
 
+/* query_id (the last tab-separated field) of `n` record spans, without decoding anything: what a rank needs to find ITS contiguous
+ * query block of a shared TSV file (pipeline.stream_scores_tsv(shard=(rank, world))).  Returns 0, or
+ * -1000 - index of the first record whose last field is not an integer. */
+int mmf_query_ids(const char* data, const int64_t* starts, const int64_t* ends, int64_t n, int64_t* out);
+
 /* Map the pages of [addr, addr + len) -- a read-only file mapping about to be split and decoded -- on `threads` threads
  * (MADV_POPULATE_READ per 2 MB piece).  A 50 KB record is ~12 pages; left to demand faulting, the ONE thread that splits
  * lines takes the faults of the whole file (fault-around maps the rest of each record with its head), which bounded the

@@ -498,6 +498,19 @@ int64_t mmf_split_lines(const char* data, int64_t len, int64_t* starts, int64_t*
     return n;
 }
 
+int mmf_query_ids(const char* data, const int64_t* starts, const int64_t* ends, int64_t n, int64_t* out) {
+    if (!data || !starts || !ends || !out || n < 0) { g_err = "mmf_query_ids: bad argument"; return -1; }
+    for (int64_t i = 0; i < n; ++i) {
+        const char* line = data + starts[i];
+        int64_t len = ends[i] - starts[i];
+        while (len > 0 && is_ascii_space((unsigned char)line[len - 1])) --len;
+        int64_t k = len;
+        while (k > 0 && line[k - 1] != '\t') --k;              // the last field: query_id of the 9-field record (a few bytes from the end; the base64 fields are never scanned)
+        if (k == 0 || !parse_i64(line + k, len - k, &out[i])) { g_err = "record " + std::to_string(i) + ": no integer query id in the last field"; return (int)(-1000 - (i < 2000000000 ? i : 2000000000)); }
+    }
+    return 0;
+}
+
 int mmf_prefault(const mmf_context* c, const void* addr, int64_t len, int32_t threads) {
     if (!c || !addr || len < 0) { g_err = "mmf_prefault: bad argument"; return -1; }
     if (len == 0) return 0;

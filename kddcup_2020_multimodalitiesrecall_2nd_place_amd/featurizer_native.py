@@ -17,7 +17,7 @@ from .config import FEAT_DIM, LABEL_LEN, N_BOX
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmmfeat.so")
 EXPORTS = ("mmf_create", "mmf_destroy", "mmf_last_error", "mmf_set_label", "mmf_tokenize_ascii", "mmf_featurize",
-           "mmf_featurize_spans", "mmf_split_lines", "mmf_b64_tier", "mmf_prefault", "mmf_release_later")
+           "mmf_featurize_spans", "mmf_split_lines", "mmf_b64_tier", "mmf_prefault", "mmf_release_later", "mmf_query_ids")
 
 
 class BatchOut(C.Structure):
@@ -52,6 +52,7 @@ def load(path=None):
             l.mmf_b64_tier.argtypes = [C.c_int32]
             l.mmf_prefault.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
             l.mmf_release_later.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+            l.mmf_query_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         _lib = l
     return _lib
 
@@ -163,11 +164,28 @@ class NativeFeaturizer:
         arr["keep"] = keep
         return arr
 
-    def iter_spans(self, path: str, batch_lines: int = 8192, ramp: int = 0):
+    def query_ids(self, path: str) -> np.ndarray:
+        """query_id of every record of a TSV file, in file order (int64), without decoding a record: line split + the last field.  A rank of
+        an N-GPU job finds its contiguous query block of a shared file with it (``pipeline.tsv_shard``)."""
+        out = []
+        save, self.prefault = self.prefault, False                # heads and tails only: nothing worth mapping ahead, nothing to release
+        try:
+            for base, _g, starts, ends in self.iter_spans(path, 1 << 16):
+                q = np.empty(len(starts), np.int64)
+                rc = self.lib.mmf_query_ids(base, starts.ctypes.data, ends.ctypes.data, len(starts), q.ctypes.data)
+                if rc != 0:
+                    raise ValueError("mmf_query_ids failed (%d): %s" % (rc, self.lib.mmf_last_error().decode()))
+                out.append(q)
+        finally:
+            self.prefault = save
+        return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+    def iter_spans(self, path: str, batch_lines: int = 8192, ramp: int = 0, records=None):
         """Stream a TSV file as record spans: yields (base address, getbytes, starts, ends) per ``batch_lines`` records
         (blank lines and header lines containing 'product_id' skipped, kdd_data.py:70-71).  ``ramp`` > 0: the first batches hold
         ramp, 2 ramp, 4 ramp ... records until ``batch_lines`` is reached -- a consumer that overlaps decode, copy and scoring starts
-        after the decode of ``ramp`` records instead of a whole batch (pipeline.stream_scores_tsv).  The file is mmapped and the line
+        after the decode of ``ramp`` records instead of a whole batch (pipeline.stream_scores_tsv).  ``records = (lo, hi)``: only the records
+        lo <= index < hi of the file (header and blank lines not counted) are yielded -- a rank's shard; the ones in front are split, not decoded.  The file is mmapped and the line
         splitting is native; the spans stay valid until the generator is advanced.  ``self.stats`` accumulates the seconds spent
         mapping / unmapping, prefaulting and splitting (tools/feat_bench.py prints them)."""
         import mmap
@@ -187,9 +205,23 @@ class NativeFeaturizer:
                 starts, ends = np.empty(batch_lines, np.int64), np.empty(batch_lines, np.int64)
                 used = C.c_int64()
                 cur = min(batch_lines, ramp) if ramp > 0 else batch_lines
+                seen, (rec_lo, rec_hi) = 0, (records if records is not None else (0, 1 << 62))
+                skip_buf = None
                 mapped, per_rec = 0, 64 << 10                # bytes of the mapping whose pages are in, estimate of a record's size
                 prefault = self.prefault and hasattr(self.lib, "mmf_prefault")
-                while pos < size:
+                while pos < size and seen < rec_hi:
+                    if seen < rec_lo:                         # records of other ranks in front of this shard: find their ends, touch nothing else
+                        if skip_buf is None:
+                            skip_buf = (np.empty(1 << 16, np.int64), np.empty(1 << 16, np.int64))
+                        k = self.lib.mmf_split_lines(base + pos, size - pos, skip_buf[0].ctypes.data, skip_buf[1].ctypes.data,
+                                                     min(1 << 16, rec_lo - seen), C.byref(used))
+                        if k < 0:
+                            raise ValueError(self.lib.mmf_last_error().decode())
+                        seen += k
+                        pos += used.value
+                        mapped = max(mapped, pos)
+                        continue
+                    cur = min(cur, rec_hi - seen)
                     want = min(size, pos + int(cur * per_rec * 1.25) + (4 << 20))
                     t0 = clock()
                     if prefault and want > mapped:            # the next batch's pages, mapped by several threads instead of by the splitter's faults
@@ -203,6 +235,7 @@ class NativeFeaturizer:
                     st["split"] = st.get("split", 0.0) + t2 - t1
                     if n < 0:
                         raise ValueError(self.lib.mmf_last_error().decode())
+                    seen += max(n, 0)
                     if n:
                         yield base + pos, (lambda a, b, p0=pos: mm[p0 + a:p0 + b]), starts[:n].copy(), ends[:n].copy()
                         per_rec = max(per_rec // 2, used.value // n)
@@ -215,9 +248,9 @@ class NativeFeaturizer:
                 mm.close()
                 st["munmap"] = st.get("munmap", 0.0) + clock() - t0
 
-    def iter_file(self, path: str, batch_lines: int = 8192, sen2forest: bool = False, layout: bool = True, ramp: int = 0):
+    def iter_file(self, path: str, batch_lines: int = 8192, sen2forest: bool = False, layout: bool = True, ramp: int = 0, records=None):
         """Stream a TSV file: yields one batch dict per ``batch_lines`` records (see ``iter_spans``)."""
-        for base, getbytes, starts, ends in self.iter_spans(path, batch_lines, ramp):
+        for base, getbytes, starts, ends in self.iter_spans(path, batch_lines, ramp, records):
             a = self._run(base, getbytes, starts, ends, sen2forest)
             yield self._layout(a) if layout else a
 

@@ -74,8 +74,34 @@ def _cached_featurizer(vocab_path, label_table, model, threads):
     return _FEATURIZERS[key]
 
 
+def tsv_shard(nf, tsv_path, rank: int, world: int):
+    """A rank's share of a TSV file that all ranks of a node read (BASELINE.json config 4): contiguous QUERY blocks
+    (``sharding.query_block`` over the file's queries in file order -- valid.tsv / testB.tsv are grouped by query), found from the records'
+    last field alone (``NativeFeaturizer.query_ids``: line split, no decode).  -> ((first record, end record), records per rank): every rank
+    computes the same list, so the score gather needs no size exchange (``sharding.gather_scores(counts=...)``)."""
+    from . import sharding
+    qid = nf.query_ids(tsv_path)
+    if qid.size == 0:
+        return (0, 0), [0] * world
+    first = np.concatenate([[0], np.flatnonzero(qid[1:] != qid[:-1]) + 1, [qid.size]])       # record index at which each query group starts (+ the end)
+    n_groups = len(first) - 1
+    bounds = [sharding.query_block(n_groups, world, r) for r in range(world)]
+    counts = [int(first[hi] - first[lo]) for lo, hi in bounds]
+    lo, hi = bounds[rank]
+    return (int(first[lo]), int(first[hi])), counts
+
+
+def decode_threads_for(world: int) -> int:
+    """libmmfeat threads of ONE rank when ``world`` ranks share the host (one featurizer per rank, each decoding only its shard): an equal share of
+    the CPUs this process may use, at most the single-consumer default (64), at least 4.  16 threads decode 360-460 k records/s on the MI355X box's
+    host (profiles/rd6_feat_sweep.txt) -- 1.6-2 x what one GPU consumes."""
+    import os as _os
+    cpus = len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else (_os.cpu_count() or 8)
+    return int(max(4, min(64, cpus // 2 // max(world, 1))))
+
+
 def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: bool = False, batch_pairs: int = 32768, threads: int = 0,
-                      ramp: int = 1024):
+                      ramp: int = 1024, shard=None):
     """TSV file -> (query_id, product_id, score) with the three stages overlapped:
 
       producer thread   libmmfeat decodes batch i+2 into one of three pinned buffer sets (ctypes releases the GIL)
@@ -85,6 +111,10 @@ def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: boo
     ``ramp``: the first batches hold ramp, 2 ramp, 4 ramp ... records (0: every batch ``batch_pairs``): the GPU starts after ~4 ms of
     host work instead of the ~27 ms a 8192-record batch takes to decode and copy -- 4 % of a 150 000-record file, a fifth of testB.
     The featurizer (its helper threads and pinned buffer sets) is kept per (vocabulary, model, threads) between calls.
+
+    ``shard = (rank, world)``: this process scores only its contiguous query block of the file (``tsv_shard``) with ``decode_threads_for(world)``
+    decode threads unless ``threads`` says otherwise, and returns a 4th value, the records per rank -- pass it to ``sharding.gather_scores`` as
+    ``counts``.  Eight ranks on one host then decode 1/8 of the file each instead of all of it eight times.
     """
     import queue
     import threading
@@ -92,13 +122,16 @@ def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: boo
     import torch
 
     from .featurizer_native import NativeFeaturizer
+    if shard is not None and threads <= 0:
+        threads = decode_threads_for(shard[1])
     nf = _cached_featurizer(vocab_path, label_table, scorer.cfg.name, threads)
+    records, counts = (None, None) if shard is None else tsv_shard(nf, tsv_path, shard[0], shard[1])
     dev = scorer.device
     q = queue.Queue(maxsize=1)           # one decoded batch waiting + one being decoded + one being copied = 3 pools
 
     def produce():
         try:
-            for b in nf.iter_file(tsv_path, batch_pairs, sen2forest, ramp=ramp):
+            for b in nf.iter_file(tsv_path, batch_pairs, sen2forest, ramp=ramp, records=records):
                 q.put(b)
             q.put(None)
         except BaseException as e:       # surfaced in the consumer
@@ -128,6 +161,8 @@ def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: boo
     th.join()
     cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
     score = torch.cat(scores).float().cpu().numpy() if scores else np.zeros(0, np.float32)
+    if shard is not None:
+        return cat(qids, np.int64), cat(pids, np.int64), score, counts
     return cat(qids, np.int64), cat(pids, np.int64), score
 
 

@@ -78,12 +78,35 @@ def ensemble_main(rank, world):
     dist.destroy_process_group()
 
 
+def tsv_main(rank, world):
+    """BASELINE.json config 4 from the FILE: every rank reads the same TSV, finds its contiguous query block from the records' last field, decodes and
+    scores only that (pipeline.stream_scores_tsv(shard=...)), one all-gather with the counts every rank computed for itself -- against rank 0 scoring the
+    whole file alone.  (fuse_attention = 1 and launches of one size regime: bit for bit.)"""
+    from kddcup_2020_multimodalitiesrecall_2nd_place_amd import featurizer as F, pipeline
+    D = os.path.join(ROOT, "tests", "golden", "featurizer")
+    vocab, table = os.path.join(D, "vocab_small.txt"), F.load_label_table(os.path.join(D, "labels.txt"))
+    path = sys.argv[3]
+    cfg = ZkConfig(layers=2, vocab=4096, inter=1024)
+    s = scorers.ZkScorer(cfg, weights.make_weights(cfg), fuse_attention=1)
+    qid, pid, score, counts = pipeline.stream_scores_tsv(s, path, vocab, table, batch_pairs=64, ramp=16, shard=(rank, world))
+    all_s, all_q, all_p = sharding.gather_scores(torch.as_tensor(score), torch.as_tensor(qid), torch.as_tensor(pid), counts=counts)
+    if rank == 0:
+        q0, p0, s0 = pipeline.stream_scores_tsv(s, path, vocab, table, batch_pairs=64, ramp=16)
+        ok = bool(np.array_equal(all_q.numpy(), q0) and np.array_equal(all_p.numpy(), p0) and np.array_equal(all_s.numpy(), s0) and len(score) == counts[0]
+                  and sum(counts) == len(s0) and len(set(counts)) > 1)
+        json.dump({"ok": ok, "pairs": int(len(s0)), "counts": counts, "max_diff": float(np.abs(all_s.numpy() - s0).max())}, open(sys.argv[1], "w"))
+    s.close()
+    dist.destroy_process_group()
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if len(sys.argv) > 2 and sys.argv[2] == "ensemble":
         return ensemble_main(rank, world)
+    if len(sys.argv) > 2 and sys.argv[2] == "tsv":
+        return tsv_main(rank, world)
     cfg = ZkConfig(layers=2, vocab=4096, inter=1024)
     w = weights.make_weights(cfg)
     NQ = 12      # ~230 pairs: whole set and shards all run in ONE engine regime (< 8192 padded token rows: register-staged tiles, N = 768

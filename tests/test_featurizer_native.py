@@ -216,3 +216,37 @@ def test_ramp_batches_double_up_to_the_batch_size(tmp_path):
     for k in want:
         if k != "keep":
             assert np.array_equal(np.concatenate([b[k] for b in got]), want[k]), k
+
+
+def test_rank_shards_of_a_shared_file_partition_it_by_query(tmp_path):
+    """pipeline.tsv_shard + iter_file(records=...): every rank of an N-rank job decodes exactly its contiguous query block of the file, the blocks
+    partition the file, and the per-rank counts every rank computes are the same list (no size exchange before the score gather)."""
+    from kddcup_2020_multimodalitiesrecall_2nd_place_amd import pipeline
+    lines = _random_lines(83, 41)                      # query id = i // 7: 12 queries, the last one short
+    body = "product_id\timage_h\timage_w\tnum_boxes\tboxes\tfeatures\tclass_labels\tquery\tquery_id\n" + "\n\n".join(lines) + "\n"
+    p = tmp_path / "testB.tsv"
+    p.write_bytes(body.encode("utf-8"))
+    nf = N.NativeFeaturizer(VOCAB, TABLE, "zk", threads=2, reuse_buffers=True, pools=2)
+    whole = N.NativeFeaturizer(VOCAB, TABLE, "zk").batch(lines)
+    assert np.array_equal(nf.query_ids(str(p)), whole["query_id"])
+    for world in (1, 2, 3, 8, 16):
+        got_q, got_p, all_counts = [], [], None
+        for rank in range(world):
+            (lo, hi), counts = pipeline.tsv_shard(nf, str(p), rank, world)
+            all_counts = all_counts or counts
+            assert counts == all_counts and hi - lo == counts[rank]
+            batches = [{k: np.array(v) for k, v in b.items() if k != "keep"} for b in nf.iter_file(str(p), 16, ramp=4, records=(lo, hi))]
+            n = sum(len(b["query_id"]) for b in batches)
+            assert n == counts[rank]
+            if n:
+                q = np.concatenate([b["query_id"] for b in batches])
+                assert np.array_equal(q, whole["query_id"][lo:hi])
+                assert np.array_equal(np.concatenate([b["np_images_features"] for b in batches]), whole["np_images_features"][lo:hi])
+                got_q.append(q)
+                got_p.append(np.concatenate([b["product_id"] for b in batches]))
+        assert sum(all_counts) == len(lines)
+        assert np.array_equal(np.concatenate(got_q), whole["query_id"]) and np.array_equal(np.concatenate(got_p), whole["product_id"])
+        if world <= 8:                                  # a query's candidates stay on one rank
+            ends = np.cumsum(all_counts)[:-1]
+            assert all(whole["query_id"][e - 1] != whole["query_id"][e] for e in ends if 0 < e < len(lines))
+    assert pipeline.decode_threads_for(8) >= 4 and pipeline.decode_threads_for(1) <= 64

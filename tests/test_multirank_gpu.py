@@ -34,6 +34,27 @@ def test_sharded_hip_scoring_equals_single_rank_bitwise(world, tmp_path):
     assert res["ok"] is True and sum(res["counts"]) == res["pairs"]
 
 
+def test_ranks_decode_and_score_only_their_query_block_of_a_shared_tsv(tmp_path):
+    """File-fed N > 1 path: three ranks read ONE TSV file, each decodes (libmmfeat) and scores its contiguous query block only; the gathered
+    (query id, product id, score) triples equal rank 0's pass over the whole file."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_featurizer_native import _random_lines
+    lines = [l for l in _random_lines(150, 77) if int(l.split("\t")[3]) > 0 and all(ord(c) < 128 for c in l.split("\t")[7])]
+    path = tmp_path / "shared.tsv"
+    path.write_bytes(("product_id\tx\n" + "\n".join(lines) + "\n").encode("utf-8"))
+    out = tmp_path / "res_tsv.json"
+    port = _port()
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), str(out), "tsv", str(path)], env=env, cwd=ROOT))
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    res = json.load(open(out))
+    assert res["ok"] is True and res["pairs"] == len(lines) and len(res["counts"]) == 3, res
+
+
 def test_eight_ranks_fused_ensemble_gather_and_rank0_post_processing(tmp_path):
     """The N = 8 code path end to end on ONE device (no 8-GPU node is available to the builder; no RCCL run exists, DESIGN.md
     section 7): 8 processes, contiguous query blocks of fewer than 3 queries each, the fused three-model scorer per rank, one
