@@ -180,12 +180,52 @@ class NativeFeaturizer:
             self.prefault = save
         return np.concatenate(out) if out else np.zeros(0, np.int64)
 
-    def iter_spans(self, path: str, batch_lines: int = 8192, ramp: int = 0, records=None):
+    def byte_shard(self, path: str, rank: int, world: int):
+        """[b0, b1): rank's share of a TSV file that ``world`` ranks read, cut at QUERY boundaries near the byte offsets size * r / world -- O(1) work per rank
+        (a look at the ~30 records around each of its two cut points), no pass over the file, shards balanced by BYTES (= decode work).  The cut for offset p is
+        the start of the first record at or after p whose query id differs from the record in front of it; ranks r and r + 1 evaluate the same function for their
+        common cut, so the shards partition the file (valid.tsv / testB.tsv: records grouped by query)."""
+        import mmap
+        size = os.path.getsize(path)
+        if size == 0 or world <= 1:
+            return 0, size
+        with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+            view = np.frombuffer(mm, np.uint8)
+            try:
+                base = view.ctypes.data
+                starts, ends, used = np.empty(64, np.int64), np.empty(64, np.int64), C.c_int64()
+                q = np.empty(64, np.int64)
+
+                def cut(p):
+                    if p <= 0:
+                        return 0
+                    if p >= size:
+                        return size
+                    pos = mm.rfind(b"\n", 0, p) + 1               # start of the line that holds byte p - 1 ... (0 when there is none)
+                    prev_q = None
+                    while pos < size:
+                        n = self.lib.mmf_split_lines(base + pos, size - pos, starts.ctypes.data, ends.ctypes.data, 64, C.byref(used))
+                        if n < 0:
+                            raise ValueError(self.lib.mmf_last_error().decode())
+                        if n and self.lib.mmf_query_ids(base + pos, starts.ctypes.data, ends.ctypes.data, n, q.ctypes.data) != 0:
+                            raise ValueError(self.lib.mmf_last_error().decode())
+                        for i in range(n):
+                            if prev_q is not None and pos + starts[i] >= p and q[i] != prev_q:
+                                return int(pos + starts[i])
+                            prev_q = q[i]
+                        pos += used.value
+                    return size
+                return cut(size * rank // world), cut(size * (rank + 1) // world)
+            finally:
+                del view
+
+    def iter_spans(self, path: str, batch_lines: int = 8192, ramp: int = 0, records=None, byte_range=None):
         """Stream a TSV file as record spans: yields (base address, getbytes, starts, ends) per ``batch_lines`` records
         (blank lines and header lines containing 'product_id' skipped, kdd_data.py:70-71).  ``ramp`` > 0: the first batches hold
         ramp, 2 ramp, 4 ramp ... records until ``batch_lines`` is reached -- a consumer that overlaps decode, copy and scoring starts
         after the decode of ``ramp`` records instead of a whole batch (pipeline.stream_scores_tsv).  ``records = (lo, hi)``: only the records
-        lo <= index < hi of the file (header and blank lines not counted) are yielded -- a rank's shard; the ones in front are split, not decoded.  The file is mmapped and the line
+        lo <= index < hi of the file (header and blank lines not counted) are yielded -- a rank's shard; the ones in front are split, not decoded.
+        ``byte_range = (b0, b1)`` (``byte_shard``): only the records that start in [b0, b1), without touching the rest of the file.  The file is mmapped and the line
         splitting is native; the spans stay valid until the generator is advanced.  ``self.stats`` accumulates the seconds spent
         mapping / unmapping, prefaulting and splitting (tools/feat_bench.py prints them)."""
         import mmap
@@ -202,12 +242,14 @@ class NativeFeaturizer:
             st["mmap"] = st.get("mmap", 0.0) + clock() - t0
             try:
                 base, pos = view.ctypes.data, 0
+                if byte_range is not None:
+                    pos, size = int(byte_range[0]), min(size, int(byte_range[1]))
                 starts, ends = np.empty(batch_lines, np.int64), np.empty(batch_lines, np.int64)
                 used = C.c_int64()
                 cur = min(batch_lines, ramp) if ramp > 0 else batch_lines
                 seen, (rec_lo, rec_hi) = 0, (records if records is not None else (0, 1 << 62))
                 skip_buf = None
-                mapped, per_rec = 0, 64 << 10                # bytes of the mapping whose pages are in, estimate of a record's size
+                mapped, per_rec = pos, 64 << 10              # bytes of the mapping whose pages are in, estimate of a record's size
                 prefault = self.prefault and hasattr(self.lib, "mmf_prefault")
                 while pos < size and seen < rec_hi:
                     if seen < rec_lo:                         # records of other ranks in front of this shard: find their ends, touch nothing else
@@ -248,9 +290,9 @@ class NativeFeaturizer:
                 mm.close()
                 st["munmap"] = st.get("munmap", 0.0) + clock() - t0
 
-    def iter_file(self, path: str, batch_lines: int = 8192, sen2forest: bool = False, layout: bool = True, ramp: int = 0, records=None):
+    def iter_file(self, path: str, batch_lines: int = 8192, sen2forest: bool = False, layout: bool = True, ramp: int = 0, records=None, byte_range=None):
         """Stream a TSV file: yields one batch dict per ``batch_lines`` records (see ``iter_spans``)."""
-        for base, getbytes, starts, ends in self.iter_spans(path, batch_lines, ramp, records):
+        for base, getbytes, starts, ends in self.iter_spans(path, batch_lines, ramp, records, byte_range):
             a = self._run(base, getbytes, starts, ends, sen2forest)
             yield self._layout(a) if layout else a
 

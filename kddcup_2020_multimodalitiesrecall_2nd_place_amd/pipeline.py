@@ -101,7 +101,7 @@ def decode_threads_for(world: int) -> int:
 
 
 def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: bool = False, batch_pairs: int = 32768, threads: int = 0,
-                      ramp: int = 1024, shard=None):
+                      ramp: int = 1024, shard=None, shard_by: str = "bytes"):
     """TSV file -> (query_id, product_id, score) with the three stages overlapped:
 
       producer thread   libmmfeat decodes batch i+2 into one of three pinned buffer sets (ctypes releases the GIL)
@@ -112,9 +112,11 @@ def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: boo
     host work instead of the ~27 ms a 8192-record batch takes to decode and copy -- 4 % of a 150 000-record file, a fifth of testB.
     The featurizer (its helper threads and pinned buffer sets) is kept per (vocabulary, model, threads) between calls.
 
-    ``shard = (rank, world)``: this process scores only its contiguous query block of the file (``tsv_shard``) with ``decode_threads_for(world)``
-    decode threads unless ``threads`` says otherwise, and returns a 4th value, the records per rank -- pass it to ``sharding.gather_scores`` as
-    ``counts``.  Eight ranks on one host then decode 1/8 of the file each instead of all of it eight times.
+    ``shard = (rank, world)``: this process scores only its share of the file with ``decode_threads_for(world)`` decode threads unless ``threads``
+    says otherwise, and returns a 4th value ``counts`` for ``sharding.gather_scores``.  ``shard_by="bytes"`` (default): the file is cut at query
+    boundaries near size * r / world (``NativeFeaturizer.byte_shard``: O(1) per rank, shards balanced by decode work; ``counts`` is None -- the gather
+    exchanges the sizes).  ``shard_by="queries"``: equal numbers of queries per rank (``tsv_shard``: every rank indexes the whole file first -- an
+    index pass per rank that costs more than the decode from ~4 ranks on, profiles/rd6_feat_sweep.txt -- and gets the static ``counts`` list).
     """
     import queue
     import threading
@@ -125,13 +127,17 @@ def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: boo
     if shard is not None and threads <= 0:
         threads = decode_threads_for(shard[1])
     nf = _cached_featurizer(vocab_path, label_table, scorer.cfg.name, threads)
-    records, counts = (None, None) if shard is None else tsv_shard(nf, tsv_path, shard[0], shard[1])
+    records = counts = byte_range = None
+    if shard is not None and shard_by == "queries":
+        records, counts = tsv_shard(nf, tsv_path, shard[0], shard[1])
+    elif shard is not None:
+        byte_range = nf.byte_shard(tsv_path, shard[0], shard[1])
     dev = scorer.device
     q = queue.Queue(maxsize=1)           # one decoded batch waiting + one being decoded + one being copied = 3 pools
 
     def produce():
         try:
-            for b in nf.iter_file(tsv_path, batch_pairs, sen2forest, ramp=ramp, records=records):
+            for b in nf.iter_file(tsv_path, batch_pairs, sen2forest, ramp=ramp, records=records, byte_range=byte_range):
                 q.put(b)
             q.put(None)
         except BaseException as e:       # surfaced in the consumer

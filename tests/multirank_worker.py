@@ -88,13 +88,20 @@ def tsv_main(rank, world):
     path = sys.argv[3]
     cfg = ZkConfig(layers=2, vocab=4096, inter=1024)
     s = scorers.ZkScorer(cfg, weights.make_weights(cfg), fuse_attention=1)
-    qid, pid, score, counts = pipeline.stream_scores_tsv(s, path, vocab, table, batch_pairs=64, ramp=16, shard=(rank, world))
-    all_s, all_q, all_p = sharding.gather_scores(torch.as_tensor(score), torch.as_tensor(qid), torch.as_tensor(pid), counts=counts)
+    ok = True
+    for by in ("bytes", "queries"):
+        qid, pid, score, counts = pipeline.stream_scores_tsv(s, path, vocab, table, batch_pairs=64, ramp=16, shard=(rank, world), shard_by=by)
+        assert (counts is None) == (by == "bytes")
+        all_s, all_q, all_p = sharding.gather_scores(torch.as_tensor(score), torch.as_tensor(qid), torch.as_tensor(pid), counts=counts)
+        if rank == 0:
+            q0, p0, s0 = pipeline.stream_scores_tsv(s, path, vocab, table, batch_pairs=64, ramp=16)
+            ok = ok and bool(np.array_equal(all_q.numpy(), q0) and np.array_equal(all_p.numpy(), p0) and np.array_equal(all_s.numpy(), s0) and 0 < len(score) < len(s0))
+            if counts is not None:
+                ok = ok and len(score) == counts[0] and sum(counts) == len(s0) and len(set(counts)) > 1
+            else:
+                counts = [len(score)]
     if rank == 0:
-        q0, p0, s0 = pipeline.stream_scores_tsv(s, path, vocab, table, batch_pairs=64, ramp=16)
-        ok = bool(np.array_equal(all_q.numpy(), q0) and np.array_equal(all_p.numpy(), p0) and np.array_equal(all_s.numpy(), s0) and len(score) == counts[0]
-                  and sum(counts) == len(s0) and len(set(counts)) > 1)
-        json.dump({"ok": ok, "pairs": int(len(s0)), "counts": counts, "max_diff": float(np.abs(all_s.numpy() - s0).max())}, open(sys.argv[1], "w"))
+        json.dump({"ok": ok, "pairs": int(len(s0)), "counts": counts + [0] * (3 - len(counts)), "max_diff": float(np.abs(all_s.numpy() - s0).max())}, open(sys.argv[1], "w"))
     s.close()
     dist.destroy_process_group()
 

@@ -250,3 +250,17 @@ def test_rank_shards_of_a_shared_file_partition_it_by_query(tmp_path):
             ends = np.cumsum(all_counts)[:-1]
             assert all(whole["query_id"][e - 1] != whole["query_id"][e] for e in ends if 0 < e < len(lines))
     assert pipeline.decode_threads_for(8) >= 4 and pipeline.decode_threads_for(1) <= 64
+    # byte shards: cut at query boundaries near size * r / world, O(1) per rank; same partition property, no index pass
+    for world in (1, 2, 3, 5, 8, 40):
+        parts, cuts = [], []
+        for rank in range(world):
+            b0, b1 = nf.byte_shard(str(p), rank, world)
+            cuts.append((b0, b1))
+            got = [np.array(b["query_id"]) for b in nf.iter_file(str(p), 16, ramp=4, byte_range=(b0, b1))]
+            parts.append(np.concatenate(got) if got else np.zeros(0, np.int64))
+        assert cuts[0][0] == 0 and cuts[-1][1] == os.path.getsize(p) and all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        assert np.array_equal(np.concatenate(parts), whole["query_id"])
+        for a_, b_ in zip(parts[:-1], parts[1:]):       # no query on two ranks
+            assert not (len(a_) and len(b_)) or a_[-1] != b_[0]
+        nonempty = [x for x in parts if len(x)]
+        assert all(set(x.tolist()).isdisjoint(y.tolist()) for i, x in enumerate(nonempty) for y in nonempty[i + 1:])
