@@ -249,7 +249,7 @@ class EnsembleScorer:
 
         def produce():
             try:
-                for base, getbytes, starts, ends in nf_zk.iter_spans(tsv_path, batch_pairs):
+                for base, getbytes, starts, ends in nf_zk.iter_spans(tsv_path, batch_pairs, ramp=1024):      # (ramp: the first fused call starts after 1024 records)
                     a = nf_zk._run(base, getbytes, starts, ends, False)
                     item = (a["query_id"].copy(), a["product_id"].copy(), nf_zk._layout(a),
                             nf_s2f._layout(nf_s2f._run(base, getbytes, starts, ends, True)),
