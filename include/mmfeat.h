@@ -49,7 +49,8 @@ typedef struct mmf_batch_out {
     int64_t* query_id;          /* [B] */
     int32_t* num_boxes;         /* [B]  raw count (may exceed 10) */
     float* boxes;               /* [B,10,box_dim]  box_dim 5: 4 normalised corners + area (zk/lds); 4: corners (lxmert) */
-    float* feats;               /* [B,10,2048] */
+    float* feats;               /* [B,10,2048], or NULL: the 2048-d features are not decoded (their base64 length is still checked) -- a second pass over
+                                 * the same records that needs the query / label side only (pipeline.EnsembleScorer: the sen2forest and lxmert flavours) */
     int32_t* label_ids;         /* [B,10,8] */
     int32_t* label_len;         /* [B,10]  untruncated label-text length */
     int32_t* query_ids;         /* [B,text_len] zero padded / truncated */

@@ -360,6 +360,7 @@ bool featurize_one(const mmf_context* c, const char* data, const char* line, int
             bx[b * box_dim + 4] = prod / (float)(w * h);                                              // float32 throughout
         }
     }
+    if (o->feats) {      // (NULL: the caller takes the features from another pass over the same records -- the fused three-model feed decodes them once, not three times)
     float* ft = o->feats + i * (int64_t)N_BOX * FEAT_DIM;
     // box rows [nb, 10) must read zero (seq_padding).  A caller that reuses its buffers tells us how many leading box rows of this batch
     // row may be non-zero (feat_rows_live, in / out): the rest is zero already and is not written again -- at 3.8 boxes per record the
@@ -369,6 +370,7 @@ bool featurize_one(const mmf_context* c, const char* data, const char* line, int
     if (b64_decode(f[5].p, f[5].n, (unsigned char*)ft, nb * FEAT_DIM * 4) != nb * FEAT_DIM * 4) { msg = "bad base64 in features"; return false; }
     if (dirty > nb) std::memset(ft + nb * FEAT_DIM, 0, sizeof(float) * (dirty - nb) * FEAT_DIM);
     if (o->feat_rows_live) o->feat_rows_live[i] = (int32_t)nb;
+    }
 
     int64_t cls_ids[N_BOX];
     if (b64_decode(f[6].p, f[6].n, (unsigned char*)cls_ids, nb * 8) != nb * 8) { msg = "bad base64 in class labels"; return false; }
@@ -586,7 +588,7 @@ int mmf_featurize(const mmf_context* c, const char* data, const int64_t* offsets
 int mmf_featurize_spans(const mmf_context* c, const char* data, const int64_t* starts, const int64_t* ends, int64_t n, int32_t text_len,
                         int32_t box_dim, int32_t sen2forest, int32_t threads, const mmf_batch_out* out) {
     if (!c || !data || !starts || !ends || !out || n < 0 || text_len <= 0 || (box_dim != 4 && box_dim != 5)) { g_err = "mmf_featurize: bad argument"; return -1; }
-    if (!out->product_id || !out->query_id || !out->num_boxes || !out->boxes || !out->feats || !out->label_ids || !out->label_len ||
+    if (!out->product_id || !out->query_id || !out->num_boxes || !out->boxes || !out->label_ids || !out->label_len ||
         !out->query_ids || !out->query_len || !out->needs_host_tokenizer || !out->query_span) { g_err = "mmf_featurize: null output buffer"; return -1; }
     if (n == 0) return 0;
     int nt = threads > 0 ? threads : default_threads();

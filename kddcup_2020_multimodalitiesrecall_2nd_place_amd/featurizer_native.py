@@ -72,11 +72,13 @@ class NativeFeaturizer:
     """model: 'zk' | 'lds' | 'lxmert' (box_dim, text_len, tokenizer flavour follow the sub-project)."""
 
     def __init__(self, vocab_path: str, label_table: dict, model: str = "zk", threads: int = 0, pinned: bool = False,
-                 reuse_buffers: bool = False, pools: int = 1):
+                 reuse_buffers: bool = False, pools: int = 1, want_feats: bool = True):
         """reuse_buffers: keep ``pools`` (pinned) sets of output buffers, grown on demand and used round-robin -- the
         returned arrays are then views that the ``pools``-th following call overwrites (streaming use: featurize ->
         H2D copy -> featurize ...).  Page-faulting fresh 336 KB/row buffers costs more than the decode itself, so the
-        streaming drivers turn this on."""
+        streaming drivers turn this on.  want_feats=False: the 2048-d box features are neither decoded nor allocated (the batch dicts
+        carry None for them) -- for a second pass over records whose features another featurizer already produced."""
+        self.want_feats = want_feats
         self.lib = load()
         self.reuse, self._caps, self._pools, self._turn = reuse_buffers, [0] * pools, [None] * pools, 0
         self.model = model
@@ -107,7 +109,7 @@ class NativeFeaturizer:
     def _spec(self, n):
         T = self.text_len
         return dict(product_id=((n,), np.int64), query_id=((n,), np.int64), num_boxes=((n,), np.int32),
-                    boxes=((n, N_BOX, self.box_dim), np.float32), feats=((n, N_BOX, FEAT_DIM), np.float32),
+                    boxes=((n, N_BOX, self.box_dim), np.float32), feats=((n if self.want_feats else 0, N_BOX, FEAT_DIM), np.float32),
                     label_ids=((n, N_BOX, LABEL_LEN), np.int32), label_len=((n, N_BOX), np.int32),
                     query_ids=((n, T), np.int32), query_len=((n,), np.int32), needs_host_tokenizer=((n,), np.uint8),
                     query_span=((n, 2), np.int64))
@@ -125,7 +127,7 @@ class NativeFeaturizer:
             # the count per row, and only the part of the zero padding that a previous record wrote over is written again
             live = np.full(self._caps[t], N_BOX, np.int32)
             self._pools[t]["feat_rows_live"] = (live, live)
-        return {k: v[0][:n] for k, v in self._pools[t].items()}, {k: v[1] for k, v in self._pools[t].items()}
+        return {k: (v[0][:n] if (k != "feats" or self.want_feats) else v[0]) for k, v in self._pools[t].items()}, {k: v[1] for k, v in self._pools[t].items()}
 
     def featurize(self, lines, sen2forest: bool = False) -> dict:
         """lines: iterable of TSV records (str or bytes).  Returns the raw padded arrays (+ ``keep`` = pinned owners)."""
@@ -146,8 +148,9 @@ class NativeFeaturizer:
         n, T = len(starts), self.text_len
         arr, keep = self._buffers(n)
         live = arr.pop("feat_rows_live", None)                    # reused buffer sets only
-        out = BatchOut(*([arr[k].ctypes.data for k in ("product_id", "query_id", "num_boxes", "boxes", "feats", "label_ids",
-                                                       "label_len", "query_ids", "query_len", "needs_host_tokenizer", "query_span")]
+        out = BatchOut(*([(arr[k].ctypes.data if (k != "feats" or self.want_feats) else None)
+                          for k in ("product_id", "query_id", "num_boxes", "boxes", "feats", "label_ids",
+                                    "label_len", "query_ids", "query_len", "needs_host_tokenizer", "query_span")]
                          + [live.ctypes.data if live is not None and n else None]))
         if n:
             import time
@@ -166,6 +169,8 @@ class NativeFeaturizer:
             arr["query_ids"][i] = 0
             arr["query_ids"][i, :min(T, len(ids))] = ids[:T]
         arr["keep"] = keep
+        if not self.want_feats:
+            arr["feats"] = None
         return arr
 
     def query_ids(self, path: str) -> np.ndarray:

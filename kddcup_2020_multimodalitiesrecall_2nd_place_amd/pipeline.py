@@ -243,8 +243,8 @@ class EnsembleScorer:
         import threading
 
         from .featurizer_native import NativeFeaturizer
-        mk = lambda m: NativeFeaturizer(vocab_path, label_table, m, threads=threads, pinned=True, reuse_buffers=True, pools=3)
-        nf_zk, nf_s2f, nf_lx = mk("zk"), mk("zk"), mk("lxmert")
+        mk = lambda m, feats=True: NativeFeaturizer(vocab_path, label_table, m, threads=threads, pinned=True, reuse_buffers=True, pools=3, want_feats=feats)
+        nf_zk, nf_s2f, nf_lx = mk("zk"), mk("zk", False), mk("lxmert", False)      # the fused feed reads the 2048-d features from the first pass only
         q = queue.Queue(maxsize=1)          # one decoded batch waiting + one being decoded + one being scored = 3 buffer sets
 
         def produce():

@@ -297,3 +297,22 @@ def test_pread_reader_yields_the_batches_of_the_mapped_reader(tmp_path, model):
     assert list(b.iter_file(str(tmp_path / "empty.tsv"))) == []
     (tmp_path / "hdr.tsv").write_bytes(b"product_id\tx\n\n")
     assert list(b.iter_file(str(tmp_path / "hdr.tsv"))) == []
+
+
+def test_second_pass_without_features_matches_the_full_pass_elsewhere():
+    """want_feats=False (mmf_batch_out.feats == NULL): everything but the 2048-d features, which stay undecoded -- the fused three-model feed's second and third pass."""
+    lines = _random_lines(40, 17)
+    for model in ("zk", "lxmert"):
+        full = N.NativeFeaturizer(VOCAB, TABLE, model, threads=2).batch(lines, sen2forest=True)
+        lite = N.NativeFeaturizer(VOCAB, TABLE, model, threads=2, reuse_buffers=True, pools=2, want_feats=False)
+        for _ in range(3):
+            got = lite.batch(lines, sen2forest=True)
+            fk = "np_images_features" if model == "zk" else "feats"
+            assert got[fk] is None
+            for k in full:
+                if k not in (fk, "keep"):
+                    assert np.array_equal(got[k], full[k]), k
+    f = lines[3].split("\t")
+    f[3] = str(int(f[3]) + 1)
+    with pytest.raises(ValueError, match="num_boxes"):             # the payload lengths are still checked
+        N.NativeFeaturizer(VOCAB, TABLE, "zk", want_feats=False).batch(["\t".join(f)])
