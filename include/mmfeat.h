@@ -83,12 +83,6 @@ int64_t mmf_split_lines(const char* data, int64_t len, int64_t* starts, int64_t*
  * -1000 - index of the first record whose last field is not an integer. */
 int mmf_query_ids(const char* data, const int64_t* starts, const int64_t* ends, int64_t n, int64_t* out);
 
-/* pread [offset, offset + len) of `fd` into dst on up to 32 of the context's threads (1 MB pieces).  Returns the bytes read (short at the end of
- * the file; the bytes read form a prefix when the file ends inside the range), or -1.  The mapping-free way to stream a file: the reader copies a
- * batch's bytes into a buffer it reuses, so no page-table work (prefault, release, unmap) is left -- what N processes on one host otherwise
- * contend on (profiles/rd6_feat_sweep.txt). */
-int64_t mmf_read_file(const mmf_context* c, int32_t fd, int64_t offset, void* dst, int64_t len, int32_t threads);
-
 /* Map the pages of [addr, addr + len) -- a read-only file mapping about to be split and decoded -- on `threads` threads
  * (MADV_POPULATE_READ per 2 MB piece).  A 50 KB record is ~12 pages; left to demand faulting, the ONE thread that splits
  * lines takes the faults of the whole file (fault-around maps the rest of each record with its head), which bounded the

@@ -513,34 +513,6 @@ int mmf_query_ids(const char* data, const int64_t* starts, const int64_t* ends, 
     return 0;
 }
 
-int64_t mmf_read_file(const mmf_context* c, int32_t fd, int64_t offset, void* dst, int64_t len, int32_t threads) {
-    if (!c || fd < 0 || offset < 0 || !dst || len < 0) { g_err = "mmf_read_file: bad argument"; return -1; }
-    if (len == 0) return 0;
-    const int64_t piece = 1 << 20, pieces = (len + piece - 1) / piece;
-    int nt = threads > 0 ? threads : default_threads();
-    if (nt > 32) nt = 32;
-    if ((int64_t)nt > pieces) nt = (int)pieces;
-    std::atomic<int64_t> next(0), got(0);
-    std::atomic<bool> failed(false);
-    c->pool.run(nt, [&](int) {
-        for (;;) {
-            const int64_t k = next.fetch_add(1);
-            if (k >= pieces) break;
-            int64_t o = k * piece;
-            const int64_t end = o + piece < len ? o + piece : len;
-            while (o < end) {
-                const ssize_t r = pread(fd, (char*)dst + o, (size_t)(end - o), (off_t)(offset + o));
-                if (r < 0) { failed.store(true); return; }
-                if (r == 0) break;                                 // end of file inside this piece
-                o += r;
-                got.fetch_add(r);
-            }
-        }
-    });
-    if (failed.load()) { g_err = "mmf_read_file: pread failed"; return -1; }
-    return got.load();
-}
-
 int mmf_prefault(const mmf_context* c, const void* addr, int64_t len, int32_t threads) {
     if (!c || !addr || len < 0) { g_err = "mmf_prefault: bad argument"; return -1; }
     if (len == 0) return 0;

@@ -17,7 +17,7 @@ from .config import FEAT_DIM, LABEL_LEN, N_BOX
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmmfeat.so")
 EXPORTS = ("mmf_create", "mmf_destroy", "mmf_last_error", "mmf_set_label", "mmf_tokenize_ascii", "mmf_featurize",
-           "mmf_featurize_spans", "mmf_split_lines", "mmf_b64_tier", "mmf_prefault", "mmf_release_later", "mmf_query_ids", "mmf_read_file")
+           "mmf_featurize_spans", "mmf_split_lines", "mmf_b64_tier", "mmf_prefault", "mmf_release_later", "mmf_query_ids")
 
 
 class BatchOut(C.Structure):
@@ -53,8 +53,6 @@ def load(path=None):
             l.mmf_prefault.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
             l.mmf_release_later.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
             l.mmf_query_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
-            l.mmf_read_file.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_int32]
-            l.mmf_read_file.restype = C.c_int64
         _lib = l
     return _lib
 
@@ -89,8 +87,6 @@ class NativeFeaturizer:
                                            never_split=F.SPECIALS if hf else ())
         self.threads, self.pinned = threads, pinned
         self.stats = {}                                   # seconds per stage, accumulated by iter_spans / _run
-        self.reader = "mmap"                              # "mmap": map the file, prefault / release batch by batch; "pread": copy each batch's bytes into a reused buffer (iter_spans)
-        self._rbuf = None
         self.prefault = True                              # iter_spans maps a batch's pages in parallel before splitting it (mmf_prefault)
         self._h = C.c_void_p()
         if self.lib.mmf_create(vocab_path.encode(), 100 if hf else 200, int(hf), C.byref(self._h)) != 0:
@@ -239,9 +235,6 @@ class NativeFeaturizer:
         mapping / unmapping, prefaulting and splitting (tools/feat_bench.py prints them)."""
         import mmap
         import time
-        if self.reader == "pread" and hasattr(self.lib, "mmf_read_file"):
-            yield from self._iter_spans_pread(path, batch_lines, ramp, records, byte_range)
-            return
         st = self.stats
         clock = time.perf_counter
         with open(path, "rb") as f:
@@ -301,86 +294,6 @@ class NativeFeaturizer:
                 del view                                     # release the exported buffer before the mmap closes
                 mm.close()
                 st["munmap"] = st.get("munmap", 0.0) + clock() - t0
-
-    def _iter_spans_pread(self, path, batch_lines, ramp, records, byte_range):
-        """``iter_spans`` without a mapping: a batch's bytes are copied (parallel pread, ``mmf_read_file``) into ONE buffer that is reused -- the bytes behind a
-        batch's last record move to the front, the next read appends.  Same batches, same order."""
-        import time
-        st, clock = self.stats, time.perf_counter
-        fd = os.open(path, os.O_RDONLY)
-        try:
-            size = os.fstat(fd).st_size
-            foff, fend = (0, size) if byte_range is None else (int(byte_range[0]), min(size, int(byte_range[1])))
-            rec_lo, rec_hi = records if records is not None else (0, 1 << 62)
-            cap = max(batch_lines, 1 << 16 if rec_lo > 0 else 0)
-            starts, ends, used = np.empty(cap, np.int64), np.empty(cap, np.int64), C.c_int64()
-            cur = min(batch_lines, ramp) if ramp > 0 else batch_lines
-            per_rec, seen, fill = 64 << 10, 0, 0
-
-            def read_more(nbytes):
-                nonlocal fill, foff, fend
-                if self._rbuf is None or len(self._rbuf) < fill + nbytes:
-                    nb = np.empty(max(fill + nbytes, 0 if self._rbuf is None else len(self._rbuf) * 3 // 2), np.uint8)
-                    if fill:
-                        nb[:fill] = self._rbuf[:fill]
-                    self._rbuf = nb
-                t0 = clock()
-                got = self.lib.mmf_read_file(self._h, fd, foff, self._rbuf.ctypes.data + fill, nbytes, self.threads)
-                st["read"] = st.get("read", 0.0) + clock() - t0
-                if got < 0:
-                    raise ValueError(self.lib.mmf_last_error().decode())
-                if got < nbytes:
-                    fend = foff + got                          # the file ended before the range did
-                fill += got
-                foff += got
-
-            def complete_bytes(eof):
-                """bytes of the buffer that are whole lines (everything once the shard's last byte is in)"""
-                if eof or fill == 0:
-                    return fill
-                for back in (256 << 10, 8 << 20, fill):
-                    a = max(0, fill - back)
-                    nl = np.flatnonzero(self._rbuf[a:fill] == 10)
-                    if nl.size:
-                        return a + int(nl[-1]) + 1
-                    if a == 0:
-                        break
-                return 0
-
-            while seen < rec_hi:
-                skipping = seen < rec_lo
-                want = min(cap, rec_lo - seen) if skipping else min(cur, rec_hi - seen)
-                while True:                                    # until the buffer holds `want` complete records, or the shard's end
-                    est = int(want * per_rec * 1.05) + (1 << 20)
-                    if foff < fend and fill < est:
-                        read_more(min(est - fill, fend - foff))
-                    eof = foff >= fend
-                    limit = complete_bytes(eof)
-                    n = 0
-                    if limit:
-                        t0 = clock()
-                        n = self.lib.mmf_split_lines(self._rbuf.ctypes.data, limit, starts.ctypes.data, ends.ctypes.data, want, C.byref(used))
-                        st["split"] = st.get("split", 0.0) + clock() - t0
-                        if n < 0:
-                            raise ValueError(self.lib.mmf_last_error().decode())
-                    if n >= want or eof:
-                        break
-                    per_rec = per_rec * 3 // 2 + 1             # the estimate was short: read more and split again
-                consumed = used.value if limit else 0
-                if n and not skipping:
-                    buf = self._rbuf
-                    yield buf.ctypes.data, (lambda a, b, bb=buf: bytes(bb[a:b])), starts[:n].copy(), ends[:n].copy()
-                    per_rec = max(per_rec // 2, consumed // n)
-                    cur = min(batch_lines, 2 * cur)
-                seen += n
-                left = fill - consumed
-                if left and consumed:
-                    self._rbuf[:left] = self._rbuf[consumed:fill] if consumed >= left else self._rbuf[consumed:fill].copy()
-                fill = left
-                if eof and (n == 0 or fill == 0):
-                    break
-        finally:
-            os.close(fd)
 
     def iter_file(self, path: str, batch_lines: int = 8192, sen2forest: bool = False, layout: bool = True, ramp: int = 0, records=None, byte_range=None):
         """Stream a TSV file: yields one batch dict per ``batch_lines`` records (see ``iter_spans``)."""

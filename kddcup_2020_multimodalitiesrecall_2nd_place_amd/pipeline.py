@@ -261,7 +261,10 @@ class EnsembleScorer:
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
-        qids, pids, merged, parts = [], [], [], [[], [], [], []]
+        import torch
+        dev = self.zk.device
+        copy_stream = torch.cuda.Stream(dev)
+        qids, pids, merged, members = [], [], [], []
         while True:
             item = q.get()
             if item is None:
@@ -271,10 +274,20 @@ class EnsembleScorer:
             qi, pi, zf, sf, lf = item
             qids.append(qi)
             pids.append(pi)
-            m, p4 = self._score(zf, sf, lf)     # H2D from the pinned set + fused call; returns after the device is done with it
+            # as in stream_scores_tsv: H2D of batch i + 1 on a copy stream while the fused call of batch i runs; nothing waits for the kernels until the end
+            with torch.cuda.stream(copy_stream):
+                prep = self.fused.prepare(ensemble_feed(zf, sf, lf))
+            copy_stream.synchronize()           # the pinned sets of this batch may be refilled from here on
+            m, mem = self.fused.score_prepared(prep)
+            for t in prep[2].values():          # allocated on the copy stream, consumed on the main one
+                if torch.is_tensor(t):
+                    t.record_stream(torch.cuda.current_stream(dev))
             merged.append(m)
-            for k in range(4):
-                parts[k].append(p4[k])
+            members.append(mem)
         th.join()
         cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
-        return cat(qids, np.int64), cat(pids, np.int64), cat(merged, np.float64), tuple(cat(x, np.float32) for x in parts)
+        if not merged:
+            return cat(qids, np.int64), cat(pids, np.int64), np.zeros(0, np.float64), tuple(np.zeros(0, np.float32) for _ in range(4))
+        mem_all = torch.cat(members, 1).cpu().numpy()
+        merged_all = torch.cat(merged).double().cpu().numpy()
+        return cat(qids, np.int64), cat(pids, np.int64), merged_all, tuple(mem_all[k] for k in range(4))

@@ -266,39 +266,6 @@ def test_rank_shards_of_a_shared_file_partition_it_by_query(tmp_path):
         assert all(set(x.tolist()).isdisjoint(y.tolist()) for i, x in enumerate(nonempty) for y in nonempty[i + 1:])
 
 
-@pytest.mark.parametrize("model", ["zk", "lxmert"])
-def test_pread_reader_yields_the_batches_of_the_mapped_reader(tmp_path, model):
-    """NativeFeaturizer.reader = "pread" (a batch's bytes copied into one reused buffer, no mapping): same batches, same arrays, for whole files, record
-    ranges and byte shards, ramped or not, with header / blank lines and a last record without a newline."""
-    lines = _random_lines(61, 9)
-    body = "product_id\timage_h\timage_w\tnum_boxes\tboxes\tfeatures\tclass_labels\tquery\tquery_id\n"
-    for i, l in enumerate(lines):
-        body += l + ("\r\n" if i % 5 == 0 else "\n") + ("\n   \n" if i % 11 == 0 else "")
-    p = tmp_path / "valid.tsv"
-    p.write_bytes(body.rstrip("\n").encode("utf-8"))
-    a = N.NativeFeaturizer(VOCAB, TABLE, model, threads=2, reuse_buffers=True)
-    b = N.NativeFeaturizer(VOCAB, TABLE, model, threads=3, reuse_buffers=True)
-    b.reader = "pread"
-
-    def run(nf, **kw):
-        return [{k: np.array(v) for k, v in x.items() if k != "keep"} for x in nf.iter_file(str(p), **kw)]
-    cases = [dict(batch_lines=7), dict(batch_lines=1000), dict(batch_lines=16, ramp=3), dict(batch_lines=9, records=(13, 40)), dict(batch_lines=64, records=(60, 61)),
-             dict(batch_lines=8, records=(0, 0))]
-    for world in (2, 5):
-        cases += [dict(batch_lines=6, ramp=2, byte_range=a.byte_shard(str(p), r, world)) for r in range(world)]
-    for kw in cases:
-        x, y = run(a, **kw), run(b, **kw)
-        assert [len(t["query_id"]) for t in x] == [len(t["query_id"]) for t in y], kw
-        for t, u in zip(x, y):
-            for k in t:
-                assert np.array_equal(t[k], u[k]), (kw, k)
-    assert b.stats.get("read", 0) > 0 and "read" not in a.stats
-    (tmp_path / "empty.tsv").write_bytes(b"")
-    assert list(b.iter_file(str(tmp_path / "empty.tsv"))) == []
-    (tmp_path / "hdr.tsv").write_bytes(b"product_id\tx\n\n")
-    assert list(b.iter_file(str(tmp_path / "hdr.tsv"))) == []
-
-
 def test_second_pass_without_features_matches_the_full_pass_elsewhere():
     """want_feats=False (mmf_batch_out.feats == NULL): everything but the 2048-d features, which stay undecoded -- the fused three-model feed's second and third pass."""
     lines = _random_lines(40, 17)

@@ -45,7 +45,6 @@ def main():
     ap.add_argument("--ranks", type=int, default=0, help="N processes, each decoding ITS query block of the one file with pipeline.decode_threads_for(N) threads (the host side of an N-GPU job)")
     ap.add_argument("--rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--shard-by", default="bytes", choices=["bytes", "queries"])
-    ap.add_argument("--reader", default="mmap", choices=["mmap", "pread"])
     ap.add_argument("--rank-threads", type=int, default=0, help="decode threads per rank (default: pipeline.decode_threads_for(ranks))")
     a = ap.parse_args()
     path = "/tmp/featbench_%d.tsv" % a.records
@@ -57,22 +56,21 @@ def main():
     if a.ranks and a.rank < 0:                      # parent: start the ranks together, wait, report the aggregate
         import subprocess
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--records", str(a.records), "--ranks", str(a.ranks), "--rank", str(r),
-                                   "--batch", str(a.batch), "--reps", str(a.reps), "--shard-by", a.shard_by, "--rank-threads", str(a.rank_threads), "--reader", a.reader] + (["--pinned"] if a.pinned else []) + (["--no-prefault"] if a.no_prefault else []),
+                                   "--batch", str(a.batch), "--reps", str(a.reps), "--shard-by", a.shard_by, "--rank-threads", str(a.rank_threads)] + (["--pinned"] if a.pinned else []) + (["--no-prefault"] if a.no_prefault else []),
                                   stdout=subprocess.PIPE, text=True)
                  for r in range(a.ranks)]
         outs = [p_.communicate()[0] for p_ in procs]
         rows = [l.split() for o in outs for l in o.splitlines() if l.startswith("RANK")]
         t0, t1 = min(float(r[2]) for r in rows), max(float(r[3]) for r in rows)
         n = sum(int(r[4]) for r in rows)
-        print("%d ranks x %s threads, one %d-record file, each rank its share (cut by %s, %s)%s%s: %d records in %.3f s wall = %.0f records/s aggregate (per rank %s)" % (
-            a.ranks, rows[0][5], a.records, a.shard_by, a.reader, " (pinned)" if a.pinned else "", " no-prefault" if a.no_prefault else "", n, t1 - t0, n / (t1 - t0), " ".join("%.0fk" % (int(r[4]) / (float(r[3]) - float(r[2])) / 1e3) for r in rows)))
+        print("%d ranks x %s threads, one %d-record file, each rank its share (cut by %s)%s%s: %d records in %.3f s wall = %.0f records/s aggregate (per rank %s)" % (
+            a.ranks, rows[0][5], a.records, a.shard_by, " (pinned)" if a.pinned else "", " no-prefault" if a.no_prefault else "", n, t1 - t0, n / (t1 - t0), " ".join("%.0fk" % (int(r[4]) / (float(r[3]) - float(r[2])) / 1e3) for r in rows)))
         return
     if a.ranks:
         from kddcup_2020_multimodalitiesrecall_2nd_place_amd import pipeline
         th = a.rank_threads or pipeline.decode_threads_for(a.ranks)
         nf = N.NativeFeaturizer(VOCAB, TABLE, "zk", threads=th, pinned=a.pinned, reuse_buffers=True, pools=3)
         nf.prefault = not a.no_prefault
-        nf.reader = a.reader
 
         def shard():
             if a.shard_by == "queries":
@@ -99,7 +97,6 @@ def main():
         for th in [int(t) for t in a.threads.split(",")]:
             nf = N.NativeFeaturizer(VOCAB, TABLE, "zk", threads=th, pinned=a.pinned, reuse_buffers=True, pools=3)
             nf.prefault = not a.no_prefault
-            nf.reader = a.reader
             nf.stats = {}
             best, parts = 0.0, {}
             for _ in range(a.reps):
@@ -109,8 +106,8 @@ def main():
                 dt = time.time() - t0
                 if k / dt > best:
                     best, parts = k / dt, dict(nf.stats, total=dt)
-            print("%s tier %s threads %3d batch %d %s%s%s: %8.0f records/s  %.2f GB/s of TSV   [ms: %s]" % (
-                libname, "-" if tier is None else tier, th or os.cpu_count(), a.batch, a.reader, " pinned" if a.pinned else "",
+            print("%s tier %s threads %3d batch %d%s%s: %8.0f records/s  %.2f GB/s of TSV   [ms: %s]" % (
+                libname, "-" if tier is None else tier, th or os.cpu_count(), a.batch, " pinned" if a.pinned else "",
                 " no-prefault" if a.no_prefault else "", best, best / a.records * gb,
                 ", ".join("%s %.0f" % (k_, v * 1e3) for k_, v in parts.items())), flush=True)
             nf.close()
