@@ -541,7 +541,12 @@ int mmf_prefault(const mmf_context* c, const void* addr, int64_t len, int32_t th
 }
 
 int mmf_release_later(const mmf_context* c, const void* addr, int64_t len) {
-    if (!c || !addr || len < 0) { g_err = "mmf_release_later: bad argument"; return -1; }
+    if (c && !addr) {      // forget every pending range: the mapping they point into is about to go away
+        std::lock_guard<std::mutex> g(c->release_m);
+        c->release_q.clear();
+        return 0;
+    }
+    if (!c || len < 0) { g_err = "mmf_release_later: bad argument"; return -1; }
     const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
     const uintptr_t lo = ((uintptr_t)addr + page - 1) & ~(page - 1), hi = ((uintptr_t)addr + (uintptr_t)len) & ~(page - 1);   // whole pages inside
     if (hi > lo) {

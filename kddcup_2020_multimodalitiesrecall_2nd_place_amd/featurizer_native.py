@@ -291,6 +291,8 @@ class NativeFeaturizer:
                     pos += used.value
             finally:
                 t0 = clock()
+                if hasattr(self.lib, "mmf_release_later"):
+                    self.lib.mmf_release_later(self._h, None, 0)      # pending ranges point into this mapping: forget them before it goes away
                 del view                                     # release the exported buffer before the mmap closes
                 mm.close()
                 st["munmap"] = st.get("munmap", 0.0) + clock() - t0

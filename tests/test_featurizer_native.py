@@ -283,3 +283,31 @@ def test_second_pass_without_features_matches_the_full_pass_elsewhere():
     f[3] = str(int(f[3]) + 1)
     with pytest.raises(ValueError, match="num_boxes"):             # the payload lengths are still checked
         N.NativeFeaturizer(VOCAB, TABLE, "zk", want_feats=False).batch(["\t".join(f)])
+
+
+def test_repeated_passes_with_one_featurizer_leave_no_stale_release_ranges(tmp_path):
+    """Regression (round 6): the consumed-batch ranges queued by mmf_release_later pointed into the file mapping of the PREVIOUS pass when the same featurizer
+    streamed a second file; the next decode dropped (MADV_DONTNEED = zeroed) whatever had been mapped there since -- heap pages: glibc aborted at exit.  iter_spans
+    now forgets pending ranges before it unmaps.  Run in a child process: several passes with allocations in between, results equal, clean exit."""
+    import subprocess
+    import sys
+    lines = _random_lines(400, 55)
+    p = tmp_path / "big.tsv"
+    p.write_bytes(("\n".join(lines) + "\n").encode("utf-8"))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_featurizer_native import N, VOCAB, TABLE
+nf = N.NativeFeaturizer(VOCAB, TABLE, "zk", threads=4, reuse_buffers=True, pools=3)
+ref, junk = None, []
+for rep in range(5):
+    got = np.concatenate([np.array(b["np_images_features"]).sum(axis=(1, 2)) for b in nf.iter_file(%r, 64, ramp=16)])
+    junk.append(np.ones((1 << 22) + rep, np.uint8))            # fresh mappings where the old file mapping was
+    assert ref is None or np.array_equal(got, ref)
+    ref = got
+    assert all(int(j.min()) == 1 for j in junk)                # nobody zeroed them
+nf.close()
+print("PASSES_OK", len(ref))
+''' % (ROOT, os.path.join(ROOT, "tests"), str(p))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "PASSES_OK 400" in out.stdout, (out.returncode, out.stderr[-2000:])
