@@ -93,7 +93,7 @@ int mmf_prefault(const mmf_context* c, const void* addr, int64_t len, int32_t th
  * this context drops those pages from the page table (madvise MADV_DONTNEED, whole pages inside the range) on one of its threads
  * while the others decode.  Unmapping a 2.5 GB file at the end instead is 30 ms of serial kernel work -- a third of the pass
  * (profiles/rd6_feat_sweep.txt).  The data stays in the page cache; touching the range again simply faults it back in.
- * addr == NULL: forget every pending range -- REQUIRED before the mapping is unmapped (a range left pending would be dropped from
+ * addr == NULL: forget every pending range (returns how many there were) -- REQUIRED before the mapping is unmapped (a range left pending would be dropped from
  * whatever is mapped at that address when the next decode runs: MADV_DONTNEED zeroes anonymous memory). */
 int mmf_release_later(const mmf_context* c, const void* addr, int64_t len);
 

@@ -543,8 +543,9 @@ int mmf_prefault(const mmf_context* c, const void* addr, int64_t len, int32_t th
 int mmf_release_later(const mmf_context* c, const void* addr, int64_t len) {
     if (c && !addr) {      // forget every pending range: the mapping they point into is about to go away
         std::lock_guard<std::mutex> g(c->release_m);
+        const int dropped = (int)c->release_q.size();
         c->release_q.clear();
-        return 0;
+        return dropped;          // (how many ranges were pending)
     }
     if (!c || len < 0) { g_err = "mmf_release_later: bad argument"; return -1; }
     const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);

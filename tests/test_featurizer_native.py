@@ -311,3 +311,15 @@ print("PASSES_OK", len(ref))
 ''' % (ROOT, os.path.join(ROOT, "tests"), str(p))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "PASSES_OK 400" in out.stdout, (out.returncode, out.stderr[-2000:])
+    # the deterministic half: nothing is pending once a pass has ended -- completed, or abandoned half way
+    nf = N.NativeFeaturizer(VOCAB, TABLE, "zk", threads=2, reuse_buffers=True, pools=2)
+    assert sum(len(b["query_id"]) for b in nf.iter_file(str(p), 64)) == 400
+    assert nf.lib.mmf_release_later(nf._h, None, 0) == 0
+    it = nf.iter_file(str(p), 64)
+    next(it); next(it)
+    it.close()
+    assert nf.lib.mmf_release_later(nf._h, None, 0) == 0
+    spans = nf.iter_spans(str(p), 64)
+    next(spans); next(spans)                                    # two batches handed out, the first one's range queued ...
+    assert nf.lib.mmf_release_later(nf._h, None, 0) >= 1       # ... (this is what used to survive the unmap)
+    spans.close()
