@@ -101,7 +101,7 @@ def decode_threads_for(world: int) -> int:
 
 
 def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: bool = False, batch_pairs: int = 32768, threads: int = 0,
-                      ramp: int = 1024, shard=None, shard_by: str = "bytes"):
+                      ramp: int = 1024, shard=None, shard_by: str = "bytes", stats: dict = None):
     """TSV file -> (query_id, product_id, score) with the three stages overlapped:
 
       producer thread   libmmfeat decodes batch i+2 into one of three pinned buffer sets (ctypes releases the GIL)
@@ -147,8 +147,13 @@ def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: boo
     th.start()
     copy_stream = torch.cuda.Stream(dev)
     qids, pids, scores = [], [], []
+    import time
+    clock = time.perf_counter
+    t_get = t_h2d = t_enq = 0.0                  # host seconds waiting for a decoded batch / for its H2D copy / enqueueing its kernels (``stats``)
     while True:
+        t0 = clock()
         b = q.get()
+        t_get += clock() - t0
         if b is None:
             break
         if isinstance(b, BaseException):
@@ -158,15 +163,22 @@ def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: boo
         with torch.cuda.stream(copy_stream):
             d = {k: (torch.from_numpy(v).to(dev, non_blocking=True) if isinstance(v, np.ndarray) and v.dtype.kind in "fiu" else v)
                  for k, v in b.items() if k not in ("query_id", "product_id", "keep")}
+        t0 = clock()
         copy_stream.synchronize()        # the pinned set may be refilled from here on; the main stream is still busy with batch i
+        t1 = clock()
         _, probs = score_batch(scorer, d)
+        t_h2d += t1 - t0
+        t_enq += clock() - t1
         for t in d.values():             # allocated on the copy stream, consumed on the main one: defer reuse of the memory
             if torch.is_tensor(t):
                 t.record_stream(torch.cuda.current_stream(dev))
         scores.append(probs[:, 1])
     th.join()
     cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+    t0 = clock()
     score = torch.cat(scores).float().cpu().numpy() if scores else np.zeros(0, np.float32)
+    if stats is not None:
+        stats.update(wait_decode_s=t_get, wait_h2d_s=t_h2d, enqueue_s=t_enq, drain_s=clock() - t0, batches=len(scores), featurizer=dict(nf.stats))
     if shard is not None:
         return cat(qids, np.int64), cat(pids, np.int64), score, counts
     return cat(qids, np.int64), cat(pids, np.int64), score

@@ -66,9 +66,11 @@ for th in threads_list:
     for bp in (8192, 16384):
         for _ in range(3):
             torch.cuda.synchronize(); t0 = time.time()
-            qid, pid, score = pipeline.stream_scores_tsv(sc, path, VOCAB, TABLE, batch_pairs=bp, threads=th)
+            stt = {}
+            qid, pid, score = pipeline.stream_scores_tsv(sc, path, VOCAB, TABLE, batch_pairs=bp, threads=th, stats=stt)
             torch.cuda.synchronize(); dt = time.time() - t0
-        print("TSV -> scores, batch %d, threads %s: %.0f pairs/s (%d pairs, %.2f s)" % (bp, th or "default", len(score) / dt, len(score), dt), flush=True)
+        print("TSV -> scores, batch %d, threads %s: %.0f pairs/s (%d pairs, %.2f s)  [host ms: waiting for a decoded batch %.0f, for H2D %.0f, enqueueing %.0f, final drain %.0f; %d batches]"
+              % (bp, th or "default", len(score) / dt, len(score), dt, stt["wait_decode_s"] * 1e3, stt["wait_h2d_s"] * 1e3, stt["enqueue_s"] * 1e3, stt["drain_s"] * 1e3, stt["batches"]), flush=True)
 # device-resident rate of the same records (the ceiling of the lines above): the batches of the file, already on the device
 nf = NativeFeaturizer(VOCAB, TABLE, name, pinned=False)
 dev_batches = []
