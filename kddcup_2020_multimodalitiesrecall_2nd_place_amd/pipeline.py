@@ -60,6 +60,17 @@ def kdd_predict(scorer, tsv_lines, label_table, tokenizer, save_path=None, batch
 
 
 _FEATURIZERS: dict = {}
+_COPY_STREAMS: dict = {}
+
+
+def _copy_stream(dev):
+    """ONE H2D stream per device for the life of the process: torch's caching allocator keeps a pool per stream, so a fresh stream per call would reserve
+    a fresh set of batch buffers per call (2.6 GB per pass of stream_scores_tsv, never reused: tools/soak_tsv.py)."""
+    import torch
+    key = (dev.type, dev.index)
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(dev)
+    return _COPY_STREAMS[key]
 
 
 def _cached_featurizer(vocab_path, label_table, model, threads):
@@ -145,7 +156,7 @@ def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: boo
 
     th = threading.Thread(target=produce, daemon=True)
     th.start()
-    copy_stream = torch.cuda.Stream(dev)
+    copy_stream = _copy_stream(dev)
     qids, pids, scores = [], [], []
     import time
     clock = time.perf_counter
@@ -275,7 +286,7 @@ class EnsembleScorer:
         th.start()
         import torch
         dev = self.zk.device
-        copy_stream = torch.cuda.Stream(dev)
+        copy_stream = _copy_stream(dev)
         qids, pids, merged, members = [], [], [], []
         while True:
             item = q.get()
