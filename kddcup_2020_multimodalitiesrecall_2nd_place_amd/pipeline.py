@@ -73,15 +73,15 @@ def _copy_stream(dev):
     return _COPY_STREAMS[key]
 
 
-def _cached_featurizer(vocab_path, label_table, model, threads):
+def _cached_featurizer(vocab_path, label_table, model, threads, want_feats=True, slot=0):
     """One NativeFeaturizer (helper threads + three pinned buffer sets, ~2 GB at 8192-record batches) per (vocabulary, label table, model,
     threads): creating them costs about as much as decoding 30 000 records."""
     from .featurizer_native import NativeFeaturizer
-    key = (os.path.abspath(vocab_path), os.path.getmtime(vocab_path), model, threads, tuple(sorted((int(k), v) for k, v in label_table.items())))
+    key = (os.path.abspath(vocab_path), os.path.getmtime(vocab_path), model, threads, want_feats, slot, tuple(sorted((int(k), v) for k, v in label_table.items())))
     if key not in _FEATURIZERS:
-        if len(_FEATURIZERS) >= 4:
+        if len(_FEATURIZERS) >= 6:
             _FEATURIZERS.pop(next(iter(_FEATURIZERS))).close()
-        _FEATURIZERS[key] = NativeFeaturizer(vocab_path, label_table, model, threads=threads, pinned=True, reuse_buffers=True, pools=3)
+        _FEATURIZERS[key] = NativeFeaturizer(vocab_path, label_table, model, threads=threads, pinned=True, reuse_buffers=True, pools=3, want_feats=want_feats)
     return _FEATURIZERS[key]
 
 
@@ -265,9 +265,10 @@ class EnsembleScorer:
         import queue
         import threading
 
-        from .featurizer_native import NativeFeaturizer
-        mk = lambda m, feats=True: NativeFeaturizer(vocab_path, label_table, m, threads=threads, pinned=True, reuse_buffers=True, pools=3, want_feats=feats)
-        nf_zk, nf_s2f, nf_lx = mk("zk"), mk("zk", False), mk("lxmert", False)      # the fused feed reads the 2048-d features from the first pass only
+        # (kept between calls like stream_scores_tsv's; the fused feed reads the 2048-d features from the first pass only, the other two flavours skip their decode)
+        nf_zk = _cached_featurizer(vocab_path, label_table, "zk", threads)
+        nf_s2f = _cached_featurizer(vocab_path, label_table, "zk", threads, want_feats=False, slot=1)
+        nf_lx = _cached_featurizer(vocab_path, label_table, "lxmert", threads, want_feats=False)
         q = queue.Queue(maxsize=1)          # one decoded batch waiting + one being decoded + one being scored = 3 buffer sets
 
         def produce():
