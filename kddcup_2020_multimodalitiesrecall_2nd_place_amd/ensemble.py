@@ -67,6 +67,69 @@ def top5(merged, filtered):
     return rows
 
 
+def submission_rows(query_id, product_id, score, gap=GAP, tie=TIE):
+    """``top5(tab, uniqueness_filter(tab))`` for the table ``tab[q][p] = score`` given as three parallel arrays (one row per (query, product) pair, rows of a
+    query in any order, first appearance = the table's query order) -- the same rows as the dict walk, computed with sorts instead of 10^5 dict operations
+    (0.24 s -> ~20 ms for 120 000 pairs: a tenth of config 5's file-to-submission time was this Python loop).  Equal to the dict form on the reference's
+    own tables and on random tables with ties (tests/test_ensemble_ndcg.py).  A (query, product) pair that occurs twice keeps its LAST score, like the dict."""
+    import numpy as np
+    q = np.asarray(query_id).astype(np.int64)
+    p = np.asarray(product_id).astype(np.int64)
+    s = np.asarray(score, np.float64)
+    n = len(q)
+    if n == 0:
+        return OrderedDict()
+    # table semantics: a repeated (q, p) overwrites the value but keeps its first position
+    key = np.stack([q, p], 1)
+    _, first_idx, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    inv = inv.reshape(-1)
+    if len(first_idx) != n:
+        last = np.zeros(len(first_idx), np.int64)
+        last[inv] = np.arange(n)                       # later rows win
+        keep = np.sort(first_idx)
+        s = s.copy()
+        s[first_idx[inv]] = s[last[inv]]
+        q, p, s = q[keep], p[keep], s[keep]
+        n = len(q)
+    # per product: best and second-best score over all queries
+    order = np.lexsort((-s, p))
+    ps, ss = p[order], s[order]
+    start = np.flatnonzero(np.r_[True, ps[1:] != ps[:-1]])
+    size = np.diff(np.r_[start, n])
+    best = ss[start]
+    second = np.where(size >= 2, ss[np.minimum(start + 1, n - 1)], -np.inf)
+    keep_product = (size < 2) | ~(best - second < gap)
+    grp = np.repeat(np.arange(len(start)), size)
+    pos = np.empty(n, np.int64)
+    pos[order] = grp                                   # row -> its product group
+    survive = keep_product[pos] & (np.abs(s - best[pos]) < tie)
+    # queries in first-appearance order; within a query a stable sort by descending score (sorted(..., reverse=True) keeps the order of equal scores)
+    uq, qfirst, qinv = np.unique(q, return_index=True, return_inverse=True)
+    qinv = qinv.reshape(-1)
+    n_surv = np.bincount(qinv[survive], minlength=len(uq))
+    rows, short = OrderedDict(), []
+    rank = np.lexsort((np.arange(n), -s, qinv))        # by query, then score descending, then original position
+    qs = qinv[rank]
+    qstart = np.flatnonzero(np.r_[True, qs[1:] != qs[:-1]])
+    qend = np.r_[qstart[1:], n]
+    seg = {int(qs[a]): (a, b) for a, b in zip(qstart, qend)}
+    surv_sorted = survive[rank]
+    # the filtered table holds the queries that have a survivor, in the table's own query order (= first appearance of the query)
+    for qi in np.argsort(qfirst, kind="stable"):
+        if n_surv[qi] == 0:
+            continue                                   # no survivor: the reference never writes that query (main.py:91-104 walks the filtered table only)
+        a, b = seg[int(qi)]
+        if n_surv[qi] >= 5:
+            r = rank[a:b][surv_sorted[a:b]][:5]
+            rows[str(int(uq[qi]))] = [str(int(x)) for x in p[r]]
+        else:
+            short.append(qi)
+    for qi in short:
+        a, b = seg[int(qi)]
+        rows[str(int(uq[qi]))] = [str(int(x)) for x in p[rank[a:b][:5]]]
+    return rows
+
+
 def ensemble(zk, zk_s2f, lds, lxmert):
     merged = merge_scores(zk, zk_s2f, lds, lxmert)
     return top5(merged, uniqueness_filter(merged))

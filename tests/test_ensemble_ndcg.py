@@ -81,3 +81,49 @@ def test_score_file_protocol_roundtrip(tmp_path):
     for line in open(os.path.join(ENS, "testBscore_imagebert.txt")).read().splitlines()[:200]:
         qq, pp, ss = line.split("\t")
         assert "%s\t%s\t%s" % (qq, pp, scorefile._fmt(float(ss))) == line
+
+
+def _rows_of_table(tab):
+    q, p, s = [], [], []
+    for qq, d in tab.items():
+        for pp, v in d.items():
+            q.append(int(qq)); p.append(int(pp)); s.append(v)
+    return np.array(q), np.array(p), np.array(s)
+
+
+def test_array_form_of_filter_and_top5_equals_the_dict_walk():
+    """ensemble.submission_rows (sorts over three arrays) against top5(uniqueness_filter(.)) (the reference's dict walk): the reference's own merged testB table,
+    and random tables with recurring products, exact ties, queries of fewer than 5 candidates, queries without a survivor, repeated (query, product) rows."""
+    merged = ensemble.merge_scores(*_tables())
+    want = ensemble.top5(merged, ensemble.uniqueness_filter(merged))
+    got = ensemble.submission_rows(*_rows_of_table(merged))
+    assert list(got) == list(want) and got == {q: list(v) for q, v in want.items()}
+    rng = np.random.default_rng(3)
+    for trial in range(30):
+        nq = int(rng.integers(1, 40))
+        tab = {}
+        for qi in rng.permutation(nq):
+            k = int(rng.integers(1, 12))
+            prods = rng.choice(60 if trial % 2 else 4000, k, replace=False)
+            sc = np.round(rng.random(k), 1 if trial % 3 == 0 else 6)              # coarse scores: ties inside a query and across queries
+            if trial % 5 == 0:
+                sc[: k // 2] = 0.97                                               # best == second best of a product: the 0.92 gap rule bites
+            tab[str(100 + int(qi))] = {str(int(a)): float(b) for a, b in zip(prods, sc)}
+        want = ensemble.top5(tab, ensemble.uniqueness_filter(tab))
+        q, p, s = _rows_of_table(tab)
+        got = ensemble.submission_rows(q, p, s)
+        assert list(got) == list(want) and got == {k_: list(v) for k_, v in want.items()}, trial
+        if len(q) > 3:                                                            # a repeated pair: the last score wins, the first position stays
+            q2, p2, s2 = np.r_[q, q[1]], np.r_[p, p[1]], np.r_[s, 0.5]
+            tab2 = {k_: dict(v) for k_, v in tab.items()}
+            tab2[str(q[1])][str(p[1])] = 0.5
+            assert ensemble.submission_rows(q2, p2, s2) == {k_: list(v) for k_, v in ensemble.top5(tab2, ensemble.uniqueness_filter(tab2)).items()}
+    assert ensemble.submission_rows([], [], []) == {}
+    # rows of different queries interleaved: the table's query order is the order of first appearance, a query's candidates keep their relative order
+    perm = rng.permutation(len(q))
+    tab3 = {}
+    for a_, b_, c_ in zip(q[perm], p[perm], s[perm]):
+        tab3.setdefault(str(a_), {})[str(b_)] = float(c_)
+    want = ensemble.top5(tab3, ensemble.uniqueness_filter(tab3))
+    got = ensemble.submission_rows(q[perm], p[perm], s[perm])
+    assert list(got) == list(want) and got == {k_: list(v) for k_, v in want.items()}

@@ -43,10 +43,7 @@ if name == "ensemble":      # BASELINE.json config 5: TSV -> four score tables -
         torch.cuda.synchronize(); t0 = time.time()
         qid, pid, merged, parts = ens.score_tsv_native(path, VOCAB, TABLE, batch_pairs=16384)
         t1 = time.time()
-        tab = OrderedDict()
-        for q, p_, m_ in zip(qid, pid, merged):
-            tab.setdefault(str(int(q)), OrderedDict())[str(int(p_))] = float(m_)
-        rows = E.top5(tab, E.uniqueness_filter(tab))
+        rows = E.submission_rows(qid, pid, merged)          # uniqueness filter + top-5 (main.py:64-104) on the three arrays
         E.write_submission("/tmp/e2e_submission.csv", rows)
         dt = time.time() - t0
     print("TSV -> 4 score tables -> submission.csv: %.0f pairs/s end to end (%d pairs, %d queries; scoring %.2f s, post-process %.2f s)"
