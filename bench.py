@@ -689,7 +689,7 @@ def tsv_pipeline_rate(scorer, records=120000):
             "host_ms": host,      # of the best pass: waiting for a decoded batch / for its H2D copy / enqueueing (incl. the call's one read-back) / final drain
             "note": "TSV file (%d records, %.2f GB) -> native featurizer threads -> pinned buffers -> H2D on a copy stream -> scorer, all "
                     "overlapped (pipeline.stream_scores_tsv, batches of 16384 after a 1024 / 2048 / 4096 / 8192 ramp); %d host threads, the decode on "
-                    "up to 64 of them" % (records, size / 1e9, os.cpu_count())}
+                    "up to 32 of them" % (records, size / 1e9, os.cpu_count())}
 
 
 def secondary(a, local, dev, ps, feats, members, scorer, feed, value):

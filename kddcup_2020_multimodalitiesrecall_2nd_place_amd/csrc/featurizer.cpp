@@ -109,10 +109,10 @@ void b64_bulk_avx512(const unsigned char* u, int64_t n, unsigned char* out, int6
     }
 }
 
-// threads <= 0: every hardware thread up to MMF_MAX_DEFAULT_THREADS.  On the 2 x 64-core / 256-thread host of the MI355X box 32 .. 128
-// threads decode 470 .. 680 k records/s depending on the box and the run; 256 are slower (a 8192-record call is ~3 ms of work per thread
-// at that width, less than it takes to wake them): profiles/rd6_feat_sweep.txt
-constexpr int MMF_MAX_DEFAULT_THREADS = 64;
+// threads <= 0: every hardware thread up to MMF_MAX_DEFAULT_THREADS.  On the 2 x 64-core / 256-thread host of the MI355X box 32 threads decode
+// 580 .. 790 k records/s, 64 threads 470 .. 680 k, 128 threads 375 .. 610 k depending on the box and the run, 256 are always slower (a 8192-record
+// call is ~3 ms of work per thread at that width, less than it takes to wake them): profiles/rd6_feat_sweep.txt, rd6_e2e_tsv.txt
+constexpr int MMF_MAX_DEFAULT_THREADS = 32;
 inline int default_threads() {
     const int hw = (int)std::thread::hardware_concurrency();
     return hw < 1 ? 1 : hw > MMF_MAX_DEFAULT_THREADS ? MMF_MAX_DEFAULT_THREADS : hw;

@@ -104,11 +104,11 @@ def tsv_shard(nf, tsv_path, rank: int, world: int):
 
 def decode_threads_for(world: int) -> int:
     """libmmfeat threads of ONE rank when ``world`` ranks share the host (one featurizer per rank, each decoding only its shard): half of an equal share
-    of the physical cores, at most the single-consumer default (64), at least 4 -- on the MI355X box's 128-core host 64 / 32 / 16 / 8 threads for 1 / 2 / 4 /
+    of the physical cores, at most the single-consumer default (32), at least 4 -- on the MI355X box's 128-core host 32 / 32 / 16 / 8 threads for 1 / 2 / 4 /
     8 ranks.  More is slower there: eight ranks decode 763 / 584-690 / 400 k records/s in all with 8 / 16 / 32 threads each (profiles/rd6_feat_sweep.txt)."""
     import os as _os
     cpus = len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else (_os.cpu_count() or 8)
-    return int(max(4, min(64, cpus // 4 // max(world, 1))))
+    return int(max(4, min(32, cpus // 4 // max(world, 1))))
 
 
 def stream_scores_tsv(scorer, tsv_path, vocab_path, label_table, sen2forest: bool = False, batch_pairs: int = 32768, threads: int = 0,
